@@ -1,0 +1,115 @@
+"""Spec + state-dict front end of the CPU oracle (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+A model is described by a plain ``spec`` dict and a ``state`` dict of *unconstrained* numpy arrays (the
+free variables GPflow would optimise):
+
+spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass", "num_classes": K,
+         "layers": [{"kind": "rbf"|"matern52", "input_dim": D_in, "ARD": bool, "has_white": bool,
+                     "mean": "zero"|"identity"|"linear", "mean_A": ndarray|None}, ...]}
+state = {"l{i}.Z": (M,D_in), "l{i}.q_mu": (M,D_out), "l{i}.q_sqrt": (D_out,M,M)  [tril part is the free var],
+         "l{i}.kern_variance_raw": (), "l{i}.kern_lengthscales_raw": () or (D_in,),
+         "l{i}.white_variance_raw": () [if has_white], "lik_variance_raw": () [gaussian]}
+"""
+import math
+import numpy as np
+
+from . import dgp_oracle as O
+
+
+def constrained_to_raw(y):
+    return O.positive_backward_np(y)
+
+
+def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
+    """layer_dicts as produced by dgp_oracle.init_layers_linear -> (spec_layers, state)."""
+    spec_layers, state = [], {}
+    for i, ld in enumerate(layer_dicts):
+        k = ld["kern"]
+        spec_layers.append(dict(kind=k.kind, input_dim=k.input_dim, ARD=k.ARD,
+                                has_white=k.white_variance is not None,
+                                mean=ld["mean"].kind, mean_A=ld["mean"].A))
+        state[f"l{i}.Z"] = np.array(ld["Z"], dtype=np.float64)
+        state[f"l{i}.q_mu"] = np.array(ld["q_mu"], dtype=np.float64)
+        state[f"l{i}.q_sqrt"] = np.array(ld["q_sqrt"], dtype=np.float64)
+        state[f"l{i}.kern_variance_raw"] = np.array(constrained_to_raw(k.variance))
+        ls = np.asarray(k.lengthscales, dtype=np.float64)
+        if k.ARD and ls.ndim == 0:
+            ls = np.full((k.input_dim,), float(ls))
+        state[f"l{i}.kern_lengthscales_raw"] = np.array(constrained_to_raw(ls))
+        if k.white_variance is not None:
+            state[f"l{i}.white_variance_raw"] = np.array(constrained_to_raw(k.white_variance))
+    if likelihood == "gaussian":
+        state["lik_variance_raw"] = np.array(constrained_to_raw(lik_variance))
+    return spec_layers, state
+
+
+def build(xp, spec, state, num_samples=1, num_data=None):
+    """Instantiate the oracle model under backend ``xp`` from (spec, state)."""
+    layers = []
+    for i, ls in enumerate(spec["layers"]):
+        g = lambda n: xp.asarray(state[f"l{i}.{n}"])
+        kern = O.Kern(ls["kind"], ls["input_dim"],
+                      variance=O.positive_forward(xp, g("kern_variance_raw")),
+                      lengthscales=O.positive_forward(xp, g("kern_lengthscales_raw")),
+                      ARD=ls["ARD"],
+                      white_variance=(O.positive_forward(xp, g("white_variance_raw"))
+                                      if ls.get("has_white") else None))
+        mf = O.MeanFn(ls["mean"], A=ls.get("mean_A"))
+        layers.append(O.SVGPLayer(kern, g("Z"), g("q_mu"), g("q_sqrt"), mf,
+                                  white=spec["white"], jitter=spec["jitter"]))
+    if spec["likelihood"] == "gaussian":
+        lik = O.Gaussian(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
+    else:
+        lik = O.MultiClass(spec["num_classes"])
+    return O.DGPOracle(layers, lik, num_samples=num_samples, num_data=num_data)
+
+
+def elbo(spec, state, X, Y, zs, num_samples, num_data=None):
+    m = build(O.NP, spec, state, num_samples, num_data)
+    return float(m.build_likelihood(O.NP, np.asarray(X, float), np.asarray(Y, float), zs))
+
+
+def elbo_and_grad(spec, state, X, Y, zs, num_samples, num_data=None):
+    """ELBO and d(ELBO)/d(state) via torch CPU float64 autograd on the identical op sequence
+    (stands in for tf.gradients [UPSTREAM]).  q_sqrt gradients are lower-triangular by construction."""
+    import torch
+    leaves = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in state.items()}
+    m = build(O.TH, spec, leaves, num_samples, num_data)
+    zs_t = [None if z is None else torch.as_tensor(np.asarray(z, dtype=np.float64)) for z in zs]
+    val = m.build_likelihood(O.TH, torch.as_tensor(np.asarray(X, float)), torch.as_tensor(np.asarray(Y, float)), zs_t)
+    val.backward()
+    grads = {k: (t.grad.numpy().copy() if t.grad is not None else np.zeros_like(state[k])) for k, t in leaves.items()}
+    return float(val.detach()), grads
+
+
+def propagate(spec, state, X, zs, S, full_cov=False):
+    m = build(O.NP, spec, state, S)
+    return m.propagate(O.NP, np.asarray(X, float), zs, full_cov=full_cov, S=S)
+
+
+def make_synthetic(name, seed=0):
+    """Synthetic datasets of SURVEY §8d shapes (real UCI/MNIST data cannot be downloaded)."""
+    rng = np.random.default_rng(seed)
+    if name == "kin8nm":
+        n, d = 7372, 8
+    elif name == "protein":
+        n, d = 41157, 9
+    elif name == "tiny":
+        n, d = 200, 3
+    else:
+        raise ValueError(name)
+    X = rng.standard_normal((n, d))
+    w1, w2 = rng.standard_normal(d), rng.standard_normal(d)
+    Y = np.sin(X @ w1) + 0.1 * (X @ w2) ** 2 + 0.1 * rng.standard_normal(n)
+    Y = ((Y - Y.mean()) / (Y.std() + 1e-6))[:, None]
+    return X, Y
+
+
+def default_Z(X, M, seed=0):
+    """kmeans2(minit='points') as demos/run_regression.py:57, with a permutation fallback."""
+    try:
+        from scipy.cluster.vq import kmeans2
+        return kmeans2(X, M, minit="points", seed=seed)[0]
+    except Exception:
+        rng = np.random.default_rng(seed)
+        return X[rng.permutation(X.shape[0])[:M]].copy()
