@@ -1,0 +1,161 @@
+// Shared host/device helpers of libdsdgp (gfx950 / CDNA4 only; fp64 throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/dsdgp.h"
+
+// ------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------
+void dsdgp_set_error(const char* fmt, ...);
+
+#define DS_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      dsdgp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return DSDGP_ERR_HIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+#define DS_CHECK_ARG(cond)                                                  \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      dsdgp_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+      return DSDGP_ERR_BAD_ARG;                                             \
+    }                                                                       \
+  } while (0)
+
+#define DS_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != DSDGP_OK) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------------
+// context: one per (host thread, device); owns the stream (unless borrowed) and a grow-only scratch used by the
+// *primitive* entry points only (the model path runs entirely inside the caller's workspace).
+// ------------------------------------------------------------------------------------------------------
+struct ProfSlot {
+  double ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct dsdgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  int prof_on = 0;
+  std::map<std::string, ProfSlot> prof;
+};
+
+int ctx_scratch(dsdgp_ctx* ctx, size_t bytes, void** out);
+
+// RAII-ish profiling bracket: records HIP events on the ctx stream around a launch when profiling is enabled.
+struct ProfScope {
+  dsdgp_ctx* ctx;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(dsdgp_ctx* c, const char* n) : ctx(c), name(n) {
+    if (ctx->prof_on) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ProfScope() {
+    if (a) {
+      hipEventRecord(b, ctx->stream);
+      ctx->prof[name].pending.push_back({a, b});
+    }
+  }
+};
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Padded inducing count used by every device-side M x M operand: next of {32,64,128,256,...} (power of two >= 32)
+// so that the register-resident chain kernels exist as a handful of template instances.
+static inline int pad_M(int M) {
+  int p = 32;
+  while (p < M) p *= 2;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), wave64.
+//   lane l: g = l>>4, c = l&15.   A operand = A[i=c][k=g];  B operand = B[k=g][j=c];
+//   D reg t (0..3) = D[row = g + 4t][col = c].
+// Note the D layout of a 16x16 block *is* the B-operand layout of four consecutive k-steps (k = g + 4t), which is
+// what lets the layer chain feed one GEMM's result straight into the next without touching LDS.
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// sum over the four 16-lane groups (same c): afterwards every lane holds the total for its column c.
+__device__ __forceinline__ double sum_groups(double x) {
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+// full 64-lane sum
+__device__ __forceinline__ double sum_wave(double x) {
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  x += __shfl_xor(x, 8, 64);
+  return sum_groups(x);
+}
+
+// hyper-parameter block layout (device doubles) produced by k_prep for every layer:
+//   hyp[0]=variance hyp[1]=white_variance hyp[2]=kdiag (=variance+white) hyp[3]=sigmoid(raw var) hyp[4]=sigmoid(raw white)
+//   hyp[8 + j]            = 1/lengthscale_j                   (j < D_in)
+//   hyp[8 + D_in + j]     = sigmoid(raw lengthscale_j)        (chain rule of the softplus transform)
+#define HYP_VAR 0
+#define HYP_WVAR 1
+#define HYP_KDIAG 2
+#define HYP_DVAR 3
+#define HYP_DWVAR 4
+#define HYP_ILS 8
+
+// stationary kernel value and d k / d r2 from the scaled squared distance r2 (variance included).
+//   RBF      [UPSTREAM]: k = s2 exp(-r2/2)
+//   Matern52 [UPSTREAM]: r = sqrt(r2 + 1e-12); k = s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)
+template <int KIND>
+__device__ __forceinline__ double kern_val(double r2, double s2) {
+  if (KIND == DSDGP_KERN_RBF) return s2 * exp(-0.5 * r2);
+  const double s5 = 2.23606797749978969641;
+  double r = sqrt(r2 + 1e-12);
+  return s2 * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+}
+template <int KIND>
+__device__ __forceinline__ void kern_val_grad(double r2, double s2, double& k, double& dk) {
+  if (KIND == DSDGP_KERN_RBF) {
+    k = s2 * exp(-0.5 * r2);
+    dk = -0.5 * k;
+    return;
+  }
+  const double s5 = 2.23606797749978969641;
+  double r = sqrt(r2 + 1e-12);
+  double e = s2 * exp(-s5 * r);
+  k = (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * e;
+  dk = -(5.0 / 6.0) * (1.0 + s5 * r) * e;
+}
+__device__ __forceinline__ double kern_val_rt(int kind, double r2, double s2) {
+  return kind == DSDGP_KERN_RBF ? kern_val<DSDGP_KERN_RBF>(r2, s2) : kern_val<DSDGP_KERN_MATERN52>(r2, s2);
+}
+#endif

@@ -1,0 +1,102 @@
+// Context, error reporting, scratch and HIP-event profiling of libdsdgp.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+static thread_local char g_err[1024] = "";
+
+void dsdgp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dsdgp_last_error(void) { return g_err; }
+extern "C" int dsdgp_version(void) { return 100; }
+
+extern "C" int dsdgp_ctx_create(dsdgp_ctx** out, int device, void* stream) {
+  DS_CHECK_ARG(out != nullptr);
+  int ndev = 0;
+  DS_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) {
+    dsdgp_set_error("no HIP device visible: libdsdgp has no CPU fallback");
+    return DSDGP_ERR_HIP;
+  }
+  DS_CHECK_ARG(device >= 0 && device < ndev);
+  DS_HIP(hipSetDevice(device));
+  dsdgp_ctx* c = new dsdgp_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    DS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  *out = c;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_ctx_destroy(dsdgp_ctx* ctx) {
+  if (!ctx) return DSDGP_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->prof)
+    for (auto& ev : kv.second.pending) {
+      hipEventDestroy(ev.first);
+      hipEventDestroy(ev.second);
+    }
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_sync(dsdgp_ctx* ctx) {
+  DS_CHECK_ARG(ctx != nullptr);
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  return DSDGP_OK;
+}
+
+int ctx_scratch(dsdgp_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) DS_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    const size_t want = round_up(bytes, 1 << 20);
+    DS_HIP(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_prof_enable(dsdgp_ctx* ctx, int on) {
+  DS_CHECK_ARG(ctx != nullptr);
+  ctx->prof_on = on;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_prof_read(dsdgp_ctx* ctx, const char* name, double* total_ms, int64_t* launches, int reset) {
+  DS_CHECK_ARG(ctx && name);
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  ProfSlot& s = ctx->prof[name];
+  for (auto& ev : s.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      s.ms += ms;
+      s.launches += 1;
+    }
+    hipEventDestroy(ev.first);
+    hipEventDestroy(ev.second);
+  }
+  s.pending.clear();
+  if (total_ms) *total_ms = s.ms;
+  if (launches) *launches = s.launches;
+  if (reset) {
+    s.ms = 0.0;
+    s.launches = 0;
+  }
+  return DSDGP_OK;
+}

@@ -1,0 +1,82 @@
+// Thin elementwise / gather entry points around the hot path (minibatch gather, Gaussian likelihood wrappers).
+#include "common.hpp"
+
+__global__ void k_gather_rows(const double* __restrict__ src, int64_t cols, const int64_t* __restrict__ idx, int64_t n,
+                              double* __restrict__ dst) {
+  const int64_t total = n * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    dst[i] = src[idx[r] * cols + c];
+  }
+}
+
+extern "C" int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols, const int64_t* idx, int64_t n,
+                                 int64_t idx_offset, double* dst) {
+  DS_CHECK_ARG(ctx && src && idx && dst && n > 0 && cols > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(n * cols, 256));
+  hipLaunchKernelGGL(k_gather_rows, dim3(nb), dim3(256), 0, ctx->stream, src, cols, idx + idx_offset, n, dst);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// mode 0: mean_s variational expectation ; mode 1: logsumexp_s predictive log density - log S
+__global__ void k_gauss_over_samples(const double* __restrict__ mean, const double* __restrict__ var,
+                                     const double* __restrict__ Y, int64_t n, int S, int DY, double s2, int mode,
+                                     double* __restrict__ out) {
+  const int64_t total = n * DY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const double y = Y[i];
+    if (mode == 0) {
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double mu = mean[(int64_t)s * total + i], v = var[(int64_t)s * total + i];
+        acc += -0.91893853320467274178 - 0.5 * log(s2) - 0.5 * ((y - mu) * (y - mu) + v) / s2;
+      }
+      out[i] = acc / S;
+    } else {
+      double mx = -1.0 / 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double mu = mean[(int64_t)s * total + i], v = var[(int64_t)s * total + i] + s2;
+        const double l = -0.91893853320467274178 - 0.5 * log(v) - 0.5 * (y - mu) * (y - mu) / v;
+        mx = l > mx ? l : mx;
+      }
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double mu = mean[(int64_t)s * total + i], v = var[(int64_t)s * total + i] + s2;
+        const double l = -0.91893853320467274178 - 0.5 * log(v) - 0.5 * (y - mu) * (y - mu) / v;
+        acc += exp(l - mx);
+      }
+      out[i] = mx + log(acc) - log((double)S);
+    }
+  }
+}
+
+static int gauss_over_samples(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int S,
+                              int DY, double s2, int mode, double* out) {
+  DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && s2 > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
+  hipLaunchKernelGGL(k_gauss_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, s2, mode, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_gauss_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
+                                   int32_t S, int32_t DY, double lik_var, double* out) {
+  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 0, out);
+}
+extern "C" int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y,
+                                           int64_t n, int32_t S, int32_t DY, double lik_var, double* out) {
+  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 1, out);
+}
+
+__global__ void k_add_scalar(const double* __restrict__ in, double v, int64_t count, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[i] + v;
+}
+extern "C" int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out) {
+  DS_CHECK_ARG(ctx && in && out && count > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
+  hipLaunchKernelGGL(k_add_scalar, dim3(nb), dim3(256), 0, ctx->stream, in, value, count, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}

@@ -1,0 +1,449 @@
+// SVGP_Layer hot path (layers.py:178-219 conditional_ND, utils.py:40-41 reparameterize) as register-resident fp64-MFMA
+// chains on gfx950.
+//
+// Orientation: everything is kept "M-major" — a wavefront owns 16 data rows r (MFMA columns) and the full padded
+// inducing dimension Mp (MFMA rows).  With  Kuf[:, r] = k_r  the layer is
+//     a1 = Lu^{-1} k ,  a = Lu^{-T} a1 ,  c_d = q_sqrt_d^T a ,
+//     mean_d = a . q_mu[:,d] + m(x) ,  var_d = kdiag - |a1|^2 + |c_d|^2 ,  F_d = mean_d + z sqrt(var_d + jitter)
+// (the "cheaper equivalent form" of SURVEY Appendix A.6 — algebraically identical to the reference's
+//  SK = q_sqrt q_sqrt^T - Ku,  B = SK A,  sum(A∘B), but all three products are triangular MFMA products and the
+//  D x M x R intermediates A_tiled / B never exist).  The weights (Lu^{-T}, Lu^{-1}, q_sqrt_d) stream from L2 as MFMA
+// A-operands with 128-B coalesced reads; the activations never leave registers because the D layout of
+// v_mfma_f64_16x16x4_f64 (row = 4*reg + lane/16) is exactly the B-operand layout of the next product's four k-steps.
+#include "layer.hpp"
+
+size_t layer_fwd_lds_bytes(int Mp, int D_in) { return (size_t)(Mp * D_in + 4 * 16 * (D_in + 1)) * sizeof(double); }
+
+// scaled squared distances between the wave's 16 rows (LDS xs, lane column c) and all Mp inducing points (LDS zs),
+// in D layout: r2[kb][t] <-> m = 16 kb + g + 4 t.
+template <int MPB>
+__device__ __forceinline__ void sqdist_tile(const double* __restrict__ zs, const double* __restrict__ xs, int Din, int g,
+                                            int c, d4 (&r2)[MPB]) {
+#pragma unroll
+  for (int kb = 0; kb < MPB; ++kb) r2[kb] = (d4){0, 0, 0, 0};
+  for (int j = 0; j < Din; ++j) {
+    const double xv = xs[c * (Din + 1) + j];
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double df = zs[(16 * kb + g + 4 * t) * Din + j] - xv;
+        r2[kb][t] = fma(df, df, r2[kb][t]);
+      }
+  }
+}
+
+template <int MPB, int KIND, bool WHITE>
+__global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int Mp = MPB * 16;
+  const int Din = a.D_in;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  double* zs = smem;
+  double* xs = smem + Mp * Din + wave * 16 * (Din + 1);
+  const double* ils = a.hyp + HYP_ILS;
+  for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  for (int idx = lane; idx < 16 * Din; idx += 64) {
+    const int rr = idx / Din, j = idx % Din;
+    int64_t row = r0 + rr;
+    if (row > a.Rin - 1) row = a.Rin - 1;
+    xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
+  }
+  __syncthreads();
+  if (r0 >= a.Rin) return;
+  const int64_t r = r0 + c;
+  const bool rvalid = r < a.Rin;
+  const int64_t rc = rvalid ? r : a.Rin - 1;
+  const double s2 = a.hyp[HYP_VAR];
+
+  // --- Kuf tile (layers.py:184) in registers
+  d4 kreg[MPB];
+  sqdist_tile<MPB>(zs, xs, Din, g, c, kreg);
+#pragma unroll
+  for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      kreg[kb][t] = (16 * kb + g + 4 * t < a.M) ? kern_val<KIND>(kreg[kb][t], s2) : 0.0;
+
+  // --- a1 = Lu^{-1} k   (layers.py:186)   A-operand element [i][k] = Linv[i][k] = LinvT[k][i]
+  d4 a1[MPB];
+#pragma unroll
+  for (int ib = 0; ib < MPB; ++ib) a1[ib] = (d4){0, 0, 0, 0};
+  {
+    const double* __restrict__ pT = a.LinvT + g * Mp + c;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = kreg[kb][s];
+#pragma unroll
+        for (int ib = kb; ib < MPB; ++ib) a1[ib] = mfma_f64(pT[(16 * kb + 4 * s) * Mp + 16 * ib], bv, a1[ib]);
+      }
+  }
+  double s1 = 0.0;
+#pragma unroll
+  for (int ib = 0; ib < MPB; ++ib)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s1 = fma(a1[ib][t], a1[ib][t], s1);
+  s1 = sum_groups(s1);
+
+  // --- a = Lu^{-T} a1   (layers.py:188, non-white)   A-operand element [i][k] = Linv[k][i]
+  d4 av[MPB];
+  if (WHITE) {
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib) av[ib] = a1[ib];
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib) av[ib] = (d4){0, 0, 0, 0};
+    const double* __restrict__ pL = a.Linv + g * Mp + c;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = a1[kb][s];
+#pragma unroll
+        for (int ib = 0; ib <= kb; ++ib) av[ib] = mfma_f64(pL[(16 * kb + 4 * s) * Mp + 16 * ib], bv, av[ib]);
+      }
+  }
+  if (a.Asave) {
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = rvalid ? av[ib][t] : 0.0;
+  }
+
+  const double kdiag = a.hyp[HYP_KDIAG];
+  for (int d = 0; d < a.D_out; ++d) {
+    // --- c_d = q_sqrt_d^T a ; |c_d|^2   (replaces SK/B of layers.py:195-212)
+    d4 cacc[MPB];
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib) cacc[ib] = (d4){0, 0, 0, 0};
+    const double* __restrict__ pTd = a.Tp + (int64_t)d * Mp * Mp + g * Mp + c;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = av[kb][s];
+#pragma unroll
+        for (int ib = 0; ib <= kb; ++ib) cacc[ib] = mfma_f64(pTd[(16 * kb + 4 * s) * Mp + 16 * ib], bv, cacc[ib]);
+      }
+    double s2sum = 0.0, mu = 0.0;
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s2sum = fma(cacc[ib][t], cacc[ib][t], s2sum);
+        mu = fma(av[ib][t], a.qmu[(16 * ib + g + 4 * t) * a.D_out + d], mu);   // layers.py:190
+      }
+    s2sum = sum_groups(s2sum);
+    mu = sum_groups(mu);
+    const double var = kdiag - s1 + s2sum;                                     // layers.py:212-217
+    if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                                  // layers.py:219
+      mu += a.X[rc * Din + d];
+    } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+      double acc = 0.0;
+      for (int j = 0; j < Din; ++j) acc = fma(a.X[rc * Din + j], a.mean_A[j * a.D_out + d], acc);
+      mu += acc;
+    }
+    if (rvalid) {
+      for (int s = g; s < a.rep; s += 4) {
+        const int64_t o = ((int64_t)s * a.Rin + r) * a.D_out + d;
+        if (a.mean) a.mean[o] = mu;
+        if (a.var) a.var[o] = var;
+        if (a.F && a.z) {
+          const double zv = a.z[s * a.zs_s + r * a.zs_n + d * a.zs_d];
+          a.F[o] = mu + zv * sqrt(var + a.jitter);                             // utils.py:41 (no clamp)
+        }
+      }
+    }
+  }
+}
+
+template <int MPB, int KIND>
+static int fwd_dispatch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int white) {
+  const int Mp = MPB * 16;
+  const size_t lds = layer_fwd_lds_bytes(Mp, a.D_in);
+  if (lds > 64 * 1024) {
+    dsdgp_set_error("layer_fwd: D_in=%d with M_pad=%d needs %zu B LDS (>64 KiB): large-D_in path not built yet", a.D_in,
+                    Mp, lds);
+    return DSDGP_ERR_UNSUPPORTED;
+  }
+  const int nblk = ceil_div(a.Rin, 64);
+  ProfScope ps(ctx, "layer_fwd");
+  if (white)
+    hipLaunchKernelGGL((k_layer_fwd<MPB, KIND, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((k_layer_fwd<MPB, KIND, false>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white) {
+#define FWD_CASE(MPB)                                                                           \
+  case MPB * 16:                                                                                \
+    return kern_kind == DSDGP_KERN_RBF ? fwd_dispatch<MPB, DSDGP_KERN_RBF>(ctx, a, white)       \
+                                       : fwd_dispatch<MPB, DSDGP_KERN_MATERN52>(ctx, a, white);
+  switch (Mp) {
+    FWD_CASE(2)
+    FWD_CASE(4)
+    FWD_CASE(8)
+    FWD_CASE(16)
+    default:
+      dsdgp_set_error("layer_fwd: padded inducing count %d not built (supported: 32,64,128,256)", Mp);
+      return DSDGP_ERR_UNSUPPORTED;
+  }
+#undef FWD_CASE
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward chain (non-white).  Per data row, with the upstream adjoints mbar_d = dl/dmean_d, vbar_d = dl/dvar_d,
+// g = sum_d vbar_d (SURVEY Appendix C re-derived in terms of Ku^{-1} so that no Cholesky adjoint is needed):
+//   abar = sum_d 2 vbar_d S_d a + sum_d q_mu[:,d] mbar_d          (S_d = q_sqrt_d q_sqrt_d^T)
+//   b    = Ku^{-1} abar ;  e = b - g a ;  kbar = e - g a          (kbar = dl/dKuf[:, r])
+//   dl/dKu(data) = -sym(sum_r e_r a_r^T)      -> k_wgrad(E, A)
+//   dl/dS_d      =  sum_r vbar_d a_r a_r^T    -> k_wgrad(A, A, scale = vbar_d)
+//   dl/dq_mu     =  sum_r a_r mbar_r^T        -> k_wgrad(A, MB)
+//   GW = kbar ∘ dk/dr2 drives dl/dX (here), dl/dZ (k_wgrad(GW, [X|1])) and the lengthscale / variance partials.
+// ------------------------------------------------------------------------------------------------------
+template <int MPB, int KIND>
+__global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int Mp = MPB * 16;
+  const int Din = a.D_in;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  double* zs = smem;
+  double* xs = smem + Mp * Din + wave * 16 * (Din + 1);
+  const double* ils = a.hyp + HYP_ILS;
+  for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
+  const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r0 = wg * 16;
+  for (int idx = lane; idx < 16 * Din; idx += 64) {
+    const int rr = idx / Din, j = idx % Din;
+    int64_t row = r0 + rr;
+    if (row > a.Rin - 1) row = a.Rin - 1;
+    xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
+  }
+  __syncthreads();
+  if (r0 >= a.ldA) return;
+  const int64_t r = r0 + c;
+  const bool rvalid = r < a.Rin;
+  const double s2 = a.hyp[HYP_VAR];
+
+  d4 av[MPB], acc[MPB];
+#pragma unroll
+  for (int ib = 0; ib < MPB; ++ib) {
+    acc[ib] = (d4){0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[ib][t] = a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r];
+  }
+  double gsum = 0.0;
+  for (int d = 0; d < a.D_out; ++d) {
+    const double vd = a.VB[(int64_t)d * a.ldA + r];
+    gsum += vd;
+    const double vd2 = 2.0 * vd;
+    const double* __restrict__ pS = a.Sd + (int64_t)d * Mp * Mp + g * Mp + c;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = av[kb][s] * vd2;
+#pragma unroll
+        for (int ib = 0; ib < MPB; ++ib) acc[ib] = mfma_f64(pS[(16 * kb + 4 * s) * Mp + 16 * ib], bv, acc[ib]);
+      }
+  }
+  for (int sp = 0; sp < a.DP4 / 4; ++sp) {
+    const double bv = a.MB[(int64_t)(4 * sp + g) * a.ldA + r];
+#pragma unroll
+    for (int ib = 0; ib < MPB; ++ib) acc[ib] = mfma_f64(a.qmu4[(16 * ib + c) * a.DP4 + 4 * sp + g], bv, acc[ib]);
+  }
+  d4 bb[MPB];
+#pragma unroll
+  for (int ib = 0; ib < MPB; ++ib) bb[ib] = (d4){0, 0, 0, 0};
+  {
+    const double* __restrict__ pK = a.Kinv + g * Mp + c;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = acc[kb][s];
+#pragma unroll
+        for (int ib = 0; ib < MPB; ++ib) bb[ib] = mfma_f64(pK[(16 * kb + 4 * s) * Mp + 16 * ib], bv, bb[ib]);
+      }
+  }
+#pragma unroll
+  for (int ib = 0; ib < MPB; ++ib)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double e = bb[ib][t] - gsum * av[ib][t];
+      a.E[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = e;
+      bb[ib][t] = e - gsum * av[ib][t];  // kbar
+    }
+
+  // recompute the Kuf tile and its r2-derivative; GW = kbar * dk/dr2
+  d4 wv[MPB];
+  sqdist_tile<MPB>(zs, xs, Din, g, c, wv);
+  double svar = 0.0;
+#pragma unroll
+  for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double k, dk;
+      kern_val_grad<KIND>(wv[kb][t], s2, k, dk);
+      const bool ok = rvalid && (16 * kb + g + 4 * t < a.M);
+      const double kb_ = bb[kb][t];
+      svar += ok ? kb_ * k : 0.0;
+      const double w = ok ? kb_ * dk : 0.0;
+      wv[kb][t] = w;
+      a.GW[(int64_t)(16 * kb + g + 4 * t) * a.ldA + r] = w;
+    }
+  svar = sum_wave(svar);
+  const double gk = sum_wave((rvalid && g == 0) ? gsum : 0.0);
+  double* hp = a.hyp_part + wg * (Din + 2);
+  if (lane == 0) {
+    hp[0] = svar / s2;   // d loss / d variance through Kuf
+    hp[1] = gk;          // d loss / d kdiag  (Kdiag = variance (+ white), layers.py:213)
+  }
+  for (int j = 0; j < Din; ++j) {
+    const double xv = xs[c * (Din + 1) + j];
+    double sx = 0.0, sl = 0.0;
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double df = xv - zs[(16 * kb + g + 4 * t) * Din + j];
+        const double wdf = wv[kb][t] * df;
+        sx += wdf;
+        sl = fma(wdf, df, sl);
+      }
+    sx = sum_groups(sx);
+    sl = sum_wave(sl);
+    if (lane == 0) hp[2 + j] = -2.0 * ils[j] * sl;   // d r2 / d l_j = -2 (x_j - z_j)^2 / l_j^3
+    if (a.dX && rvalid && g == 0) {
+      double dx = 2.0 * ils[j] * sx;                  // d r2 / d x_j = 2 (x_j - z_j) / l_j^2
+      if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
+        dx += a.MB[(int64_t)j * a.ldA + r];
+      } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+        for (int d = 0; d < a.D_out; ++d) dx = fma(a.mean_A[j * a.D_out + d], a.MB[(int64_t)d * a.ldA + r], dx);
+      }
+      a.dX[r * Din + j] = dx;
+    }
+  }
+}
+
+template <int MPB, int KIND>
+static int bwd_dispatch(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
+  const int Mp = MPB * 16;
+  const size_t lds = layer_fwd_lds_bytes(Mp, a.D_in);
+  if (lds > 64 * 1024) {
+    dsdgp_set_error("layer_bwd: D_in=%d too large for the fused path", a.D_in);
+    return DSDGP_ERR_UNSUPPORTED;
+  }
+  const int nblk = ceil_div(a.ldA, 64);
+  ProfScope ps(ctx, "layer_bwd");
+  hipLaunchKernelGGL((k_layer_bwd<MPB, KIND>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
+  if (white) {
+    dsdgp_set_error("layer_bwd: gradients for white=True are not built yet (forward/predict are)");
+    return DSDGP_ERR_UNSUPPORTED;
+  }
+#define BWD_CASE(MPB)                                                                   \
+  case MPB * 16:                                                                        \
+    return kern_kind == DSDGP_KERN_RBF ? bwd_dispatch<MPB, DSDGP_KERN_RBF>(ctx, a)      \
+                                       : bwd_dispatch<MPB, DSDGP_KERN_MATERN52>(ctx, a);
+  switch (Mp) {
+    BWD_CASE(2)
+    BWD_CASE(4)
+    BWD_CASE(8)
+    BWD_CASE(16)
+    default:
+      dsdgp_set_error("layer_bwd: padded inducing count %d not built", Mp);
+      return DSDGP_ERR_UNSUPPORTED;
+  }
+#undef BWD_CASE
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Split-K "weight gradient" products over the data rows: out = P diag(scale) Q^T with P (rowsP x R), Q (rowsQ x R)
+// both M-major.  One wavefront per (job, split, tile); operands go straight from L2/HBM to MFMA registers: each lane
+// loads 4 consecutive r (32 B) of one row, and the t-th of them is the k-operand of the t-th MFMA, so a 16-row x
+// 16-r fragment costs two 16-B loads per lane and no LDS.
+// ------------------------------------------------------------------------------------------------------
+template <int NI, int NJ>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
+                                               int64_t Rp, int total_tasks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int w = blockIdx.x * 4 + wave;
+  if (w >= total_tasks) return;
+  int jb = 0;
+  while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
+  const WgradJob J = jobs[jb];
+  int local = w - J.task_start;
+  const int tiles = J.ti * J.tj;
+  const int split = local / tiles;
+  local = local % tiles;
+  const int tile_i = local / J.tj, tile_j = local % J.tj;
+  const int64_t nch = Rp / 16;
+  const int64_t c_lo = split * nch / nsplit, c_hi = (split + 1) * nch / nsplit;
+  d4 acc[NI][NJ];
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
+  const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
+  const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
+  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
+    const int64_t rb = ch * 16;
+    d4 pa[NI], qb[NJ];
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4*>(Pp + (int64_t)16 * ii * ld + rb);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) qb[jj] = *reinterpret_cast<const d4*>(Qp + (int64_t)16 * jj * ld + rb);
+    if (J.scale) {
+      const d4 sc = *reinterpret_cast<const d4*>(J.scale + rb + 4 * g);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) qb[jj] *= sc;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
+  }
+  const int rowsP = 16 * NI * J.ti;
+  double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] = acc[ii][jj][t];
+}
+
+int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
+                 int NI, int NJ) {
+  ProfScope ps(ctx, "wgrad");
+  const dim3 grid(ceil_div(total_tasks, 4)), blk(256);
+#define WG_CASE(I, Jn)                                                                                              \
+  if (NI == I && NJ == Jn) {                                                                                        \
+    hipLaunchKernelGGL((k_wgrad<I, Jn>), grid, blk, 0, ctx->stream, jobs_dev, njobs, nsplit, ld, Rp, total_tasks); \
+    DS_HIP(hipGetLastError());                                                                                      \
+    return DSDGP_OK;                                                                                                \
+  }
+  WG_CASE(4, 4)
+  WG_CASE(2, 2)
+  WG_CASE(4, 1)
+  WG_CASE(2, 1)
+#undef WG_CASE
+  dsdgp_set_error("wgrad: tile shape %dx%d not built", NI, NJ);
+  return DSDGP_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,67 @@
+// SVGP_Layer hot path on gfx950: register-resident MFMA chains (one wavefront owns 16 data rows end to end).
+#pragma once
+#include "common.hpp"
+
+// SVGP_Layer.conditional_ND + reparameterize (layers.py:178-219, utils.py:40-41), fused.
+struct LayerFwdArgs {
+  const double* X;   // (Rin x D_in) row-major inputs (for layer 0: the N minibatch rows, shared by all S samples)
+  int64_t Rin;
+  int32_t rep;       // S for layer 0 (tf.tile of dgp.py:63 is never materialised), 1 otherwise
+  int32_t D_in, D_out, M;
+  const double* Zp;     // (Mp x D_in), rows >= M zero
+  const double* hyp;    // see common.hpp HYP_*
+  const double* LinvT;  // (Mp x Mp)  Lu^{-T}
+  const double* Linv;   // (Mp x Mp)  Lu^{-1}
+  const double* Tp;     // (D_out x Mp x Mp) lower-triangular q_sqrt, zero padded
+  const double* qmu;    // (Mp x D_out)
+  int32_t mean_kind;
+  const double* mean_A; // (D_in x D_out) for the fixed Linear mean function
+  const double* z;      // N(0,1) draws, element (s,i,d) at z[s*zs_s + i*zs_n + d*zs_d]; NULL -> F not produced
+  int64_t zs_s, zs_n, zs_d;
+  double jitter;
+  double* F;            // (rep*Rin x D_out) samples or NULL
+  double* mean;         // (rep*Rin x D_out) or NULL
+  double* var;          // (rep*Rin x D_out) or NULL
+  double* Asave;        // (Mp x ldA): A = Ku^{-1} Kuf (white: Lu^{-1} Kuf), kept for the backward pass, or NULL
+  int64_t ldA;
+};
+
+struct LayerBwdArgs {
+  const double* X;
+  int64_t Rin;
+  int32_t D_in, D_out, M, DP4;
+  const double* Zp;
+  const double* hyp;
+  const double* Kinv;   // (Mp x Mp)
+  const double* Linv;   // (Mp x Mp)   (white path)
+  const double* Sd;     // (D_out x Mp x Mp)  q_sqrt q_sqrt^T
+  const double* qmu4;   // (Mp x DP4)
+  const double* Asave;
+  int64_t ldA;
+  const double* VB;     // (D_out.. x ldA)  d loss / d var, transposed, zero beyond Rin
+  const double* MB;     // (>=DP4 x ldA)    d loss / d mean, transposed, zero padded
+  double* E;            // (Mp x ldA)  out: so that d loss/d Ku (data) = -sym(E A^T)
+  double* GW;           // (Mp x ldA)  out: Kuf-bar * dk/dr2
+  double* dX;           // (Rin x D_in) out or NULL
+  int32_t mean_kind;
+  const double* mean_A;
+  double* hyp_part;     // [nwaves][D_in + 2]: sum kbar*k, sum vbar, lengthscale partials
+};
+
+// out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]
+struct WgradJob {
+  const double* P;
+  const double* Q;
+  const double* scale;  // or NULL
+  double* out;          // [nsplit][rowsP][ldo]
+  int32_t ti, tj;       // tiles in i / j (tile = 16*NI x 16*NJ)
+  int32_t ldo;
+  int32_t task_start;
+};
+
+int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
+int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
+// jobs_dev: device copy of `njobs` jobs with task_start filled (tasks = nsplit*ti*tj each); NI/NJ in {4,2}/{4,2,1}
+int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
+                 int NI, int NJ);
+size_t layer_fwd_lds_bytes(int Mp, int D_in);

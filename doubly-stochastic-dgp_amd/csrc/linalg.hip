@@ -1,0 +1,466 @@
+// fp64 MFMA dense kernels for the M x M algebra of the DS-DGP path (gfx950).
+//   k_gemm_grouped  : grouped/batched GEMM, 64x64 tiles, LDS-staged, v_mfma_f64_16x16x4_f64
+//   k_potrf_trtri   : blocked right-looking Cholesky (tf.cholesky, layers.py:172) with MFMA trailing update, followed by
+//                     the blocked triangular inverse that turns the two tf.matrix_triangular_solve calls of
+//                     layers.py:186,188 into MFMA products inside the layer chain kernel.
+#include "linalg.hpp"
+
+#define GT 64
+#define GK 16
+#define GLD 81  // odd LDS row stride (doubles): conflict-free k-major writes, <=2-way on the fragment reads
+
+__global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restrict__ probs, int nprob) {
+  __shared__ double As[GK * GLD];
+  __shared__ double Bs[GK * GLD];
+  const int bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  const GemmProblem P = probs[p];
+  int t = bid - P.tile_start;
+  const int tiles = P.tiles_m * P.tiles_n;
+  int b0, b1;
+  if (P.batch_reduce) {
+    b0 = 0;
+    b1 = P.batch;
+  } else {
+    b0 = t / tiles;
+    b1 = b0 + 1;
+    t = t % tiles;
+  }
+  const int m0 = (t / P.tiles_n) * GT, n0 = (t % P.tiles_n) * GT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+
+  for (int b = b0; b < b1; ++b) {
+    const double* A = P.A + (int64_t)b * P.sA;
+    const double* B = P.B + (int64_t)b * P.sB;
+    for (int k0 = 0; k0 < P.k; k0 += GK) {
+      if (!P.transA) {
+        const int kk = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mm = (tid >> 4) + 16 * i;
+          double v = 0.0;
+          if (m0 + mm < P.m && k0 + kk < P.k) v = A[(int64_t)(m0 + mm) * P.lda + k0 + kk];
+          As[kk * GLD + mm] = v;
+        }
+      } else {
+        const int mm = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = (tid >> 6) + 4 * i;
+          double v = 0.0;
+          if (m0 + mm < P.m && k0 + kk < P.k) v = A[(int64_t)(k0 + kk) * P.lda + m0 + mm];
+          As[kk * GLD + mm] = v;
+        }
+      }
+      if (!P.transB) {
+        const int nn = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = (tid >> 6) + 4 * i;
+          double v = 0.0;
+          if (n0 + nn < P.n && k0 + kk < P.k) v = B[(int64_t)(k0 + kk) * P.ldb + n0 + nn];
+          Bs[kk * GLD + nn] = v;
+        }
+      } else {
+        const int kk = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nn = (tid >> 4) + 16 * i;
+          double v = 0.0;
+          if (n0 + nn < P.n && k0 + kk < P.k) v = B[(int64_t)(n0 + nn) * P.ldb + k0 + kk];
+          Bs[kk * GLD + nn] = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k4 = 0; k4 < GK; k4 += 4) {
+        const double a0 = As[(k4 + g) * GLD + wr * 32 + c];
+        const double a1 = As[(k4 + g) * GLD + wr * 32 + 16 + c];
+        const double b0v = Bs[(k4 + g) * GLD + wc * 32 + c];
+        const double b1v = Bs[(k4 + g) * GLD + wc * 32 + 16 + c];
+        acc[0][0] = mfma_f64(a0, b0v, acc[0][0]);
+        acc[0][1] = mfma_f64(a0, b1v, acc[0][1]);
+        acc[1][0] = mfma_f64(a1, b0v, acc[1][0]);
+        acc[1][1] = mfma_f64(a1, b1v, acc[1][1]);
+      }
+      __syncthreads();
+    }
+  }
+  double* C = P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC);
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 32 + ib * 16 + g + 4 * r;
+        const int col = n0 + wc * 32 + jb * 16 + c;
+        if (row < P.m && col < P.n) {
+          double v = P.alpha * acc[ib][jb][r];
+          if (P.beta != 0.0) v += P.beta * C[(int64_t)row * P.ldc + col];
+          C[(int64_t)row * P.ldc + col] = v;
+        }
+      }
+}
+
+int gemm_plan(GemmProblem* host, int nprob) {
+  int total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    GemmProblem& P = host[i];
+    P.tiles_m = ceil_div(P.m, GT);
+    P.tiles_n = ceil_div(P.n, GT);
+    P.tile_start = total;
+    total += P.tiles_m * P.tiles_n * (P.batch_reduce ? 1 : P.batch);
+  }
+  return total;
+}
+
+int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles) {
+  if (total_tiles <= 0) return DSDGP_OK;
+  ProfScope ps(ctx, "gemm");
+  hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, ctx->stream, dev, nprob);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Blocked Cholesky + triangular inverse, one 256-thread workgroup per matrix, NB = 16.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict__ items) {
+  __shared__ double Ld[16 * 17];
+  __shared__ double Xd[16 * 17];
+  __shared__ int s_info;
+  __shared__ double s_red[4];
+  const PotrfItem it = items[blockIdx.x];
+  const int n = it.n, ld = it.ld, nb = n / 16;
+  double* __restrict__ W = it.W;
+  double* __restrict__ Linv = it.Linv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  if (tid == 0) s_info = 0;
+  __syncthreads();
+
+  for (int jb = 0; jb < nb; ++jb) {
+    const int j0 = jb * 16;
+    // (a) diagonal block: wave 0, lane i (<16) owns row i in registers; columns eliminated with cross-lane shuffles.
+    if (wave == 0) {
+      const int i = c;
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = W[(int64_t)(j0 + i) * ld + j0 + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double ajj = __shfl(a[j], j, 64);
+        if (!(ajj > 0.0) && lane == 0 && s_info == 0) s_info = j0 + j + 1;
+        const double inv = 1.0 / sqrt(ajj);
+        const double lij = (i >= j) ? a[j] * inv : 0.0;
+        a[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = __shfl(lij, k, 64);
+          a[k] -= lij * lkj;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double v = (j <= i) ? a[j] : 0.0;
+          Ld[i * 17 + j] = v;
+          W[(int64_t)(j0 + i) * ld + j0 + j] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+      // column `lane` of X = L_jj^{-1} by forward substitution (LDS reads are broadcasts)
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= Ld[i * 17 + k] * x[k];
+        x[i] = s / Ld[i * 17 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        Xd[i * 17 + lane] = x[i];
+        if (Linv) Linv[(int64_t)(j0 + i) * ld + j0 + lane] = x[i];
+      }
+    }
+    __syncthreads();
+    // (b) panel: L_ij = A_ij * L_jj^{-T}   (16x16 MFMA products)
+    for (int ib = jb + 1 + wave; ib < nb; ib += 4) {
+      d4 acc = (d4){0, 0, 0, 0};
+      double av[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = W[(int64_t)(ib * 16 + c) * ld + j0 + 4 * s + g];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_f64(av[s], Xd[c * 17 + 4 * s + g], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[(int64_t)(ib * 16 + g + 4 * r) * ld + j0 + c] = acc[r];
+    }
+    __syncthreads();
+    // (c) trailing update (syrk): A_ik -= L_ij L_kj^T for jb < kb <= ib
+    const int nt = nb - jb - 1;
+    const int cnt = nt * (nt + 1) / 2;
+    for (int idx = wave; idx < cnt; idx += 4) {
+      int ib2 = 0;
+      while ((ib2 + 1) * (ib2 + 2) / 2 <= idx) ++ib2;
+      const int kb2 = idx - ib2 * (ib2 + 1) / 2;
+      const int ib = jb + 1 + ib2, kb = jb + 1 + kb2;
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double a = W[(int64_t)(ib * 16 + c) * ld + j0 + 4 * s + g];
+        const double b = W[(int64_t)(kb * 16 + c) * ld + j0 + 4 * s + g];
+        acc = mfma_f64(-a, b, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c] = acc[r];
+    }
+    __syncthreads();
+  }
+  // zero the strict upper triangle of L
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    if (j > i) W[(int64_t)i * ld + j] = 0.0;
+  }
+  // logdet over the real (unpadded) part
+  {
+    double s = 0.0;
+    for (int i = tid; i < it.nreal; i += 256) s += 2.0 * log(W[(int64_t)i * ld + i]);
+    s = sum_wave(s);
+    if (lane == 0) s_red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+      it.scal[0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      it.scal[1] = (double)s_info;
+    }
+  }
+  if (!Linv) return;
+  __syncthreads();
+  // blocked triangular inverse: Linv_ij = -Linv_ii * sum_{k=j}^{i-1} L_ik Linv_kj
+  for (int ib = 1; ib < nb; ++ib) {
+    for (int jb2 = wave; jb2 < ib; jb2 += 4) {
+      d4 S = (d4){0, 0, 0, 0};
+      for (int kb = jb2; kb < ib; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double a = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
+          const double b = Linv[(int64_t)(kb * 16 + 4 * s + g) * ld + jb2 * 16 + c];
+          S = mfma_f64(a, b, S);
+        }
+      }
+      d4 R = (d4){0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double a = -Linv[(int64_t)(ib * 16 + c) * ld + ib * 16 + 4 * s + g];
+        R = mfma_f64(a, S[s], R);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Linv[(int64_t)(ib * 16 + g + 4 * r) * ld + jb2 * 16 + c] = R[r];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    double v = 0.0;
+    if (j <= i)
+      v = Linv[(int64_t)i * ld + j];
+    else
+      Linv[(int64_t)i * ld + j] = 0.0;
+    if (it.LinvT) it.LinvT[(int64_t)j * ld + i] = v;
+  }
+}
+
+int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems) {
+  ProfScope ps(ctx, "potrf");
+  hipLaunchKernelGGL(k_potrf_trtri, dim3(nitems), dim3(256), 0, ctx->stream, dev_items);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pad / unpad helpers for the primitive entry points (arbitrary n -> multiple of 16 with an identity pad)
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_pad_spd(const double* __restrict__ A, int64_t lda, int64_t strideA, int n, double* __restrict__ P,
+                          int np) {
+  const double* Ab = A + (int64_t)blockIdx.y * strideA;
+  double* Pb = P + (int64_t)blockIdx.y * np * np;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < np * np; idx += gridDim.x * blockDim.x) {
+    const int i = idx / np, j = idx % np;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < n && j < n) v = (j <= i) ? Ab[(int64_t)i * lda + j] : Ab[(int64_t)j * lda + i];
+    Pb[idx] = v;
+  }
+}
+__global__ void k_unpad(const double* __restrict__ P, int np, double* __restrict__ A, int64_t lda, int64_t strideA,
+                        int n) {
+  const double* Pb = P + (int64_t)blockIdx.y * np * np;
+  double* Ab = A + (int64_t)blockIdx.y * strideA;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
+    const int i = idx / n, j = idx % n;
+    Ab[(int64_t)i * lda + j] = Pb[(int64_t)i * np + j];
+  }
+}
+
+extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t lda, int64_t stride, int* info) {
+  DS_CHECK_ARG(ctx && A && batch > 0 && n > 0 && lda >= n);
+  const int np = (int)round_up(n, 16);
+  const size_t mat_bytes = (size_t)batch * np * np * sizeof(double);
+  const size_t item_bytes = round_up(batch * sizeof(PotrfItem), 256);
+  const size_t scal_bytes = round_up((size_t)batch * 2 * sizeof(double), 256);
+  void* scr;
+  DS_TRY(ctx_scratch(ctx, mat_bytes + item_bytes + scal_bytes, &scr));
+  double* P = (double*)scr;
+  PotrfItem* items_d = (PotrfItem*)((char*)scr + mat_bytes);
+  double* scal_d = (double*)((char*)scr + mat_bytes + item_bytes);
+  std::vector<PotrfItem> items(batch);
+  for (int b = 0; b < batch; ++b) {
+    items[b] = PotrfItem{P + (size_t)b * np * np, nullptr, nullptr, scal_d + 2 * b, np, np, n, 0};
+  }
+  DS_HIP(hipMemcpyAsync(items_d, items.data(), batch * sizeof(PotrfItem), hipMemcpyHostToDevice, ctx->stream));
+  DS_HIP(hipStreamSynchronize(ctx->stream));  // items vector is stack-lifetime
+  hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
+  DS_TRY(potrf_launch(ctx, items_d, batch));
+  hipLaunchKernelGGL(k_unpad, dim3(ceil_div(n * n, 256), batch), dim3(256), 0, ctx->stream, P, np, A, lda, stride, n);
+  DS_HIP(hipGetLastError());
+  if (info) {
+    std::vector<double> sc(2 * batch);
+    DS_HIP(hipMemcpyAsync(sc.data(), scal_d, sc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+    *info = 0;
+    for (int b = 0; b < batch; ++b)
+      if (sc[2 * b + 1] != 0.0 && *info == 0) *info = (int)sc[2 * b + 1];
+    if (*info) {
+      dsdgp_set_error("Cholesky decomposition was not successful (pivot %d)", *info);
+      return DSDGP_ERR_NOT_SPD;
+    }
+  }
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, int k, double alpha, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  DS_CHECK_ARG(ctx && A && B && C && m > 0 && n > 0 && k > 0);
+  GemmProblem P{};
+  P.A = A; P.B = B; P.C = C;
+  P.lda = lda; P.ldb = ldb; P.ldc = ldc;
+  P.m = m; P.n = n; P.k = k;
+  P.transA = transA; P.transB = transB;
+  P.batch = 1; P.batch_reduce = 0;
+  P.alpha = alpha; P.beta = beta;
+  const int total = gemm_plan(&P, 1);
+  void* scr;
+  DS_TRY(ctx_scratch(ctx, sizeof(GemmProblem), &scr));
+  DS_HIP(hipMemcpyAsync(scr, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  return gemm_launch(ctx, (const GemmProblem*)scr, 1, total);
+}
+
+// B <- L^{-1} B (trans=0) or L^{-T} B (trans=1): explicit blocked inverse of L (k_potrf_trtri's second half would need
+// the factor; here L is given, so pad it, invert it with the same blocked recurrence, then one MFMA GEMM).
+__global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ W, double* __restrict__ Linv, int n) {
+  // W: padded lower-triangular L (n multiple of 16, identity pad). Reuses the recurrence of k_potrf_trtri.
+  __shared__ double Ld[16 * 17];
+  const int ld = n, nb = n / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  for (int jb = 0; jb < nb; ++jb) {
+    const int j0 = jb * 16;
+    __syncthreads();
+    for (int idx = tid; idx < 256; idx += 256) Ld[(idx >> 4) * 17 + (idx & 15)] = W[(int64_t)(j0 + (idx >> 4)) * ld + j0 + (idx & 15)];
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= Ld[i * 17 + k] * x[k];
+        x[i] = s / Ld[i * 17 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Linv[(int64_t)(j0 + i) * ld + j0 + lane] = x[i];
+    }
+  }
+  __syncthreads();
+  for (int ib = 1; ib < nb; ++ib) {
+    for (int jb2 = wave; jb2 < ib; jb2 += 4) {
+      d4 S = (d4){0, 0, 0, 0};
+      for (int kb = jb2; kb < ib; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double a = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
+          const double b = Linv[(int64_t)(kb * 16 + 4 * s + g) * ld + jb2 * 16 + c];
+          S = mfma_f64(a, b, S);
+        }
+      }
+      d4 R = (d4){0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) R = mfma_f64(-Linv[(int64_t)(ib * 16 + c) * ld + ib * 16 + 4 * s + g], S[s], R);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Linv[(int64_t)(ib * 16 + g + 4 * r) * ld + jb2 * 16 + c] = R[r];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    if (j > i) Linv[(int64_t)i * ld + j] = 0.0;
+  }
+}
+
+__global__ void k_pad_tril(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ P, int np) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < np * np; idx += gridDim.x * blockDim.x) {
+    const int i = idx / np, j = idx % np;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < n && j < n) v = (j <= i) ? L[(int64_t)i * ldl + j] : 0.0;
+    P[idx] = v;
+  }
+}
+__global__ void k_copy2d(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int rows,
+                         int64_t cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / cols, j = idx % cols;
+    dst[i * ldd + j] = src[i * lds_ + j];
+  }
+}
+
+extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const double* L, int64_t ldl, double* B,
+                          int64_t ldb) {
+  DS_CHECK_ARG(ctx && L && B && n > 0 && nrhs > 0 && ldl >= n && ldb >= nrhs);
+  const int np = (int)round_up(n, 16);
+  const size_t mat = (size_t)np * np * sizeof(double);
+  const size_t rhs = round_up((size_t)n * nrhs * sizeof(double), 256);
+  void* scr;
+  DS_TRY(ctx_scratch(ctx, 2 * mat + rhs + 256, &scr));
+  double* Lp = (double*)scr;
+  double* Li = (double*)((char*)scr + mat);
+  double* Bc = (double*)((char*)scr + 2 * mat);
+  GemmProblem* Pd = (GemmProblem*)((char*)scr + 2 * mat + rhs);
+  hipLaunchKernelGGL(k_pad_tril, dim3(ceil_div(np * np, 256)), dim3(256), 0, ctx->stream, L, ldl, n, Lp, np);
+  hipLaunchKernelGGL(k_trtri_only, dim3(1), dim3(256), 0, ctx->stream, Lp, Li, np);
+  const int nblk = (int)std::min<int64_t>(4096, ceil_div((int64_t)n * nrhs, 256));
+  hipLaunchKernelGGL(k_copy2d, dim3(nblk), dim3(256), 0, ctx->stream, B, ldb, Bc, nrhs, n, nrhs);
+  GemmProblem P{};
+  P.A = Li; P.B = Bc; P.C = B;
+  P.lda = np; P.ldb = nrhs; P.ldc = ldb;
+  P.m = n; P.n = (int)nrhs; P.k = n;
+  P.transA = trans ? 1 : 0; P.transB = 0;
+  P.batch = 1; P.alpha = 1.0; P.beta = 0.0;
+  const int total = gemm_plan(&P, 1);
+  DS_HIP(hipMemcpyAsync(Pd, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  return gemm_launch(ctx, Pd, 1, total);
+}

@@ -1,0 +1,942 @@
+// DGP_Base / SVGP_Layer orchestration (dgp.py:42-126, layers.py:122-246) over the HIP kernels of this library.
+// One C call enqueues a whole ELBO evaluation (+ reverse-mode gradient) on the ctx stream; nothing here touches the host
+// between kernels except reading the final scalars when the caller asks for them.
+#include "layer.hpp"
+#include "linalg.hpp"
+
+int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const double* X2, int64_t n2, int D,
+                const double* hyp_dev, double diag_add, int symmetric, double* out, int64_t ld);
+
+#define SOFTPLUS_LOWER 1e-6  // [UPSTREAM] gpflow.transforms.positive
+
+// ------------------------------------------------------------------------------------------------------
+// device-resident per-layer descriptor shared by all the small per-layer kernels
+// ------------------------------------------------------------------------------------------------------
+struct LayerDev {
+  int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, pad0;
+  int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
+  double *Zp, *hyp, *Tp, *qmu, *qmu4;
+  double *Kp, *Linv, *LinvT, *Kinv, *scal;
+  double *V, *nL, *Sd, *klv;
+  double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
+  double *bigred, *thinq, *thinz, *hyp_red;
+};
+
+struct RedJob {
+  const double* part;
+  double* out;
+  int64_t count;
+  int32_t nsplit, blk_start;
+};
+
+struct LayerState {
+  dsdgp_layer_desc d;
+  LayerDev dev;
+  int64_t R_max;    // max output rows (s_max * n_max)
+  int64_t ld_max;
+  int nsplit_big_max, nsplit_thin_max;
+  double *A, *E, *GW, *VB, *MB, *XT1;
+  double *F, *mean, *var, *zbuf, *dF;
+  double *part_big, *part_thin, *hyp_part;
+  WgradJob* wj;        // device: (1 + D_out) big jobs followed by 2 thin jobs, rebuilt when (n, S) changes
+  int ns_big, ns_thin, tot_big, tot_thin;
+  // z actually used by the last forward (for the backward pass)
+  const double* z_used;
+  int64_t zs_s, zs_n, zs_d;
+  const double* X_used;
+  int64_t Rin_used;
+  int rep_used;
+  int64_t ld_used;
+};
+
+struct dsdgp_model {
+  dsdgp_ctx* ctx;
+  dsdgp_model_desc desc;
+  int64_t n_max;
+  int s_max;
+  double *theta, *grad, *adam_m, *adam_v;
+  LayerState L[DSDGP_MAX_LAYERS];
+  LayerDev* layers_dev;
+  double* mask;
+  double* lik_const;   // [0] = variance, [1] = sigmoid(raw)
+  double* lik_part;    // [blocks][2]
+  int lik_blocks_max;
+  double *lik_dmean, *lik_dvar;
+  double* scal4;       // internal copy of out
+  PotrfItem* potrf_items;
+  GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2;
+  int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2;
+  RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
+  int rjobs_cap, n_red, red_blocks;
+  int64_t plan_n;
+  int plan_S;
+  bool prepared;
+};
+
+struct Bump {
+  char* base;
+  size_t off;
+  template <class T>
+  T* take(size_t count) {
+    off = (size_t)round_up((int64_t)off, 256);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
+  int ns = target_tasks / (tiles_per_split > 0 ? tiles_per_split : 1);
+  if (ns < 1) ns = 1;
+  int64_t cap = nchunks / 4;
+  if (cap < 1) cap = 1;
+  if (ns > cap) ns = (int)cap;
+  return ns;
+}
+
+static void wgrad_shapes(int Mp, int& NI, int& ti) {
+  NI = (Mp % 64 == 0) ? 4 : 2;
+  ti = Mp / (16 * NI);
+}
+
+static void layout(dsdgp_model* m, char* base, size_t* total) {
+  Bump b{base, 0};
+  const dsdgp_model_desc& D = m->desc;
+  m->layers_dev = b.take<LayerDev>(D.L);
+  m->mask = b.take<double>(D.n_theta);
+  m->lik_const = b.take<double>(8);
+  m->scal4 = b.take<double>(8);
+  const int64_t Rlast = (int64_t)m->s_max * m->n_max;
+  m->lik_blocks_max = ceil_div(Rlast * D.layers[D.L - 1].D_out, 256);
+  m->lik_part = b.take<double>((size_t)m->lik_blocks_max * 2);
+  m->lik_dmean = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
+  m->lik_dvar = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
+  m->potrf_items = b.take<PotrfItem>(D.L);
+  m->gp_fwd = b.take<GemmProblem>(4 * D.L);
+  m->gp_bwd1 = b.take<GemmProblem>(3 * D.L);
+  m->gp_bwd2 = b.take<GemmProblem>(D.L);
+  m->rjobs_cap = 0;
+  for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 4;
+  m->rjobs = b.take<RedJob>(m->rjobs_cap);
+  for (int l = 0; l < D.L; ++l) {
+    LayerState& S = m->L[l];
+    const dsdgp_layer_desc& d = D.layers[l];
+    S.d = d;
+    LayerDev& v = S.dev;
+    v.M = d.M; v.Mp = pad_M(d.M); v.D_in = d.D_in; v.D_out = d.D_out;
+    v.DP4 = (int)round_up(d.D_out, 4); v.DP16 = (int)round_up(d.D_out, 16); v.DinP16 = (int)round_up(d.D_in + 1, 16);
+    v.kern_kind = d.kern_kind; v.ard = d.ard; v.has_white = d.has_white; v.white = D.white; v.pad0 = 0;
+    v.off_Z = d.off_Z; v.off_q_mu = d.off_q_mu; v.off_q_sqrt = d.off_q_sqrt;
+    v.off_kvar = d.off_kvar; v.off_kls = d.off_kls; v.off_wvar = d.off_wvar;
+    const size_t Mp = v.Mp, MM = Mp * Mp;
+    v.Zp = b.take<double>(Mp * d.D_in);
+    v.hyp = b.take<double>(HYP_ILS + 2 * d.D_in + 8);
+    v.Tp = b.take<double>(d.D_out * MM);
+    v.qmu = b.take<double>(Mp * d.D_out);
+    v.qmu4 = b.take<double>(Mp * v.DP4);
+    v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.Kinv = b.take<double>(MM);
+    v.scal = b.take<double>(8);
+    v.V = b.take<double>(d.D_out * MM); v.nL = b.take<double>(Mp * v.DP4); v.Sd = b.take<double>(d.D_out * MM);
+    v.klv = b.take<double>(8);
+    v.U = b.take<double>(d.D_out * MM); v.n4 = b.take<double>(Mp * v.DP4); v.PT = b.take<double>(d.D_out * MM);
+    v.UU = b.take<double>(MM); v.Kbar = b.take<double>(MM); v.wm = b.take<double>(MM); v.wk = b.take<double>(MM);
+    v.bigred = b.take<double>((1 + d.D_out) * MM);
+    v.thinq = b.take<double>(Mp * v.DP16);
+    v.thinz = b.take<double>(Mp * v.DinP16);
+    v.hyp_red = b.take<double>(d.D_in + 2 + 8);
+    S.R_max = (int64_t)m->s_max * m->n_max;
+    const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
+    S.ld_max = round_up(Rin_max, 16);
+    S.A = b.take<double>(Mp * S.ld_max); S.E = b.take<double>(Mp * S.ld_max); S.GW = b.take<double>(Mp * S.ld_max);
+    S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
+    S.XT1 = b.take<double>(v.DinP16 * S.ld_max);
+    S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
+    S.var = b.take<double>(S.R_max * d.D_out); S.zbuf = b.take<double>(S.R_max * d.D_out + 2);
+    S.dF = b.take<double>(S.R_max * d.D_out);
+    int NI, ti;
+    wgrad_shapes(v.Mp, NI, ti);
+    const int tj_big = v.Mp / (16 * NI);
+    S.nsplit_big_max = choose_nsplit((1 + d.D_out) * ti * tj_big, S.ld_max / 16, 1024);
+    S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
+    S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
+    S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
+    S.hyp_part = b.take<double>((size_t)(S.ld_max / 16) * (d.D_in + 2));
+    S.wj = b.take<WgradJob>(d.D_out + 3);
+  }
+  *total = (size_t)round_up((int64_t)b.off, 256);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// parameter transforms + padding (LowerTriangular / positive transforms of layers.py:150 and [UPSTREAM] kernels)
+__global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restrict__ layers, double* __restrict__ lik_const,
+                       int64_t off_lik, int lik_gauss) {
+  const LayerDev v = layers[blockIdx.y];
+  const int tid0 = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  if (tid0 == 0) {
+    const double rv = theta[v.off_kvar];
+    const double var = softplus_d(rv) + SOFTPLUS_LOWER;
+    double wv = 0.0, dwv = 0.0;
+    if (v.has_white) {
+      const double rw = theta[v.off_wvar];
+      wv = softplus_d(rw) + SOFTPLUS_LOWER;
+      dwv = sigmoid_d(rw);
+    }
+    v.hyp[HYP_VAR] = var; v.hyp[HYP_WVAR] = wv; v.hyp[HYP_KDIAG] = var + wv;
+    v.hyp[HYP_DVAR] = sigmoid_d(rv); v.hyp[HYP_DWVAR] = dwv;
+    for (int j = 0; j < v.D_in; ++j) {
+      const double rl = theta[v.off_kls + (v.ard ? j : 0)];
+      v.hyp[HYP_ILS + j] = 1.0 / (softplus_d(rl) + SOFTPLUS_LOWER);
+      v.hyp[HYP_ILS + v.D_in + j] = sigmoid_d(rl);
+    }
+    if (blockIdx.y == 0 && lik_gauss) {
+      const double rl = theta[off_lik];
+      lik_const[0] = softplus_d(rl) + SOFTPLUS_LOWER;
+      lik_const[1] = sigmoid_d(rl);
+    }
+  }
+  const int Mp = v.Mp, M = v.M;
+  for (int idx = tid0; idx < Mp * v.D_in; idx += nth) v.Zp[idx] = (idx / v.D_in < M) ? theta[v.off_Z + idx] : 0.0;
+  for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
+    const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
+    v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+  }
+  for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
+    v.qmu[idx] = (idx / v.D_out < M) ? theta[v.off_q_mu + idx] : 0.0;
+  for (int idx = tid0; idx < Mp * v.DP4; idx += nth) {
+    const int i = idx / v.DP4, d = idx % v.DP4;
+    v.qmu4[idx] = (i < M && d < v.D_out) ? theta[v.off_q_mu + (int64_t)i * v.D_out + d] : 0.0;
+  }
+}
+
+// Ku = K(Z,Z) + (white + jitter) I   (layers.py:171), identity on the padding
+__global__ void k_kuu_pad(const LayerDev* __restrict__ layers, double jitter) {
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp;
+  const double* ils = v.hyp + HYP_ILS;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
+    const int i = idx / Mp, j = idx % Mp;
+    double k = (i == j) ? 1.0 : 0.0;
+    if (i < v.M && j < v.M) {
+      double r2 = 0.0;
+      for (int q = 0; q < v.D_in; ++q) {
+        const double df = (v.Zp[i * v.D_in + q] - v.Zp[j * v.D_in + q]) * ils[q];
+        r2 = fma(df, df, r2);
+      }
+      k = kern_val_rt(v.kern_kind, r2, v.hyp[HYP_VAR]);
+      if (i == j) k += v.hyp[HYP_WVAR] + jitter;
+    }
+    v.Kp[idx] = k;
+  }
+}
+
+__device__ double block_sum_256(double x, double* sh) {
+  x = sum_wave(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// SVGP_Layer.KL (layers.py:221-246); V = Lu^-1 q_sqrt_d and nL = Lu^-1 q_mu come from the grouped GEMM.
+__global__ __launch_bounds__(256) void k_kl(const LayerDev* __restrict__ layers) {
+  __shared__ double sh[4];
+  const LayerDev v = layers[blockIdx.x];
+  const int Mp = v.Mp, M = v.M, tid = threadIdx.x;
+  double acc = 0.0;
+  for (int idx = tid; idx < v.D_out * M; idx += 256) {
+    const int d = idx / M, i = idx % M;
+    const double t = v.Tp[((int64_t)d * Mp + i) * Mp + i];
+    acc -= 0.5 * log(t * t);                                            // layers.py:235
+  }
+  if (!v.white) {
+    for (int64_t idx = tid; idx < (int64_t)v.D_out * Mp * Mp; idx += 256) acc += 0.5 * v.V[idx] * v.V[idx];   // :239
+    for (int idx = tid; idx < Mp * v.DP4; idx += 256) acc += 0.5 * v.nL[idx] * v.nL[idx];                     // :240-241
+  } else {
+    for (int64_t idx = tid; idx < (int64_t)v.D_out * Mp * Mp; idx += 256) acc += 0.5 * v.Tp[idx] * v.Tp[idx];  // :243
+    for (int idx = tid; idx < Mp * v.D_out; idx += 256) acc += 0.5 * v.qmu[idx] * v.qmu[idx];                  // :244
+  }
+  const double tot = block_sum_256(acc, sh);
+  if (tid == 0) {
+    double kl = tot - 0.5 * v.D_out * M;                                // layers.py:234
+    if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                      // layers.py:238 (sum log diag Lu = logdet/2)
+    v.klv[0] = kl;
+  }
+}
+
+// [UPSTREAM] Gaussian.variational_expectations (dgp.py:89-90) and its adjoints w.r.t. the last layer's mean/var.
+__global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ mean, const double* __restrict__ var,
+                                                   const double* __restrict__ Y, int64_t n, int S, int DY,
+                                                   const double* __restrict__ lik_const, double w,
+                                                   double* __restrict__ part, double* __restrict__ dmean,
+                                                   double* __restrict__ dvar) {
+  __shared__ double sh[4];
+  const double s2 = lik_const[0];
+  const int64_t total = (int64_t)S * n * DY;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double ve = 0.0, dl = 0.0;
+  if (idx < total) {
+    const int64_t row = idx / DY;
+    const int dd = (int)(idx % DY);
+    const double y = Y[(row % n) * DY + dd];
+    const double mu = mean[idx], v = var[idx];
+    const double q = (y - mu) * (y - mu) + v;
+    ve = -0.91893853320467274178 - 0.5 * log(s2) - 0.5 * q / s2;
+    dl = -0.5 / s2 + 0.5 * q / (s2 * s2);
+    if (dmean) {
+      dmean[idx] = -w * (y - mu) / s2;
+      dvar[idx] = 0.5 * w / s2;
+    }
+  }
+  const double a = block_sum_256(ve, sh);
+  const double b = block_sum_256(dl, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// ELBO = data_scale/S * sum ve - kl_weight * sum KL   (dgp.py:92-98)
+__global__ __launch_bounds__(256) void k_finalize(const LayerDev* __restrict__ layers, int L, const double* __restrict__ part,
+                                                  int nblocks, double w, double kl_weight, const double* __restrict__ lik_const,
+                                                  double* __restrict__ grad, int64_t off_lik, int with_grad,
+                                                  double* __restrict__ out) {
+  __shared__ double sh[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    a += part[2 * i];
+    b += part[2 * i + 1];
+  }
+  a = block_sum_256(a, sh);
+  b = block_sum_256(b, sh);
+  if (threadIdx.x == 0) {
+    double kl = 0.0, info = 0.0;
+    for (int l = 0; l < L; ++l) {
+      kl += layers[l].klv[0];
+      if (layers[l].scal[1] != 0.0 && info == 0.0) info = layers[l].scal[1];
+    }
+    out[0] = w * a - kl_weight * kl;
+    out[1] = w * a;
+    out[2] = kl;
+    out[3] = info;
+    if (with_grad && grad && off_lik >= 0) grad[off_lik] = -w * b * lik_const[1];
+  }
+}
+
+// Philox4x32-10 + Box–Muller: replaces tf.random_normal (layers.py:101-102)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__global__ void k_randn(uint64_t seed, uint64_t stream, int64_t count, double* __restrict__ out) {
+  const int64_t npairs = (count + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const uint64_t a = ((uint64_t)c[1] << 32) | c[0], b = ((uint64_t)c[3] << 32) | c[2];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    out[2 * i] = rad * cs;
+    if (2 * i + 1 < count) out[2 * i + 1] = rad * sn;
+  }
+}
+
+__global__ void k_reparam(const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ z,
+                          double jitter, int64_t count, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = mean[i] + z[i] * sqrt(var[i] + jitter);
+}
+
+// upstream adjoints of one layer, transposed to the M-major layout of the chain kernels:
+//   MB[d][r] = sum_s (dF + dmean)[s,r,d]
+//   VB[d][r] = sum_s (dF * z / (2 sqrt(var + jitter)) + dvar)[s,r,d]       (utils.py:41 reverse)
+//   XT1      = [X^T ; 1]  (for dl/dZ = GW [X | 1])
+__global__ void k_adj_prep(const double* __restrict__ dF, const double* __restrict__ dmean, const double* __restrict__ dvar,
+                           const double* __restrict__ z, int64_t zs_s, int64_t zs_n, int64_t zs_d,
+                           const double* __restrict__ var, const double* __restrict__ X, int64_t Rin, int rep, int D_in,
+                           int D_out, int DP16, int DinP16, double jitter, int64_t ld, double* __restrict__ MB,
+                           double* __restrict__ VB, double* __restrict__ XT1) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ld) return;
+  const bool ok = r < Rin;
+  for (int d = 0; d < DP16; ++d) {
+    double mb = 0.0, vb = 0.0;
+    if (ok && d < D_out) {
+      for (int s = 0; s < rep; ++s) {
+        const int64_t o = ((int64_t)s * Rin + r) * D_out + d;
+        if (dF) {
+          const double f = dF[o];
+          mb += f;
+          vb += f * z[s * zs_s + r * zs_n + d * zs_d] / (2.0 * sqrt(var[o] + jitter));
+        }
+        if (dmean) {
+          mb += dmean[o];
+          vb += dvar[o];
+        }
+      }
+    }
+    MB[(int64_t)d * ld + r] = mb;
+    VB[(int64_t)d * ld + r] = vb;
+  }
+  for (int j = 0; j < DinP16; ++j) {
+    double v = 0.0;
+    if (ok) v = (j < D_in) ? X[r * D_in + j] : (j == D_in ? 1.0 : 0.0);
+    XT1[(int64_t)j * ld + r] = v;
+  }
+}
+
+__global__ void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs) {
+  int jb = 0;
+  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_start) ++jb;
+  const RedJob J = jobs[jb];
+  const int64_t i = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
+  if (i >= J.count) return;
+  double s = 0.0;
+  for (int sp = 0; sp < J.nsplit; ++sp) s += J.part[(int64_t)sp * J.count + i];
+  J.out[i] = s;
+}
+
+// dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu
+// then wm = Kbar ∘ dk/dr2 and wk = Kbar ∘ k / variance for the Gram adjoint.
+__global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp, M = v.M;
+  const double* G = v.bigred;
+  const double* ils = v.hyp + HYP_ILS;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
+    const int i = idx / Mp, j = idx % Mp;
+    double kb = 0.0, wm = 0.0, wk = 0.0;
+    if (i < M && j < M) {
+      double nn = 0.0;
+      for (int d = 0; d < v.D_out; ++d) nn += v.n4[i * v.DP4 + d] * v.n4[j * v.DP4 + d];
+      kb = -0.5 * (G[i * Mp + j] + G[j * Mp + i]) +
+           kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * v.UU[idx] - 0.5 * nn);
+      double r2 = 0.0;
+      for (int q = 0; q < v.D_in; ++q) {
+        const double df = (v.Zp[i * v.D_in + q] - v.Zp[j * v.D_in + q]) * ils[q];
+        r2 = fma(df, df, r2);
+      }
+      double k, dk;
+      if (v.kern_kind == DSDGP_KERN_RBF)
+        kern_val_grad<DSDGP_KERN_RBF>(r2, v.hyp[HYP_VAR], k, dk);
+      else
+        kern_val_grad<DSDGP_KERN_MATERN52>(r2, v.hyp[HYP_VAR], k, dk);
+      wm = kb * dk;
+      wk = kb * k / v.hyp[HYP_VAR];
+    }
+    v.Kbar[idx] = kb;
+    v.wm[idx] = wm;
+    v.wk[idx] = wk;
+  }
+}
+
+// final assembly of d loss / d theta for one layer (one workgroup per layer)
+__global__ __launch_bounds__(256) void k_asm_final(const LayerDev* __restrict__ layers, const double* __restrict__ theta,
+                                                   double* __restrict__ grad, double kl_w) {
+  __shared__ double sh[4];
+  const LayerDev v = layers[blockIdx.x];
+  const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out, tid = threadIdx.x;
+  const double* ils = v.hyp + HYP_ILS;
+  // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
+  for (int64_t idx = tid; idx < (int64_t)Dout * M * M; idx += 256) {
+    const int d = (int)(idx / ((int64_t)M * M)), rem = (int)(idx % ((int64_t)M * M)), i = rem / M, j = rem % M;
+    double gq = 0.0;
+    if (j <= i) {
+      const int64_t p = ((int64_t)d * Mp + i) * Mp + j;
+      gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
+    }
+    grad[v.off_q_sqrt + idx] = gq;
+  }
+  // q_mu: A mbar + kl_w Ku^-1 q_mu
+  for (int idx = tid; idx < M * Dout; idx += 256) {
+    const int i = idx / Dout, d = idx % Dout;
+    grad[v.off_q_mu + idx] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
+  }
+  // Z: through Kuf (GW [X|1]) and through Ku (wm)
+  for (int idx = tid; idx < M * Din; idx += 256) {
+    const int i = idx / Din, q = idx % Din;
+    const double zi = v.Zp[i * Din + q];
+    double s = 0.0;
+    for (int j = 0; j < M; ++j) s = fma(v.wm[i * Mp + j], zi - v.Zp[j * Din + q], s);
+    const double il2 = ils[q] * ils[q];
+    grad[v.off_Z + idx] = 4.0 * il2 * s - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
+  }
+  // kernel variance
+  double a = 0.0, tr = 0.0;
+  for (int idx = tid; idx < M * M; idx += 256) {
+    const int i = idx / M, j = idx % M;
+    a += v.wk[i * Mp + j];
+    if (i == j) tr += v.Kbar[i * Mp + i];
+  }
+  a = block_sum_256(a, sh);
+  tr = block_sum_256(tr, sh);
+  if (tid == 0) {
+    grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
+    if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
+  }
+  // lengthscales
+  double iso = 0.0;
+  for (int q = 0; q < Din; ++q) {
+    double s = 0.0;
+    for (int idx = tid; idx < M * M; idx += 256) {
+      const int i = idx / M, j = idx % M;
+      const double df = v.Zp[i * Din + q] - v.Zp[j * Din + q];
+      s = fma(v.wm[i * Mp + j], df * df, s);
+    }
+    s = block_sum_256(s, sh);
+    const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
+    if (v.ard) {
+      if (tid == 0) grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
+    } else {
+      iso += gl;
+    }
+  }
+  if (!v.ard && tid == 0) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
+}
+
+__global__ void k_adam(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
+                       double* __restrict__ v, const double* __restrict__ mask, int64_t n, double lr_t, double b1,
+                       double b2, double eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask[i] == 0.0) continue;
+    const double g = grad[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * g;
+    const double vi = b2 * v[i] + (1.0 - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] -= lr_t * mi / (sqrt(vi) + eps);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static int validate_desc(const dsdgp_model_desc* d) {
+  DS_CHECK_ARG(d && d->L >= 1 && d->L <= DSDGP_MAX_LAYERS && d->n_theta > 0);
+  DS_CHECK_ARG(d->lik_kind == DSDGP_LIK_GAUSSIAN || d->lik_kind == DSDGP_LIK_MULTICLASS);
+  for (int l = 0; l < d->L; ++l) {
+    const dsdgp_layer_desc& y = d->layers[l];
+    DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
+    DS_CHECK_ARG(y.kern_kind == DSDGP_KERN_RBF || y.kern_kind == DSDGP_KERN_MATERN52);
+    if (pad_M(y.M) > 256) {
+      dsdgp_set_error("layer %d: M=%d > 256 inducing points needs the streamed large-M path (not built yet)", l, y.M);
+      return DSDGP_ERR_UNSUPPORTED;
+    }
+    if (l > 0) DS_CHECK_ARG(y.D_in == d->layers[l - 1].D_out);
+    if (y.mean_kind == DSDGP_MEAN_IDENTITY) DS_CHECK_ARG(y.D_in == y.D_out);
+    if (y.mean_kind == DSDGP_MEAN_LINEAR) DS_CHECK_ARG(y.mean_A != nullptr);
+  }
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_workspace_bytes(const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max, int64_t* bytes) {
+  DS_TRY(validate_desc(desc));
+  DS_CHECK_ARG(bytes && n_max > 0 && s_max > 0);
+  dsdgp_model tmp{};
+  tmp.desc = *desc;
+  tmp.n_max = n_max;
+  tmp.s_max = s_max;
+  size_t total = 0;
+  layout(&tmp, nullptr, &total);
+  *bytes = (int64_t)total;
+  return DSDGP_OK;
+}
+
+static void fill_gemm(GemmProblem& P, const double* A, const double* B, double* C, int m, int n, int k, int lda, int ldb,
+                      int ldc, int tA, int tB, int batch, int64_t sA, int64_t sB, int64_t sC, int reduce) {
+  memset(&P, 0, sizeof(P));
+  P.A = A; P.B = B; P.C = C;
+  P.m = m; P.n = n; P.k = k;
+  P.lda = lda; P.ldb = ldb; P.ldc = ldc;
+  P.transA = tA; P.transB = tB;
+  P.batch = batch; P.sA = sA; P.sB = sB; P.sC = sC; P.batch_reduce = reduce;
+  P.alpha = 1.0; P.beta = 0.0;
+}
+
+extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max,
+                                  double* theta, double* grad, double* adam_m, double* adam_v, void* workspace,
+                                  int64_t workspace_bytes, dsdgp_model** out) {
+  DS_CHECK_ARG(ctx && out && theta && workspace);
+  DS_TRY(validate_desc(desc));
+  DS_CHECK_ARG(((uintptr_t)workspace & 255) == 0);
+  dsdgp_model* m = new dsdgp_model();
+  m->ctx = ctx;
+  m->desc = *desc;
+  m->n_max = n_max;
+  m->s_max = s_max;
+  m->theta = theta; m->grad = grad; m->adam_m = adam_m; m->adam_v = adam_v;
+  size_t total = 0;
+  layout(m, (char*)workspace, &total);
+  if ((int64_t)total > workspace_bytes) {
+    dsdgp_set_error("workspace too small: need %zu bytes, got %lld", total, (long long)workspace_bytes);
+    delete m;
+    return DSDGP_ERR_WORKSPACE;
+  }
+  hipStream_t st = ctx->stream;
+  DS_HIP(hipMemsetAsync(workspace, 0, total, st));
+  const int L = desc->L;
+  std::vector<LayerDev> ld(L);
+  std::vector<PotrfItem> items(L);
+  std::vector<GemmProblem> gf, g1, g2;
+  for (int l = 0; l < L; ++l) {
+    const LayerDev& v = m->L[l].dev;
+    ld[l] = v;
+    items[l] = PotrfItem{v.Kp, v.Linv, v.LinvT, v.scal, v.Mp, v.Mp, v.M, 0};
+    const int Mp = v.Mp;
+    const int64_t MM = (int64_t)Mp * Mp;
+    GemmProblem P;
+    fill_gemm(P, v.LinvT, v.Linv, v.Kinv, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, 1, 0, 0, 0, 0);              // Ku^-1
+    gf.push_back(P);
+    fill_gemm(P, v.Linv, v.Tp, v.V, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);            // Lu^-1 q_sqrt
+    gf.push_back(P);
+    fill_gemm(P, v.Linv, v.qmu4, v.nL, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // Lu^-1 q_mu
+    gf.push_back(P);
+    fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
+    gf.push_back(P);
+    fill_gemm(P, v.Kinv, v.Tp, v.U, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);            // U_d
+    g1.push_back(P);
+    fill_gemm(P, v.Kinv, v.qmu4, v.n4, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // n
+    g1.push_back(P);
+    fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
+    g1.push_back(P);
+    fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, 0, 1);               // sum U U^T
+    g2.push_back(P);
+  }
+  m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
+  m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
+  m->n_bwd2 = (int)g2.size(); m->t_bwd2 = gemm_plan(g2.data(), m->n_bwd2);
+  DS_HIP(hipMemcpyAsync(m->layers_dev, ld.data(), L * sizeof(LayerDev), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->potrf_items, items.data(), L * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->gp_fwd, gf.data(), gf.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->gp_bwd1, g1.data(), g1.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->gp_bwd2, g2.data(), g2.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  // trainable mask (set_trainable(False) of the reference, e.g. tests/test_dgp.py:141-145)
+  std::vector<double> mask(desc->n_theta, 0.0);
+  auto mark = [&](int64_t off, int64_t cnt, int on) {
+    for (int64_t i = 0; i < cnt; ++i) mask[off + i] = on ? 1.0 : 0.0;
+  };
+  for (int l = 0; l < L; ++l) {
+    const dsdgp_layer_desc& y = desc->layers[l];
+    mark(y.off_Z, (int64_t)y.M * y.D_in, y.trainable_Z);
+    mark(y.off_q_mu, (int64_t)y.M * y.D_out, y.trainable_q_mu);
+    mark(y.off_q_sqrt, (int64_t)y.D_out * y.M * y.M, y.trainable_q_sqrt);
+    mark(y.off_kvar, 1, y.trainable_kvar);
+    mark(y.off_kls, y.ard ? y.D_in : 1, y.trainable_kls);
+    if (y.has_white) mark(y.off_wvar, 1, y.trainable_wvar);
+  }
+  if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, desc->trainable_lik_var);
+  DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  DS_HIP(hipStreamSynchronize(st));
+  m->prepared = false;
+  m->plan_n = -1;
+  m->plan_S = -1;
+  *out = m;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
+  if (m) {
+    hipStreamSynchronize(m->ctx->stream);
+    delete m;
+  }
+  return DSDGP_OK;
+}
+
+static int prepare_async(dsdgp_model* m) {
+  dsdgp_ctx* ctx = m->ctx;
+  const int L = m->desc.L;
+  hipLaunchKernelGGL(k_prep, dim3(64, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev, m->lik_const,
+                     m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0);
+  hipLaunchKernelGGL(k_kuu_pad, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
+  DS_HIP(hipGetLastError());
+  DS_TRY(potrf_launch(ctx, m->potrf_items, L));
+  DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd));
+  hipLaunchKernelGGL(k_kl, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev);
+  DS_HIP(hipGetLastError());
+  m->prepared = true;
+  return DSDGP_OK;
+}
+
+static int read_info(dsdgp_model* m, int* info) {
+  if (!info) return DSDGP_OK;
+  *info = 0;
+  for (int l = 0; l < m->desc.L; ++l) {
+    double sc[2];
+    DS_HIP(hipMemcpyAsync(sc, m->L[l].dev.scal, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream));
+    DS_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (sc[1] != 0.0 && *info == 0) *info = (int)sc[1];
+  }
+  if (*info) {
+    dsdgp_set_error("Cholesky decomposition was not successful (layer Kuu pivot %d)", *info);
+    return DSDGP_ERR_NOT_SPD;
+  }
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_prepare(dsdgp_model* m, int* info) {
+  DS_CHECK_ARG(m != nullptr);
+  DS_TRY(prepare_async(m));
+  return read_info(m, info);
+}
+
+static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out) {
+  const int nb = (int)std::min<int64_t>(2048, ceil_div((count + 1) / 2, 256));
+  hipLaunchKernelGGL(k_randn, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, seed, stream, count, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// dgp.py:61-76 propagate
+static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, const double* const* zs,
+                          const int64_t* zstride, uint64_t seed, bool save, bool need_last_F, double* const* Fs,
+                          double* const* Fmeans, double* const* Fvars) {
+  dsdgp_ctx* ctx = m->ctx;
+  const int L = m->desc.L;
+  DS_CHECK_ARG(n > 0 && n <= m->n_max && S > 0 && S <= m->s_max);
+  const double* Xin = X;
+  for (int l = 0; l < L; ++l) {
+    LayerState& St = m->L[l];
+    const LayerDev& v = St.dev;
+    const int64_t Rin = (l == 0) ? n : (int64_t)S * n;
+    const int rep = (l == 0) ? S : 1;
+    const bool last = (l == L - 1);
+    const bool want_F = !last || need_last_F;
+    LayerFwdArgs a{};
+    a.X = Xin; a.Rin = Rin; a.rep = rep;
+    a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
+    a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+    a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
+    a.jitter = m->desc.jitter;
+    a.z = nullptr;
+    if (want_F) {
+      if (zs && zs[l]) {
+        a.z = zs[l];
+        a.zs_s = zstride[3 * l]; a.zs_n = zstride[3 * l + 1]; a.zs_d = zstride[3 * l + 2];
+      } else {
+        DS_TRY(randn_async(ctx, seed, (uint64_t)l, (int64_t)S * n * v.D_out, St.zbuf));
+        a.z = St.zbuf;
+        a.zs_s = n * v.D_out; a.zs_n = v.D_out; a.zs_d = 1;
+      }
+    }
+    a.F = want_F ? ((Fs && Fs[l]) ? Fs[l] : St.F) : nullptr;
+    a.mean = (Fmeans && Fmeans[l]) ? Fmeans[l] : St.mean;
+    a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
+    a.ldA = round_up(Rin, 16);
+    a.Asave = save ? St.A : nullptr;
+    DS_TRY(layer_fwd_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
+    St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
+    St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
+    Xin = a.F;
+  }
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_propagate(dsdgp_model* m, const double* X, int64_t n, int32_t S, const double* const* zs,
+                                     const int64_t* zstride, uint64_t seed, double* const* Fs, double* const* Fmeans,
+                                     double* const* Fvars) {
+  DS_CHECK_ARG(m && X);
+  DS_CHECK_ARG(!zs || zstride);
+  if (!m->prepared) DS_TRY(prepare_async(m));
+  return forward_layers(m, X, n, S, zs, zstride, seed, false, true, Fs, Fmeans, Fvars);
+}
+
+// (re)build the split-K job lists for minibatch shape (n, S); uploaded once, reused by every step of that shape
+static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
+  if (m->plan_n == n && m->plan_S == S) return DSDGP_OK;
+  dsdgp_ctx* ctx = m->ctx;
+  const int L = m->desc.L;
+  std::vector<RedJob> red;
+  for (int l = 0; l < L; ++l) {
+    LayerState& St = m->L[l];
+    const LayerDev& v = St.dev;
+    const int64_t Rin = (l == 0) ? n : (int64_t)S * n;
+    const int64_t ld = round_up(Rin, 16), nch = ld / 16;
+    int NI, ti;
+    wgrad_shapes(v.Mp, NI, ti);
+    const int64_t MM = (int64_t)v.Mp * v.Mp;
+    std::vector<WgradJob> jobs(v.D_out + 3);
+    int ns = choose_nsplit((1 + v.D_out) * ti * ti, nch, 1024);
+    if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
+    St.ns_big = ns;
+    int start = 0;
+    for (int j = 0; j <= v.D_out; ++j) {
+      WgradJob& J = jobs[j];
+      J.P = (j == 0) ? St.E : St.A;
+      J.Q = St.A;
+      J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
+      J.out = St.part_big + (int64_t)j * ns * MM;
+      J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
+      start += ns * ti * ti;
+      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0});
+    }
+    St.tot_big = start;
+    int nt = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), nch, 512);
+    if (nt > St.nsplit_thin_max) nt = St.nsplit_thin_max;
+    St.ns_thin = nt;
+    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, v.DP16 / 16, v.DP16, 0};
+    jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, v.DinP16 / 16,
+                                 v.DinP16, nt * ti * (v.DP16 / 16)};
+    St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
+    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0});
+    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, (int)nch, 0});
+    DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  int blocks = 0;
+  for (auto& r : red) {
+    r.blk_start = blocks;
+    blocks += ceil_div(r.count, 256);
+  }
+  if ((int)red.size() > m->rjobs_cap) {
+    dsdgp_set_error("internal: reduction job list overflow");
+    return DSDGP_ERR_WORKSPACE;
+  }
+  DS_HIP(hipMemcpyAsync(m->rjobs, red.data(), red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ctx->stream));
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  m->n_red = (int)red.size();
+  m->red_blocks = blocks;
+  m->plan_n = n;
+  m->plan_S = S;
+  return DSDGP_OK;
+}
+
+static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
+  dsdgp_ctx* ctx = m->ctx;
+  const int L = m->desc.L;
+  DS_TRY(ensure_plan(m, n, S));
+  for (int l = L - 1; l >= 0; --l) {
+    LayerState& St = m->L[l];
+    const LayerDev& v = St.dev;
+    const bool last = (l == L - 1);
+    const int64_t Rin = St.Rin_used, ld = St.ld_used;
+    const int rep = St.rep_used;
+    hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
+                       last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
+                       St.zs_d, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
+                       St.MB, St.VB, St.XT1);
+    DS_HIP(hipGetLastError());
+    LayerBwdArgs b{};
+    b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
+    b.Zp = v.Zp; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.Sd = v.Sd; b.qmu4 = v.qmu4;
+    b.Asave = St.A; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = St.E; b.GW = St.GW;
+    b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
+    b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
+    b.hyp_part = St.hyp_part;
+    DS_TRY(layer_bwd_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
+    int NI, ti;
+    wgrad_shapes(v.Mp, NI, ti);
+    DS_TRY(wgrad_launch(ctx, St.wj, 1 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI));
+    DS_TRY(wgrad_launch(ctx, St.wj + 1 + v.D_out, 2, St.tot_thin, St.ns_thin, ld, ld, NI, 1));
+  }
+  hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red);
+  DS_HIP(hipGetLastError());
+  DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1));
+  DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2));
+  hipLaunchKernelGGL(k_asm_kbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
+  hipLaunchKernelGGL(k_asm_final, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev, m->theta, m->grad, kl_weight);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S,
+                                const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
+                                double kl_weight, int with_grad, double* out) {
+  DS_CHECK_ARG(m && X && Y && out);
+  DS_CHECK_ARG(!zs || zstride);
+  if (m->desc.lik_kind != DSDGP_LIK_GAUSSIAN) {
+    dsdgp_set_error("only the Gaussian likelihood is built on the device ELBO path so far");
+    return DSDGP_ERR_UNSUPPORTED;
+  }
+  if (with_grad) {
+    DS_CHECK_ARG(m->grad != nullptr);
+    if (m->desc.white) {
+      dsdgp_set_error("gradients for white=True are not built yet");
+      return DSDGP_ERR_UNSUPPORTED;
+    }
+  }
+  dsdgp_ctx* ctx = m->ctx;
+  const int L = m->desc.L;
+  DS_TRY(prepare_async(m));
+  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr));
+  LayerState& last = m->L[L - 1];
+  const int DY = last.dev.D_out;
+  const int64_t total = (int64_t)S * n * DY;
+  const int nblocks = ceil_div(total, 256);
+  const double w = data_scale / (double)S;
+  hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
+                     w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+  DS_HIP(hipGetLastError());
+  if (with_grad) {
+    DS_HIP(hipMemsetAsync(m->grad, 0, m->desc.n_theta * sizeof(double), ctx->stream));
+    DS_TRY(backward_layers(m, n, S, kl_weight));
+  }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, L, m->lik_part, nblocks, w, kl_weight,
+                     m->lik_const, m->grad, m->desc.off_lik_var, with_grad, out);
+  DS_HIP(hipGetLastError());
+  m->prepared = true;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t) {
+  DS_CHECK_ARG(m && m->grad && m->adam_m && m->adam_v && t >= 1);
+  const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  const int64_t n = m->desc.n_theta;
+  const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));
+  hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
+                     lr_t, beta1, beta2, eps);
+  DS_HIP(hipGetLastError());
+  m->prepared = false;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out) {
+  DS_CHECK_ARG(m && out && l >= 0 && l < m->desc.L);
+  if (!m->prepared) DS_TRY(prepare_async(m));
+  DS_HIP(hipMemcpyAsync(out, m->L[l].dev.klv, sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const double* X, int64_t n, double* mean,
+                                             double* var) {
+  DS_CHECK_ARG(m && X && mean && var && l >= 0 && l < m->desc.L && n > 0);
+  if (!m->prepared) DS_TRY(prepare_async(m));
+  LayerState& St = m->L[l];
+  const LayerDev& v = St.dev;
+  LayerFwdArgs a{};
+  a.X = X; a.Rin = n; a.rep = 1;
+  a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
+  a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+  a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
+  a.jitter = m->desc.jitter;
+  a.mean = mean; a.var = var;
+  a.ldA = round_up(n, 16);
+  return layer_fwd_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
+}
+
+extern "C" int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,
+                                    int64_t count, double* out) {
+  DS_CHECK_ARG(ctx && mean && var && z && out && count > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
+  hipLaunchKernelGGL(k_reparam, dim3(nb), dim3(256), 0, ctx->stream, mean, var, z, jitter, count, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out) {
+  DS_CHECK_ARG(ctx && out && count > 0);
+  return randn_async(ctx, seed, stream, count, out);
+}

@@ -1,0 +1,188 @@
+"""Host mirror of the reference's model classes (dgp.py:35-192): `DGP_Base`, `DGP` with the same constructors and the
+`propagate / _build_predict / E_log_p_Y / _build_likelihood / compute_log_likelihood / predict_*` surface.  Every
+evaluation is one libdsdgp call (HIP kernels on gfx950); this file holds shapes, minibatching and bookkeeping only."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .gpflow_compat import Gaussian, Parameterized, Zero
+from .layer_initializations import init_layers_linear
+from .utils import BroadcastingLikelihood
+
+
+class Minibatch:
+    """[UPSTREAM] gpflow.params.Minibatch(value, batch_size, seed): epoch-wise shuffled minibatches.  X and Y use the
+    same seed (dgp.py:51-52) so rows stay paired; TF's shuffle order itself is not reproducible, so this uses its own
+    numpy Generator.  The data stays resident on the device; only the int64 row indices are produced on the host."""
+
+    def __init__(self, n_rows, batch_size, seed=0):
+        self.n_rows, self.batch_size = int(n_rows), int(batch_size)
+        self.rng = np.random.default_rng(seed)
+        self._perm = None
+        self._pos = 0
+
+    def next_indices(self):
+        out = []
+        need = self.batch_size
+        while need > 0:
+            if self._perm is None or self._pos >= self.n_rows:
+                self._perm = self.rng.permutation(self.n_rows)
+                self._pos = 0
+            take = min(need, self.n_rows - self._pos)
+            out.append(self._perm[self._pos:self._pos + take])
+            self._pos += take
+            need -= take
+        return np.concatenate(out).astype(np.int64)
+
+
+class DGP_Base(Parameterized):
+    """dgp.py:35-126."""
+
+    def __init__(self, X, Y, likelihood, layers, minibatch_size=None, num_samples=1, num_data=None, **kwargs):
+        self.num_samples = int(num_samples)
+        self.X_data = np.ascontiguousarray(X, dtype=np.float64)
+        self.Y_data = np.ascontiguousarray(Y, dtype=np.float64)
+        self.num_data = num_data or self.X_data.shape[0]                        # dgp.py:49
+        self.minibatch_size = int(minibatch_size) if minibatch_size else None
+        self._minibatch = Minibatch(self.X_data.shape[0], self.minibatch_size, seed=0) if self.minibatch_size else None
+        self.likelihood = BroadcastingLikelihood(likelihood)                    # dgp.py:57
+        self.layers = list(layers)                                              # dgp.py:59
+        self.white = bool(self.layers[0].white) if self.layers else False
+        object.__setattr__(self, "_eng", None)
+        object.__setattr__(self, "_dev_data", None)
+        self._seed = 0
+        # data-parallel hooks (distributed.py): (rank, world_size, all_reduce_fn)
+        object.__setattr__(self, "_dist", None)
+
+    # ------------------------------------------------------------------ engine / data plumbing
+    def engine(self):
+        if self._eng is None:
+            from .engine import Engine
+            n0 = self.minibatch_size or self.X_data.shape[0]
+            eng = Engine(self.layers, self.likelihood.likelihood, self.white, n_max=n0, s_max=self.num_samples)
+            for i, layer in enumerate(self.layers):
+                object.__setattr__(layer, "_model_engine", (eng, i))
+            object.__setattr__(self, "_eng", eng)
+        return self._eng
+
+    def _device_data(self):
+        if self._dev_data is None:
+            ctx = self.engine().ctx
+            object.__setattr__(self, "_dev_data", (ctx.to_device(self.X_data), ctx.to_device(self.Y_data)))
+        return self._dev_data
+
+    def _next_seed(self):
+        self._seed += 1
+        return self._seed
+
+    def next_minibatch(self):
+        """Device tensors (Xb, Yb) of the next minibatch (dgp.py:51-52), or the full data when not minibatching."""
+        Xd, Yd = self._device_data()
+        if self._minibatch is None:
+            return Xd, Yd
+        eng = self.engine()
+        ctx = eng.ctx
+        idx = ctx.torch.as_tensor(self._minibatch.next_indices()).to(Xd.device)
+        n = idx.shape[0]
+        Xb, Yb = ctx.empty(n, Xd.shape[1]), ctx.empty(n, Yd.shape[1])
+        ctx.torch.cuda.current_stream().synchronize()
+        for src, dst in ((Xd, Xb), (Yd, Yb)):
+            _lib.check(ctx.lib.dsdgp_gather_rows(ctx.handle, C.c_void_p(src.data_ptr()), src.shape[1],
+                                                 C.c_void_p(idx.data_ptr()), n, 0, C.c_void_p(dst.data_ptr())))
+        self._keep_idx = idx
+        return Xb, Yb
+
+    @staticmethod
+    def _np(ts):
+        return [t.cpu().numpy() for t in ts]
+
+    # ------------------------------------------------------------------ dgp.py:61-76
+    def propagate(self, X, full_cov=False, S=1, zs=None):
+        if full_cov:
+            raise NotImplementedError("full_cov=True propagation is a 'next' row (SURVEY §8f), not built yet")
+        eng = self.engine()
+        Fs, Fmeans, Fvars = eng.propagate(X, int(S), zs=zs, seed=self._next_seed())
+        eng.ctx.sync()
+        return self._np(Fs), self._np(Fmeans), self._np(Fvars)
+
+    # dgp.py:78-81
+    def _build_predict(self, X, full_cov=False, S=1, zs=None):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is a 'next' row (SURVEY §8f), not built yet")
+        eng = self.engine()
+        _, Fmeans, Fvars = eng.propagate(X, int(S), zs=zs, seed=self._next_seed(), want=("mean", "var"))
+        eng.ctx.sync()
+        return Fmeans[-1].cpu().numpy(), Fvars[-1].cpu().numpy()
+
+    # dgp.py:83-90
+    def E_log_p_Y(self, X, Y, zs=None):
+        Fmean, Fvar = self._build_predict(X, full_cov=False, S=self.num_samples, zs=zs)
+        return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64))
+
+    # dgp.py:92-98
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False):
+        eng = self.engine()
+        if X is None:
+            X, Y = self.next_minibatch()
+        n_local = X.shape[0]
+        rank, world, allreduce = self._dist if self._dist else (0, 1, None)
+        scale = float(self.num_data) / float(n_local * world)                   # dgp.py:96-97
+        out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
+                       kl_weight=1.0 / world, with_grad=with_grad, sync=allreduce is None)
+        if allreduce is not None:
+            out = allreduce(eng, with_grad)
+        return float(out[0])
+
+    def compute_log_likelihood(self, X=None, Y=None, zs=None):
+        """[UPSTREAM] Model.compute_log_likelihood: evaluates _build_likelihood (one MC draw of the ELBO)."""
+        return self._build_likelihood(X, Y, zs)
+
+    def train_step(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, X=None, Y=None, zs=None, sync=False):
+        """One optimiser step of -ELBO: minibatch gather + forward + reverse-mode gradient + Adam
+        (one `session.run(opt_op)` of demos/demo_regression_UCI.ipynb:324).  Returns the ELBO if sync=True."""
+        eng = self.engine()
+        if X is None:
+            X, Y = self.next_minibatch()
+        n_local = X.shape[0]
+        rank, world, allreduce = self._dist if self._dist else (0, 1, None)
+        scale = float(self.num_data) / float(n_local * world)
+        out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
+                       kl_weight=1.0 / world, with_grad=True, sync=False)
+        if allreduce is not None:
+            out = allreduce(eng, True, sync=sync)
+        eng.adam_step(lr, beta1, beta2, eps)
+        if sync:
+            eng.ctx.sync()
+            return float(eng.out4.cpu().numpy()[0]) if out is None else float(out[0])
+        return None
+
+    # ------------------------------------------------------------------ dgp.py:100-126
+    def predict_f(self, Xnew, num_samples):
+        return self._build_predict(Xnew, full_cov=False, S=num_samples)
+
+    def predict_f_full_cov(self, Xnew, num_samples):
+        return self._build_predict(Xnew, full_cov=True, S=num_samples)
+
+    def predict_all_layers(self, Xnew, num_samples):
+        return self.propagate(Xnew, full_cov=False, S=num_samples)
+
+    def predict_all_layers_full_cov(self, Xnew, num_samples):
+        return self.propagate(Xnew, full_cov=True, S=num_samples)
+
+    def predict_y(self, Xnew, num_samples):
+        Fmean, Fvar = self._build_predict(Xnew, full_cov=False, S=num_samples)
+        return self.likelihood.predict_mean_and_var(Fmean, Fvar)
+
+    def predict_density(self, Xnew, Ynew, num_samples):
+        Fmean, Fvar = self._build_predict(Xnew, full_cov=False, S=num_samples)
+        return self.likelihood.predict_density_logmeanexp(Fmean, Fvar, np.asarray(Ynew, dtype=np.float64))
+
+
+class DGP(DGP_Base):
+    """The doubly-stochastic DGP with linear/identity mean functions (dgp.py:169-192)."""
+
+    def __init__(self, X, Y, Z, kernels, likelihood, num_outputs=None, mean_function=None, white=False, **kwargs):
+        layers = init_layers_linear(X, Y, Z, kernels, num_outputs=num_outputs,
+                                    mean_function=Zero() if mean_function is None else mean_function, white=white)
+        DGP_Base.__init__(self, X, Y, likelihood, layers, **kwargs)

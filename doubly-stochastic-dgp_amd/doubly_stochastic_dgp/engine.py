@@ -1,0 +1,378 @@
+"""Device engine: owns the flat unconstrained parameter vector theta, the workspace and the libdsdgp model handle for a
+list of SVGP layers + likelihood, and keeps host `Parameter` objects coherent with it.
+
+torch is used ONLY as the device allocator / stream provider (and, in distributed.py, for the RCCL process group);
+no torch op runs on the hot path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, settings
+from .gpflow_compat import (Gaussian, MultiClass, Parameter, positive_backward, positive_forward, split_kernel)
+
+_KIND = {"rbf": _lib.KERN_RBF, "matern52": _lib.KERN_MATERN52}
+_MEAN = {"zero": _lib.MEAN_ZERO, "identity": _lib.MEAN_IDENTITY, "linear": _lib.MEAN_LINEAR}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.DsdgpError("no MI355X visible (torch.cuda.is_available() is False): the DGP compute path has no CPU "
+                              "fallback")
+    return torch
+
+
+class Context:
+    """One libdsdgp context per process, bound to torch's current HIP stream on cuda:<device>."""
+    _inst = None
+
+    def __init__(self, device=None):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else device
+        self.torch = torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _lib.check(self.lib.dsdgp_ctx_create(C.byref(h), self.device, C.c_void_p(stream)))
+        self.handle = h
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = Context()
+        return cls._inst
+
+    def sync(self):
+        _lib.check(self.lib.dsdgp_sync(self.handle))
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=f"cuda:{self.device}")
+
+    def to_device(self, arr):
+        t = self.torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64))
+        return t.to(f"cuda:{self.device}")
+
+    def prof_enable(self, on=True):
+        _lib.check(self.lib.dsdgp_prof_enable(self.handle, int(on)))
+
+    def prof_read(self, name, reset=True):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(self.lib.dsdgp_prof_read(self.handle, name.encode(), C.byref(ms), C.byref(cnt), int(reset)))
+        return ms.value, cnt.value
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Engine:
+    def __init__(self, layers, likelihood, white, n_max=1024, s_max=1):
+        self.ctx = Context.get()
+        self.lib = self.ctx.lib
+        self.layers, self.likelihood, self.white = list(layers), likelihood, bool(white)
+        self.jitter = float(settings.jitter)
+        self.model = None
+        self.n_max, self.s_max = 0, 0
+        self._host_dirty = True        # host Parameter values newer than device theta
+        self._dev_dirty = False        # device theta newer than host Parameter values
+        self._structure_dirty = False
+        self._needs_prepare = True
+        self._build_layout()
+        self._ensure(n_max, s_max)
+
+    # ------------------------------------------------------------------ parameter layout
+    def _params_of(self, layer):
+        stat, white = split_kernel(layer.kern)
+        return stat, white
+
+    def _build_layout(self):
+        off = 0
+        self.entries = []      # (Parameter, offset, count, kind) ; kind in {'id','pos','qsqrt'}
+        self.desc = _lib.ModelDesc()
+        d = self.desc
+        d.L = len(self.layers)
+        if d.L > _lib.DSDGP_MAX_LAYERS:
+            raise ValueError("too many layers")
+        d.white = int(self.white)
+        d.jitter = self.jitter
+        self._mean_A = []
+        for l, layer in enumerate(self.layers):
+            stat, wk = self._params_of(layer)
+            ld = d.layers[l]
+            M, Din = layer.feature.Z.shape
+            Dout = layer.num_outputs
+            ld.M, ld.D_in, ld.D_out = M, Din, Dout
+            ld.kern_kind = _KIND[stat.kind]
+            ld.ard = int(stat.ARD)
+            ld.has_white = int(wk is not None)
+            ld.mean_kind = _MEAN[layer.mean_function.kind]
+            if layer.mean_function.kind == "linear":
+                A = np.asarray(layer.mean_function.A._value, dtype=np.float64)
+                if A.shape != (Din, Dout):
+                    raise ValueError("Linear mean function has the wrong shape")
+                tA = self.ctx.to_device(A)
+                self._mean_A.append(tA)
+                ld.mean_A = tA.data_ptr()
+
+            def add(p, kind, name):
+                nonlocal off
+                cnt = int(np.prod(p.shape)) if p.shape else 1
+                self.entries.append((p, off, cnt, kind))
+                setattr(ld, "off_" + name, off)
+                if self not in p._owners:
+                    p._owners.append(self)
+                off += cnt
+                return p.trainable
+
+            ld.trainable_Z = int(add(layer.feature.Z, "id", "Z"))
+            ld.trainable_q_mu = int(add(layer.q_mu, "id", "q_mu"))
+            ld.trainable_q_sqrt = int(add(layer.q_sqrt, "qsqrt", "q_sqrt"))
+            ld.trainable_kvar = int(add(stat.variance, "pos", "kvar"))
+            ld.trainable_kls = int(add(stat.lengthscales, "pos", "kls"))
+            if wk is not None:
+                ld.trainable_wvar = int(add(wk.variance, "pos", "wvar"))
+        if isinstance(self.likelihood, Gaussian):
+            d.lik_kind = _lib.LIK_GAUSSIAN
+            p = self.likelihood.variance
+            self.entries.append((p, off, 1, "pos"))
+            if self not in p._owners:
+                p._owners.append(self)
+            d.off_lik_var = off
+            d.trainable_lik_var = int(p.trainable)
+            off += 1
+        elif isinstance(self.likelihood, MultiClass):
+            d.lik_kind = _lib.LIK_MULTICLASS
+            d.num_classes = self.likelihood.num_classes
+            d.off_lik_var = -1
+        else:
+            raise NotImplementedError(type(self.likelihood).__name__)
+        d.n_theta = off
+        self.n_theta = off
+
+    def _pack_host(self):
+        th = np.zeros(self.n_theta)
+        for p, off, cnt, kind in self.entries:
+            v = np.asarray(p._value, dtype=np.float64)
+            if kind == "pos":
+                v = positive_backward(v)
+            elif kind == "qsqrt":
+                v = np.tril(v)
+            th[off:off + cnt] = np.ravel(v)
+        return th
+
+    def _unpack_host(self, th):
+        for p, off, cnt, kind in self.entries:
+            v = th[off:off + cnt].reshape(p.shape)
+            if kind == "pos":
+                v = positive_forward(v)
+            p._value = np.array(v, dtype=np.float64)
+
+    # ------------------------------------------------------------------ coherence
+    def mark_host_dirty(self):
+        self._host_dirty = True
+
+    def mark_structure_dirty(self):
+        self._structure_dirty = True
+
+    def sync_to_host(self):
+        if self._dev_dirty and self.model is not None:
+            self.ctx.sync()
+            self._unpack_host(self.theta.cpu().numpy())
+            self._dev_dirty = False
+
+    def _upload_if_needed(self):
+        if settings.jitter != self.jitter or self._structure_dirty:
+            self.sync_to_host()
+            self.jitter = float(settings.jitter)
+            self._structure_dirty = False
+            for p, *_ in self.entries:
+                if self in p._owners:
+                    p._owners.remove(self)
+            self._build_layout()
+            n, s = self.n_max, self.s_max
+            self._destroy()
+            self._host_dirty = True
+            self._ensure(n, s)
+        if self._host_dirty:
+            th = self._pack_host()
+            self.theta.copy_(self.ctx.torch.as_tensor(th))
+            self._host_dirty = False
+            self._dev_dirty = False
+            self._needs_prepare = True
+
+    def _prepare_checked(self):
+        """build_cholesky_if_needed (layers.py:167-175) once per parameter change, surfacing tf.cholesky failures."""
+        self._upload_if_needed()
+        if self._needs_prepare:
+            info = C.c_int(0)
+            _lib.check(self.lib.dsdgp_model_prepare(self.model, C.byref(info)))
+            self._needs_prepare = False
+
+    # ------------------------------------------------------------------ model lifetime
+    def _destroy(self):
+        if self.model is not None:
+            _lib.check(self.lib.dsdgp_model_destroy(self.model))
+            self.model = None
+        self.n_max = self.s_max = 0
+
+    def _ensure(self, n, s):
+        if self.model is not None and n <= self.n_max and s <= self.s_max:
+            return
+        self.sync_to_host()
+        n_max, s_max = max(n, self.n_max), max(s, self.s_max)
+        self._destroy()
+        torch = self.ctx.torch
+        nbytes = C.c_int64()
+        _lib.check(self.lib.dsdgp_model_workspace_bytes(C.byref(self.desc), n_max, s_max, C.byref(nbytes)))
+        dev = f"cuda:{self.ctx.device}"
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+        base = self.workspace.data_ptr()
+        self._ws_ptr = (base + 255) // 256 * 256
+        self.theta = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+        self.grad = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+        self.adam_m = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+        self.adam_v = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+        self.out4 = torch.zeros(4, dtype=torch.float64, device=dev)
+        h = C.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.dsdgp_model_create(self.ctx.handle, C.byref(self.desc), n_max, s_max, ptr(self.theta),
+                                               ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
+                                               C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
+        self.model = h
+        self.n_max, self.s_max = n_max, s_max
+        self._host_dirty = True
+        self._needs_prepare = True
+        self.adam_t = 0
+
+    # ------------------------------------------------------------------ compute
+    def _zs_args(self, zs, S, n):
+        """zs: list (per layer) of None or arrays broadcastable to (S, n, D_out) -> (ptr array, stride array, keepalive)"""
+        L = len(self.layers)
+        if zs is None:
+            return None, None, []
+        ptrs = (C.c_void_p * L)()
+        strides = (C.c_int64 * (3 * L))()
+        keep = []
+        for l, z in enumerate(zs):
+            if z is None:
+                ptrs[l] = None
+                continue
+            D = self.layers[l].num_outputs
+            if hasattr(z, "data_ptr"):
+                t = z
+                shape = tuple(t.shape)
+            else:
+                z = np.asarray(z, dtype=np.float64)
+                if z.ndim != 3:
+                    raise ValueError("z must be rank-3, broadcastable to (S, N, D_out)")
+                shape = z.shape
+                t = self.ctx.to_device(z)
+            for want, got in zip((S, n, D), shape):
+                if got not in (1, want):
+                    raise ValueError(f"z of shape {shape} does not broadcast to {(S, n, D)}")
+            keep.append(t)
+            ptrs[l] = t.data_ptr()
+            st = (shape[1] * shape[2], shape[2], 1)
+            for k in range(3):
+                strides[3 * l + k] = 0 if shape[k] == 1 else st[k]
+        return ptrs, strides, keep
+
+    def prepare(self):
+        self._prepare_checked()
+
+    def propagate(self, X, S, zs=None, seed=0, want=("F", "mean", "var")):
+        """X: numpy (n, D) or device tensor. Returns lists of device tensors (S, n, D_out_l)."""
+        Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
+        n = Xd.shape[0]
+        self._ensure(n, S)
+        self._prepare_checked()
+        L = len(self.layers)
+        outs = {}
+        arrs = {}
+        for key in ("F", "mean", "var"):
+            if key in want:
+                ts = [self.ctx.empty(S, n, layer.num_outputs) for layer in self.layers]
+                a = (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+            else:
+                ts, a = None, None
+            outs[key], arrs[key] = ts, a
+        zp, zst, keep = self._zs_args(zs, S, n)
+        self.ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.dsdgp_model_propagate(self.model, ptr(Xd), n, S, zp, zst, C.c_uint64(seed), arrs["F"],
+                                                  arrs["mean"], arrs["var"]))
+        return outs["F"], outs["mean"], outs["var"]
+
+    def elbo(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, with_grad=False, sync=True):
+        Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
+        Yd = Y if hasattr(Y, "data_ptr") else self.ctx.to_device(Y)
+        n = Xd.shape[0]
+        self._ensure(n, S)
+        self._upload_if_needed()
+        zp, zst, keep = self._zs_args(zs, S, n)
+        if keep or not hasattr(X, "data_ptr"):
+            self.ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.dsdgp_model_elbo(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed),
+                                             float(data_scale), float(kl_weight), int(with_grad), ptr(self.out4)))
+        if not sync:
+            return None
+        self.ctx.sync()
+        out = self.out4.cpu().numpy()
+        if out[3] != 0.0:
+            raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(out[3])})")
+        return out
+
+    def adam_step(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.adam_t += 1
+        _lib.check(self.lib.dsdgp_model_adam_step(self.model, lr, beta1, beta2, eps, self.adam_t))
+        self._dev_dirty = True
+        self._needs_prepare = True
+
+    def layer_kl(self, l):
+        self._prepare_checked()
+        out = self.ctx.empty(1)
+        _lib.check(self.lib.dsdgp_model_layer_kl(self.model, l, ptr(out)))
+        self.ctx.sync()
+        return float(out.cpu().numpy()[0])
+
+    def layer_conditional(self, l, X):
+        Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
+        n = Xd.shape[0]
+        self._ensure(max(n, 1), 1)
+        self._prepare_checked()
+        D = self.layers[l].num_outputs
+        mean, var = self.ctx.empty(n, D), self.ctx.empty(n, D)
+        self.ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.dsdgp_model_layer_conditional(self.model, l, ptr(Xd), n, ptr(mean), ptr(var)))
+        return mean, var
+
+    def randn(self, shape, seed=None):
+        """N(0,1) draws from the device Philox generator (tf.random_normal, layers.py:101-102) as a numpy array."""
+        n = int(np.prod(shape))
+        out = self.ctx.empty(n)
+        self._rng_calls = getattr(self, "_rng_calls", 0) + 1
+        _lib.check(self.lib.dsdgp_randn(self.ctx.handle, C.c_uint64(0x5eed if seed is None else seed),
+                                        C.c_uint64(1 << 32 | self._rng_calls), n, ptr(out)))
+        self.ctx.sync()
+        return out.cpu().numpy().reshape(shape)
+
+    def gradient_dict(self):
+        """d loss / d (unconstrained) parameters of the last elbo(with_grad=True), keyed like oracle/model.py."""
+        self.ctx.sync()
+        g = self.grad.cpu().numpy()
+        out = {}
+        names = {}
+        for l, layer in enumerate(self.layers):
+            stat, wk = self._params_of(layer)
+            names[id(layer.feature.Z)] = f"l{l}.Z"
+            names[id(layer.q_mu)] = f"l{l}.q_mu"
+            names[id(layer.q_sqrt)] = f"l{l}.q_sqrt"
+            names[id(stat.variance)] = f"l{l}.kern_variance_raw"
+            names[id(stat.lengthscales)] = f"l{l}.kern_lengthscales_raw"
+            if wk is not None:
+                names[id(wk.variance)] = f"l{l}.white_variance_raw"
+        if isinstance(self.likelihood, Gaussian):
+            names[id(self.likelihood.variance)] = "lik_variance_raw"
+        for p, off, cnt, kind in self.entries:
+            out[names[id(p)]] = g[off:off + cnt].reshape(p.shape).copy()
+        return out

@@ -1,0 +1,186 @@
+/*
+ * dsdgp.h — C-ABI of the MI355X-native doubly-stochastic DGP hot path (libdsdgp.so, gfx950).
+ *
+ * The reference (UCL-SML/Doubly-Stochastic-DGP) has NO FFI / plugin interface: its hot path is reached only
+ * through Python classes that compose GPflow/TF ops.  Each entry point below therefore cites the reference
+ * *call site* (file:line under /root/reference) whose TF/GPflow op sequence it replaces.  A maintainer binds
+ * these with ctypes; the shipped host mirror lives in
+ * doubly-stochastic-dgp_amd/doubly_stochastic_dgp/.
+ *
+ * Conventions
+ *   - every function returns int: 0 = DSDGP_OK, <0 = dsdgp_status; dsdgp_last_error() gives a thread-local
+ *     message (the reference surfaces errors as Python exceptions from session.run, e.g. "Cholesky
+ *     decomposition was not successful" — the host mirror re-raises DSDGP_ERR_NOT_SPD the same way).
+ *   - all data pointers are DEVICE pointers to row-major float64 unless marked "host"; the caller owns every
+ *     buffer (including workspaces); the library never frees caller memory and keeps model-bound pointers only
+ *     until dsdgp_model_destroy.
+ *   - work is enqueued asynchronously on the ctx stream; dsdgp_sync() waits for it.
+ *   - all arithmetic is float64 (settings.float_type, layers.py:68).
+ */
+#ifndef DSDGP_H
+#define DSDGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsdgp_ctx dsdgp_ctx;
+typedef struct dsdgp_model dsdgp_model;
+
+typedef enum {
+  DSDGP_OK = 0,
+  DSDGP_ERR_BAD_ARG = -1,
+  DSDGP_ERR_NOT_SPD = -2,      /* tf.cholesky failure, layers.py:172 */
+  DSDGP_ERR_HIP = -3,
+  DSDGP_ERR_UNSUPPORTED = -4,
+  DSDGP_ERR_WORKSPACE = -5
+} dsdgp_status;
+
+enum { DSDGP_KERN_RBF = 0, DSDGP_KERN_MATERN52 = 1 };            /* [UPSTREAM] gpflow.kernels */
+enum { DSDGP_MEAN_ZERO = 0, DSDGP_MEAN_IDENTITY = 1, DSDGP_MEAN_LINEAR = 2 }; /* layer_initializations.py:30-42,51 */
+enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1 };       /* dgp.py:57, utils.py:54-93 */
+
+#define DSDGP_MAX_LAYERS 16
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+int dsdgp_version(void);
+const char* dsdgp_last_error(void);
+/* stream: a hipStream_t (as void*) to enqueue on, or NULL for a library-owned stream. */
+int dsdgp_ctx_create(dsdgp_ctx** out, int device, void* stream);
+int dsdgp_ctx_destroy(dsdgp_ctx* ctx);
+int dsdgp_sync(dsdgp_ctx* ctx);
+/* HIP-event timing of the most recent launch of a named kernel class on the ctx stream (bench.py roofline):
+ * enable, run, then read the accumulated milliseconds and launch count. name in
+ * {"layer_fwd","layer_bwd","wgrad","gram","potrf","gemm"}. */
+int dsdgp_prof_enable(dsdgp_ctx* ctx, int on);
+int dsdgp_prof_read(dsdgp_ctx* ctx, const char* name, double* total_ms, int64_t* launches, int reset);
+
+/* ---- primitives (north_star: Gram assembly, blocked Cholesky, trsm) ----------------------------------- */
+/* Kernel hyper-parameters, host side.  lengthscales: host pointer to 1 (ard=0) or input_dim (ard=1) values. */
+typedef struct {
+  int32_t kind;            /* DSDGP_KERN_* */
+  int32_t input_dim;
+  int32_t ard;
+  int32_t has_white;       /* k + White(white_variance): only K(X) and Kdiag see it */
+  double variance;
+  double white_variance;
+  const double* lengthscales; /* host */
+} dsdgp_kernel;
+
+/* K1/K3 — feature.Kuu(kern, jitter) / feature.Kuf(kern, X) (layers.py:171,184 -> [UPSTREAM] kern.K):
+ *   X2 == NULL : out[n,n]  = k(X,X) + (white_variance + jitter) I          (symmetric)
+ *   else       : out[n,n2] = k(X,X2)                                       (White contributes 0)   */
+int dsdgp_gram(dsdgp_ctx* ctx, const dsdgp_kernel* kern, const double* X, int64_t n, const double* X2, int64_t n2,
+               double jitter, double* out, int64_t ld_out);
+
+/* K2 — tf.cholesky (layers.py:172): in-place lower Cholesky of `batch` n x n SPD matrices (upper part zeroed).
+ * info (host, may be NULL): 0 ok, i>0 = first non-positive pivot (1-based) in some batch entry.
+ * Blocked right-looking factorisation; the trailing update is an fp64-MFMA syrk/gemm. */
+int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t lda, int64_t stride, int* info);
+
+/* K4 — tf.matrix_triangular_solve(L, B, lower=True) and its transposed form (layers.py:186,188,239):
+ *   trans=0: B <- L^{-1} B ;  trans=1: B <- L^{-T} B.   L: n x n lower, B: n x nrhs. */
+int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const double* L, int64_t ldl, double* B, int64_t ldb);
+
+/* plain fp64-MFMA GEMM used by the M x M algebra: C = alpha op(A) op(B) + beta C (row-major). */
+int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, int k, double alpha, const double* A,
+               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
+/* ---- model: DGP_Base / SVGP_Layer (dgp.py:42-126, layers.py:122-246) ----------------------------------- */
+typedef struct {
+  int32_t M, D_in, D_out;          /* SVGP_Layer.__init__ layers.py:123-165 */
+  int32_t kern_kind, ard, has_white;
+  int32_t mean_kind;               /* DSDGP_MEAN_* */
+  int32_t trainable_Z, trainable_q_mu, trainable_q_sqrt, trainable_kvar, trainable_kls, trainable_wvar;
+  const double* mean_A;            /* device, (D_in x D_out) for DSDGP_MEAN_LINEAR (fixed: layer_initializations.py:42) */
+  /* offsets (in doubles) into the flat unconstrained parameter vector theta: */
+  int64_t off_Z;                   /* (M, D_in)                       feature.Z           layers.py:153 */
+  int64_t off_q_mu;                /* (M, D_out)                      layers.py:146-147 */
+  int64_t off_q_sqrt;              /* (D_out, M, M) dense; tril part is the free variable  layers.py:149-151 */
+  int64_t off_kvar;                /* scalar, softplus^-1(variance)   [UPSTREAM] transforms.positive */
+  int64_t off_kls;                 /* 1 or D_in values, softplus^-1(lengthscales) */
+  int64_t off_wvar;                /* scalar (if has_white) */
+} dsdgp_layer_desc;
+
+typedef struct {
+  int32_t L;
+  int32_t white;                   /* DGP(..., white=False) dgp.py:187 */
+  int32_t lik_kind;
+  int32_t num_classes;
+  int32_t trainable_lik_var;
+  int32_t reserved;
+  double jitter;                   /* settings.jitter, layers.py:171, utils.py:41 */
+  int64_t off_lik_var;             /* scalar, softplus^-1(Gaussian.variance) */
+  int64_t n_theta;
+  dsdgp_layer_desc layers[DSDGP_MAX_LAYERS];
+} dsdgp_model_desc;
+
+/* Workspace needed for minibatches of up to n_max rows and s_max samples. */
+int dsdgp_model_workspace_bytes(const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max, int64_t* bytes);
+/* theta/grad/adam_m/adam_v: device, n_theta doubles each (grad/adam_* may be NULL for predict-only models). */
+int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max, double* theta,
+                       double* grad, double* adam_m, double* adam_v, void* workspace, int64_t workspace_bytes,
+                       dsdgp_model** out);
+int dsdgp_model_destroy(dsdgp_model* m);
+
+/* build_cholesky_if_needed for every layer (layers.py:167-175): Ku, Lu (+ Lu^-1, Ku^-1) from the current theta.
+ * Must precede propagate / layer calls after theta changed; dsdgp_model_elbo calls it itself.
+ * info (host, may be NULL) is filled after an implicit sync with the Cholesky status. */
+int dsdgp_model_prepare(dsdgp_model* m, int* info);
+
+/* DGP_Base.propagate (dgp.py:61-76) with full_cov=False.
+ *   X (n x D_in0) device. zs: host array of L device pointers (or NULL entries / NULL array): explicit N(0,1) draws
+ *   for layer l; element (s,i,d) is read at zs[l][s*zstride[3l] + i*zstride[3l+1] + d*zstride[3l+2]] (strides in
+ *   doubles, 0 = broadcast; dgp.py:62,68 "zs" injection).  NULL -> on-device Philox draws from `seed`.
+ *   Fs/Fmeans/Fvars: host arrays of L device pointers ((S*n) x D_out_l each, row (s*n+i)) or NULL / NULL entries. */
+int dsdgp_model_propagate(dsdgp_model* m, const double* X, int64_t n, int32_t S, const double* const* zs,
+                          const int64_t* zstride, uint64_t seed, double* const* Fs, double* const* Fmeans,
+                          double* const* Fvars);
+
+/* DGP_Base._build_likelihood (dgp.py:92-98) on an explicit minibatch, optionally with the reverse-mode gradient of
+ * loss = -(data_scale * sum_n E_log_p_Y - kl_weight * sum_l KL_l) w.r.t. theta written to `grad`
+ * (stands in for tf.gradients [UPSTREAM]).  data_scale = num_data / n_global (dgp.py:96-97); kl_weight = 1, or
+ * 1/world_size when the row-sharded data-parallel all-reduce sums ranks.
+ * out (device, 4 doubles): [elbo_local, data_term (scaled), KL_sum, potrf_info]. */
+int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S,
+                     const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
+                     double kl_weight, int with_grad, double* out);
+
+/* [UPSTREAM] tf.train.AdamOptimizer step on theta using grad (t counts from 1). Non-trainable entries are skipped. */
+int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t);
+
+/* SVGP_Layer.KL (layers.py:221-246) of layer l after dsdgp_model_prepare; out: device scalar. */
+int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out);
+
+/* SVGP_Layer.conditional_ND (layers.py:178-219, full_cov=False) of layer l on X (n x D_in_l):
+ * mean, var: (n x D_out_l). */
+int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const double* X, int64_t n, double* mean, double* var);
+
+/* utils.reparameterize, diagonal case (utils.py:40-41): out = mean + z * sqrt(var + jitter), count elements. */
+int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,
+                         int64_t count, double* out);
+
+/* N(0,1) float64 draws (Philox4x32-10 + Box–Muller), replaces tf.random_normal (layers.py:101-102). */
+int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out);
+
+/* Minibatch gather ([UPSTREAM] gpflow.params.Minibatch, dgp.py:51-52): dst[i,:] = src[idx[idx_offset+i],:], cols wide.
+ * idx: device int64.  Index generation stays on the host (own RNG; TF's shuffle order is not reproducible). */
+int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols, const int64_t* idx, int64_t n, int64_t idx_offset,
+                      double* dst);
+
+/* DGP_Base.E_log_p_Y with the Gaussian likelihood (dgp.py:83-90): out[i,d] = mean_s varexp(mean[s,i,d], var[s,i,d], Y[i,d]).
+ * mean/var: (S*n x DY); Y, out: (n x DY); lik_var: host scalar. */
+int dsdgp_gauss_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int32_t S,
+                        int32_t DY, double lik_var, double* out);
+/* DGP_Base.predict_density, Gaussian (dgp.py:121-126): out[i,d] = logsumexp_s log N(Y | mean, var + lik_var) - log S. */
+int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
+                                int32_t S, int32_t DY, double lik_var, double* out);
+/* out = in + value (Gaussian.predict_mean_and_var adds the noise variance, dgp.py:116-119). */
+int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDGP_H */

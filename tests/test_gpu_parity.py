@@ -1,0 +1,334 @@
+"""-m gpu parity tests: HIP path (through the C-ABI / host mirror) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64; Cholesky is not bit-stable — SURVEY §8c): primitives rtol 1e-11..1e-9 (stated per test);
+per-layer mean/var rtol 1e-9 atol 1e-10; ELBO rtol 1e-9; gradients rtol 1e-7 of the largest entry (the oracle side is
+torch autograd of the *reference-form* op sequence, which itself carries ~1e-10 cancellation noise).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import dgp_oracle as O
+from oracle import model as OM
+from tests.helpers import kern_spec, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from doubly_stochastic_dgp.engine import Context
+    return Context.get()
+
+
+def _dev(ctx, a):
+    return ctx.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------- primitives
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(16, 16, 4), (50, 37, 19), (128, 128, 128), (200, 65, 130)])
+def test_gemm(ctx, tA, tB, m, n, k):
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(m + n + k)
+    A = rng.randn(*((k, m) if tA else (m, k)))
+    B = rng.randn(*((n, k) if tB else (k, n)))
+    Cc = rng.randn(m, n)
+    dA, dB, dC = _dev(ctx, A), _dev(ctx, B), _dev(ctx, Cc)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gemm(ctx.handle, tA, tB, m, n, k, 1.5, _p(dA), A.shape[1], _p(dB), B.shape[1], -0.5, _p(dC), n))
+    ctx.sync()
+    ref = 1.5 * (A.T if tA else A) @ (B.T if tB else B) - 0.5 * Cc
+    assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
+
+
+@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256])
+def test_potrf(ctx, n):
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n)
+    A0 = rng.randn(n, n)
+    A0 = A0 @ A0.T + n * np.eye(n)
+    batch = 3
+    A = np.stack([A0 * (1 + b) for b in range(batch)])
+    dA = _dev(ctx, A)
+    info = C.c_int(-1)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_potrf(ctx.handle, batch, n, _p(dA), n, n * n, C.byref(info)))
+    ctx.sync()
+    L = dA.cpu().numpy()
+    assert info.value == 0
+    for b in range(batch):
+        assert np.allclose(np.triu(L[b], 1), 0.0)
+        assert np.linalg.norm(L[b] @ L[b].T - A[b]) / np.linalg.norm(A[b]) <= 1e-14 * n      # SURVEY §8c bar
+        assert_allclose(L[b], np.linalg.cholesky(A[b]), rtol=1e-11, atol=1e-11)
+
+
+def test_potrf_not_spd(ctx):
+    from doubly_stochastic_dgp import _lib
+    A = np.eye(20)
+    A[7, 7] = -1.0
+    dA = _dev(ctx, A)
+    info = C.c_int(0)
+    ctx.torch.cuda.current_stream().synchronize()
+    rc = ctx.lib.dsdgp_potrf(ctx.handle, 1, 20, _p(dA), 20, 400, C.byref(info))
+    assert rc == _lib.ERR_NOT_SPD and info.value == 8
+
+
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("n,nrhs", [(19, 7), (128, 1000), (50, 333)])
+def test_trsm(ctx, trans, n, nrhs):
+    import scipy.linalg as sla
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n)
+    L = np.tril(rng.randn(n, n)) + 4 * np.eye(n)
+    B = rng.randn(n, nrhs)
+    dL, dB = _dev(ctx, L), _dev(ctx, B)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_trsm(ctx.handle, trans, n, nrhs, _p(dL), n, _p(dB), nrhs))
+    ctx.sync()
+    ref = sla.solve_triangular(L, B, lower=True, trans=trans)
+    assert_allclose(dB.cpu().numpy(), ref, rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("ard", [False, True])
+def test_gram(ctx, kind, ard):
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(3)
+    D, n, n2 = 8, 37, 1003
+    X, X2 = rng.randn(n, D), rng.randn(n2, D)
+    ls = (0.5 + rng.rand(D)) if ard else np.array([0.8])
+    k = O.Kern(kind, D, variance=1.7, lengthscales=ls if ard else float(ls[0]), ARD=ard, white_variance=0.3)
+    spec = _lib.KernelSpec(kind={"rbf": 0, "matern52": 1}[kind], input_dim=D, ard=int(ard), has_white=1, variance=1.7,
+                           white_variance=0.3, lengthscales=ls.ctypes.data_as(_lib.c_double_p))
+    dX, dX2 = _dev(ctx, X), _dev(ctx, X2)
+    out = ctx.empty(n, n2)
+    outs = ctx.empty(n, n)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, _p(dX2), n2, 0.0, _p(out), n2))
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, None, 0, 1e-6, _p(outs), n))
+    ctx.sync()
+    # direct-difference r2 (HIP) vs expand-the-square r2 (GPflow form in the oracle): ~1e-15 * |x|^2 apart
+    assert_allclose(out.cpu().numpy(), k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
+    Ks = outs.cpu().numpy()
+    assert_allclose(Ks, k.K(O.NP, X) + 1e-6 * np.eye(n), rtol=1e-11, atol=1e-13)
+    assert np.array_equal(Ks, Ks.T)
+
+
+def test_randn_statistics(ctx):
+    from doubly_stochastic_dgp import _lib
+    n = 1 << 20
+    out = ctx.empty(n)
+    _lib.check(ctx.lib.dsdgp_randn(ctx.handle, C.c_uint64(7), C.c_uint64(3), n, _p(out)))
+    ctx.sync()
+    z = out.cpu().numpy()
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 0.01
+    assert abs(np.mean(z ** 3)) < 0.02 and abs(np.mean(z ** 4) - 3) < 0.05
+    out2 = ctx.empty(n)
+    _lib.check(ctx.lib.dsdgp_randn(ctx.handle, C.c_uint64(7), C.c_uint64(3), n, _p(out2)))
+    ctx.sync()
+    assert np.array_equal(z, out2.cpu().numpy())                      # counter-based: reproducible
+
+
+# ---------------------------------------------------------------- layer level (layers.py:178-246)
+CASES = [
+    # M, D_in, D_out, kind, white, ARD
+    (19, 2, 3, "matern52", True, False),
+    (19, 2, 3, "matern52", False, False),
+    (50, 8, 1, "rbf", False, False),
+    (100, 5, 5, "rbf", False, True),
+    (128, 8, 8, "rbf", False, False),
+    (128, 8, 8, "rbf", True, False),
+    (200, 9, 9, "rbf", False, False),
+]
+
+
+@pytest.mark.parametrize("M,Din,Dout,kind,white,ard", CASES)
+def test_layer_conditional_and_KL(M, Din, Dout, kind, white, ard):
+    rng = np.random.RandomState(M + Din)
+    N = 333
+    X, Y = rng.randn(N, Din), rng.randn(N, Dout)
+    Z = X[rng.permutation(N)[:M]] + 0.01 * rng.randn(M, Din)
+    ls = (0.8 + rng.rand(Din)) if ard else 1.1
+    specs = [kern_spec(kind, Din, 1.3, ls, ard, white_variance=0.05)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=1)
+    om = OM.build(O.NP, spec, state)
+    layer_o = om.layers[0]
+    Xs = rng.randn(77, Din)
+    mo, vo = layer_o.conditional_ND(O.NP, Xs)
+    m, v = model.layers[0].conditional_ND(Xs)
+    assert_allclose(m, mo, rtol=1e-9, atol=1e-10)
+    assert_allclose(v, vo, rtol=1e-9, atol=1e-10)
+    assert_allclose(model.layers[0].KL(), layer_o.KL(O.NP), rtol=1e-10)
+
+
+def test_cholesky_failure_raises():
+    from doubly_stochastic_dgp import _lib, settings
+    rng = np.random.RandomState(0)
+    X = rng.randn(30, 2)
+    Z = np.concatenate([X[:10], X[:10]])                               # duplicated inducing points, no jitter
+    specs = [kern_spec("rbf", 2)]
+    with settings.temp_jitter(1e-6):
+        spec, state, model = make_case(X, rng.randn(30, 1), Z, specs, S=1, randomize=False)
+    with settings.temp_jitter(-1e-3):
+        with pytest.raises(_lib.CholeskyError):
+            model.layers[0].conditional_ND(X)
+
+
+# ---------------------------------------------------------------- model level (dgp.py:61-98)
+def _three_layer(N=200, D=8, M=128, S=4, kind="rbf", q_sqrt_scale=None, seed=0, num_data=None):
+    rng = np.random.RandomState(seed)
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[rng.permutation(N)[:M]] + 0.01 * rng.randn(M, D) if M <= N else rng.randn(M, D)
+    specs = [kern_spec(kind, D, 1.0, 1.0)] * 3
+    spec, state, model = make_case(X, Y, Z, specs, S=S, q_sqrt_scale=q_sqrt_scale, num_data=num_data, seed=seed)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 1)]
+    return X, Y, spec, state, model, zs
+
+
+def test_propagate_three_layers():
+    X, Y, spec, state, model, zs = _three_layer()
+    Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, 4)
+    Fs, Fm, Fv = model.propagate(X, S=4, zs=zs)
+    for l in range(3):
+        assert_allclose(Fm[l], Fm_o[l], rtol=1e-9, atol=1e-10)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-9, atol=1e-10)
+        assert_allclose(Fs[l], Fs_o[l], rtol=1e-9, atol=1e-10)
+
+
+def test_propagate_broadcast_z():
+    # DGP_Quad-style z of shape (S,1,D) (dgp.py:148,153)
+    X, Y, spec, state, model, zs = _three_layer(N=50, M=30, S=3)
+    zb = [zs[0][:, :1, :], zs[1][:, :1, :], np.zeros((1, 1, 1))]
+    _, Fm_o, Fv_o = OM.propagate(spec, state, X, zb, 3)
+    _, Fm, Fv = model.propagate(X, S=3, zs=zb)
+    assert_allclose(Fm[-1], Fm_o[-1], rtol=1e-9, atol=1e-10)
+    assert_allclose(Fv[-1], Fv_o[-1], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_elbo_value(kind):
+    X, Y, spec, state, model, zs = _three_layer(kind=kind, num_data=7372)
+    ref = OM.elbo(spec, state, X, Y, zs, 4, num_data=7372)
+    got = model.compute_log_likelihood(X, Y, zs=zs)
+    assert_allclose(got, ref, rtol=1e-9)
+    e = model.E_log_p_Y(X, Y, zs=zs)
+    om = OM.build(O.NP, spec, state, 4, 7372)
+    assert_allclose(e, om.E_log_p_Y(O.NP, X, Y, zs), rtol=1e-9, atol=1e-10)
+
+
+def test_elbo_demo_init_small_q_sqrt():
+    # demos shrink inner q_sqrt by 1e-5 (demo_regression_UCI.ipynb:183): cancellation-dominated variances
+    X, Y, spec, state, model, zs = _three_layer(q_sqrt_scale=1e-5)
+    ref = OM.elbo(spec, state, X, Y, zs, 4)
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), ref, rtol=1e-7)
+
+
+def _grad_check(X, Y, spec, state, model, zs, S, num_data=None, tol=1e-7):
+    ref, gref = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=num_data)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    g = model.engine().gradient_dict()
+    worst = {}
+    for k in gref:
+        worst[k] = np.max(np.abs(-gref[k] - g[k])) / (np.max(np.abs(gref[k])) + 1e-12)
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, f"gradient mismatch (rel to max entry): {bad}; all: {worst}"
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_gradients_three_layers(kind):
+    X, Y, spec, state, model, zs = _three_layer(N=150, D=4, M=40, S=3, kind=kind, num_data=1000)
+    _grad_check(X, Y, spec, state, model, zs, 3, num_data=1000)
+
+
+def test_gradients_cfg2_shape_slice():
+    X, Y, spec, state, model, zs = _three_layer(N=64, D=8, M=128, S=4, num_data=7372, seed=3)
+    _grad_check(X, Y, spec, state, model, zs, 4, num_data=7372)
+
+
+def test_gradients_ard_white_stepdown():
+    rng = np.random.RandomState(5)
+    N, S = 90, 2
+    X, Y = rng.randn(N, 6), rng.randn(N, 2)
+    Z = X[:25].copy()
+    specs = [kern_spec("rbf", 6, 1.2, 0.8 + rng.rand(6), True, white_variance=0.02),
+             kern_spec("rbf", 3, 0.9, 1.3, False, white_variance=0.01),
+             kern_spec("rbf", 3, 1.1, 0.7 + rng.rand(3), True)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=500)
+    zs = [rng.randn(S, N, 3), rng.randn(S, N, 3), rng.randn(S, N, 2)]
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=500)
+
+
+def test_adam_training_steps_match_oracle():
+    X, Y, spec, state, model, zs = _three_layer(N=80, D=3, M=20, S=2, num_data=400)
+    keys = sorted(state.keys())
+    th = {k: state[k].copy() for k in keys}
+    m = {k: np.zeros_like(state[k]) for k in keys}
+    v = {k: np.zeros_like(state[k]) for k in keys}
+    for t in range(1, 4):
+        _, g = OM.elbo_and_grad(spec, th, X, Y, zs, 2, num_data=400)
+        for k in keys:
+            O.adam_step(th[k], -g[k], m[k], v[k], t, lr=0.01)
+        model.train_step(0.01, X=X, Y=Y, zs=zs)
+    ref = OM.elbo(spec, th, X, Y, zs, 2, num_data=400)
+    got = model.compute_log_likelihood(X, Y, zs=zs)
+    assert_allclose(got, ref, rtol=1e-7)
+    assert_allclose(model.layers[1].q_mu.value, th["l1.q_mu"], rtol=1e-6, atol=1e-8)
+    assert_allclose(model.likelihood.likelihood.variance.value, O.positive_forward(O.NP, th["lik_variance_raw"]), rtol=1e-7)
+
+
+def test_trainable_flags_respected():
+    X, Y, spec, state, model, zs = _three_layer(N=60, D=3, M=16, S=2)
+    model.layers[0].feature.Z.set_trainable(False)
+    model.likelihood.likelihood.variance.set_trainable(False)
+    Z0 = model.layers[0].feature.Z.read_value()
+    q0 = model.layers[0].q_mu.read_value()
+    model.train_step(0.01, X=X, Y=Y, zs=zs)
+    assert np.array_equal(model.layers[0].feature.Z.value, Z0)
+    assert not np.array_equal(model.layers[0].q_mu.value, q0)
+    assert_allclose(model.likelihood.likelihood.variance.value, 0.1, rtol=1e-12)
+
+
+def test_mc_elbo_unbiased_vs_explicit_z():
+    # device Philox draws: the mean of many stochastic ELBOs must sit within 4 s.e. of the mean over explicit z draws
+    X, Y, spec, state, model, zs = _three_layer(N=40, D=2, M=16, S=8)
+    vals = np.array([model.compute_log_likelihood(X, Y) for _ in range(200)])
+    rng = np.random.RandomState(11)
+    ref = np.array([OM.elbo(spec, state, X, Y, [rng.randn(8, 40, 2), rng.randn(8, 40, 2), np.zeros((1, 1, 1))], 8) for _ in range(200)])
+    se = np.sqrt(vals.var() / len(vals) + ref.var() / len(ref))
+    assert abs(vals.mean() - ref.mean()) < 4 * se
+
+
+def test_predict_wrappers():
+    X, Y, spec, state, model, zs = _three_layer(N=50, D=3, M=16, S=5)
+    om = OM.build(O.NP, spec, state, 5)
+    _, Fm, Fv = om.propagate(O.NP, X, zs[:2] + [np.zeros((1, 1, 1))], S=5)
+    lik = om.likelihood
+    m, v = model._build_predict(X, S=5, zs=zs[:2] + [None])
+    assert_allclose(m, Fm[-1], rtol=1e-9, atol=1e-10)
+    my, vy = model.likelihood.predict_mean_and_var(m, v)
+    assert_allclose(vy, Fv[-1] + 0.1, rtol=1e-9)
+    dens = model.likelihood.predict_density_logmeanexp(m, v, Y)
+    l = lik.predict_density(O.NP, Fm[-1], Fv[-1], Y)
+    from scipy.special import logsumexp
+    assert_allclose(dens, logsumexp(l - np.log(5), axis=0), rtol=1e-9, atol=1e-10)
+    mf, vf = model.predict_f(X, 7)
+    assert mf.shape == (7, 50, 1) and vf.shape == (7, 50, 1)
+
+
+def test_minibatch_gather_pairs_rows():
+    rng = np.random.RandomState(0)
+    X = rng.randn(500, 3)
+    Y = X[:, :1] * 2.0
+    spec, state, model = make_case(X, Y, X[:10].copy(), [kern_spec("rbf", 3)], S=1, minibatch_size=64)
+    for _ in range(10):
+        Xb, Yb = model.next_minibatch()
+        assert Xb.shape == (64, 3)
+        assert np.array_equal(Yb.cpu().numpy(), Xb.cpu().numpy()[:, :1] * 2.0)

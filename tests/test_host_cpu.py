@@ -1,0 +1,119 @@
+"""CPU-side tests (-m "not gpu"): the C-ABI library loads and exports every symbol of include/dsdgp.h, the host mirror
+reproduces the reference's construction logic (layer_initializations.py:16-52, layers.py:123-165, dgp.py:42-59), and the
+product path refuses to run without the HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import dgp_oracle as O
+from tests.helpers import kern_spec, product_kernel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib_or_skip():
+    from doubly_stochastic_dgp import _lib
+    if not os.path.exists(_lib.lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_cabi_exports_every_declared_symbol():
+    _lib = _lib_or_skip()
+    header = open(os.path.join(ROOT, "include", "dsdgp.h")).read()
+    declared = set(re.findall(r"\b(dsdgp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"dsdgp_status"}
+    lib = ctypes.CDLL(_lib.lib_path())          # dlopen only: no compute call without a GPU
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(_lib.EXPORTED_SYMBOLS) <= declared
+    assert lib.dsdgp_version() >= 100
+
+
+def test_struct_layout_matches_header():
+    _lib = _lib_or_skip()
+    # sizes the C side expects (LP64): dsdgp_layer_desc = 13*4 (+4 pad) + 8 + 6*8 ; model desc = 6*4 + 3*8 + 16 layers
+    assert ctypes.sizeof(_lib.LayerDesc) == 112
+    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 16 * 112
+    assert ctypes.sizeof(_lib.KernelSpec) == 40
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from doubly_stochastic_dgp import _lib
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian
+    X = np.random.randn(20, 2)
+    m = DGP(X, X[:, :1], X[:5], [RBF(2)], Gaussian())
+    with pytest.raises(_lib.DsdgpError, match="no CPU fallback"):
+        m.compute_log_likelihood()
+
+
+@pytest.mark.parametrize("dims", [(3, 3, 3), (8, 4, 4), (2, 5, 5), (6, 3, 1)])
+@pytest.mark.parametrize("white", [False, True])
+def test_init_layers_linear_matches_reference_logic(dims, white):
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import Gaussian
+    rng = np.random.RandomState(0)
+    X, Y = rng.randn(40, dims[0]), rng.randn(40, 2)
+    Z = X[:12].copy()
+    specs = [kern_spec("rbf", d, 1.0 + 0.1 * i, 0.9) for i, d in enumerate(dims)]
+    lds = O.init_layers_linear(X, Y, Z, specs, white=white)
+    model = DGP(X, Y, Z, [product_kernel(s) for s in specs], Gaussian(), white=white)
+    assert len(model.layers) == len(lds)
+    for l, layer in zip(lds, model.layers):
+        assert layer.mean_function.kind == l["mean"].kind
+        assert_allclose(layer.feature.Z.value, l["Z"], rtol=1e-12, atol=1e-12)
+        assert_allclose(layer.q_sqrt.value, l["q_sqrt"], rtol=1e-9, atol=1e-12)
+        assert layer.q_mu.shape == l["q_mu"].shape and not layer.q_mu.value.any()
+        if l["mean"].kind == "linear":
+            assert_allclose(layer.mean_function.A.value, l["mean"].A, rtol=1e-12, atol=1e-12)
+            assert layer.mean_function.A.trainable is False
+    assert model.layers[-1].num_outputs == 2 and model.num_data == 40
+
+
+def test_parameter_semantics():
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian, Matern52, White
+    X = np.random.RandomState(1).randn(10, 2)
+    lik = Gaussian()
+    lik.variance = 0.01                                            # tests/test_dgp.py:40
+    assert lik.variance.value == 0.01
+    k = Matern52(2, lengthscales=0.5) + White(2, variance=1e-5)
+    assert k.input_dim == 2
+    m = DGP(X, X[:, :1], X, [RBF(2), k], lik, num_samples=2)
+    q = np.random.randn(10, 1)
+    m.layers[-1].q_mu = q                                          # tests/test_dgp.py:91
+    assert np.array_equal(m.layers[-1].q_mu.value, q)
+    assert np.array_equal(m.layers[-1].q_mu.read_value(), q)
+    m.likelihood.likelihood.variance = 0.05                        # using_natural_gradients.ipynb:99
+    assert m.likelihood.likelihood.variance.value == 0.05
+    m.layers[0].q_sqrt = m.layers[0].q_sqrt.value * 1e-5           # demo_regression_UCI.ipynb:183
+    assert m.layers[0].q_sqrt.value.max() < 1e-4
+    m.layers[0].q_mu.set_trainable(False)
+    assert m.layers[0].q_mu.trainable is False
+
+
+def test_minibatch_epochs_cover_data():
+    from doubly_stochastic_dgp.dgp import Minibatch
+    mb = Minibatch(103, 10, seed=0)
+    seen = np.concatenate([mb.next_indices() for _ in range(31)])   # 310 = 3 epochs + 1
+    assert seen.shape == (310,)
+    for e in range(3):
+        assert sorted(seen[e * 103:(e + 1) * 103]) == list(range(103))
+    mb2 = Minibatch(103, 10, seed=0)
+    assert np.array_equal(mb2.next_indices(), seen[:10])            # deterministic
+
+
+def test_positive_transform_roundtrip():
+    from doubly_stochastic_dgp.gpflow_compat import positive_backward, positive_forward
+    y = np.array([1e-5, 0.01, 1.0, 50.0])
+    assert_allclose(positive_forward(positive_backward(y)), y, rtol=1e-12)
+    assert_allclose(positive_forward(positive_backward(y)), O.positive_forward(O.NP, O.positive_backward_np(y)), rtol=1e-14)
