@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
         if (a.mean) a.mean[o] = mu;
         if (a.var) a.var[o] = var;
         if (a.F && a.z) {
-          const double zv = a.z[s * a.zs_s + r * a.zs_n + d * a.zs_d];
+          const int64_t orow = (int64_t)s * a.Rin + r;
+          const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
           a.F[o] = mu + zv * sqrt(var + a.jitter);                             // utils.py:41 (no clamp)
         }
       }

@@ -18,6 +18,7 @@ struct LayerFwdArgs {
   const double* mean_A; // (D_in x D_out) for the fixed Linear mean function
   const double* z;      // N(0,1) draws, element (s,i,d) at z[s*zs_s + i*zs_n + d*zs_d]; NULL -> F not produced
   int64_t zs_s, zs_n, zs_d;
+  int64_t n_inner;      // minibatch rows per sample: output row o = s*n_inner + i
   double jitter;
   double* F;            // (rep*Rin x D_out) samples or NULL
   double* mean;         // (rep*Rin x D_out) or NULL

@@ -365,7 +365,7 @@ __global__ void k_reparam(const double* __restrict__ mean, const double* __restr
 //   VB[d][r] = sum_s (dF * z / (2 sqrt(var + jitter)) + dvar)[s,r,d]       (utils.py:41 reverse)
 //   XT1      = [X^T ; 1]  (for dl/dZ = GW [X | 1])
 __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restrict__ dmean, const double* __restrict__ dvar,
-                           const double* __restrict__ z, int64_t zs_s, int64_t zs_n, int64_t zs_d,
+                           const double* __restrict__ z, int64_t zs_s, int64_t zs_n, int64_t zs_d, int64_t n_inner,
                            const double* __restrict__ var, const double* __restrict__ X, int64_t Rin, int rep, int D_in,
                            int D_out, int DP16, int DinP16, double jitter, int64_t ld, double* __restrict__ MB,
                            double* __restrict__ VB, double* __restrict__ XT1) {
@@ -380,7 +380,8 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
         if (dF) {
           const double f = dF[o];
           mb += f;
-          vb += f * z[s * zs_s + r * zs_n + d * zs_d] / (2.0 * sqrt(var[o] + jitter));
+          const int64_t orow = (int64_t)s * Rin + r;
+          vb += f * z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d] / (2.0 * sqrt(var[o] + jitter));
         }
         if (dmean) {
           mb += dmean[o];
@@ -720,6 +721,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
     a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
     a.jitter = m->desc.jitter;
+    a.n_inner = n;
     a.z = nullptr;
     if (want_F) {
       if (zs && zs[l]) {
@@ -826,7 +828,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     const int rep = St.rep_used;
     hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                        last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
-                       St.zs_d, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
+                       St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
                        St.MB, St.VB, St.XT1);
     DS_HIP(hipGetLastError());
     LayerBwdArgs b{};
@@ -922,6 +924,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
   a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
   a.jitter = m->desc.jitter;
+  a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
   return layer_fwd_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);

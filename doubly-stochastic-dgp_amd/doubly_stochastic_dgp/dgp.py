@@ -8,6 +8,7 @@ import numpy as np
 from . import _lib
 from .gpflow_compat import Gaussian, Parameterized, Zero
 from .layer_initializations import init_layers_linear
+from .distributed import shard_terms
 from .utils import BroadcastingLikelihood
 
 
@@ -127,9 +128,9 @@ class DGP_Base(Parameterized):
             X, Y = self.next_minibatch()
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
-        scale = float(self.num_data) / float(n_local * world)                   # dgp.py:96-97
+        scale, klw = shard_terms(self.num_data, n_local, world)                 # dgp.py:96-97
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
-                       kl_weight=1.0 / world, with_grad=with_grad, sync=allreduce is None)
+                       kl_weight=klw, with_grad=with_grad, sync=allreduce is None)
         if allreduce is not None:
             out = allreduce(eng, with_grad)
         return float(out[0])
@@ -146,9 +147,9 @@ class DGP_Base(Parameterized):
             X, Y = self.next_minibatch()
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
-        scale = float(self.num_data) / float(n_local * world)
+        scale, klw = shard_terms(self.num_data, n_local, world)
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
-                       kl_weight=1.0 / world, with_grad=True, sync=False)
+                       kl_weight=klw, with_grad=True, sync=False)
         if allreduce is not None:
             out = allreduce(eng, True, sync=sync)
         eng.adam_step(lr, beta1, beta2, eps)

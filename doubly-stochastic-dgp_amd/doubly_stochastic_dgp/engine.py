@@ -230,10 +230,12 @@ class Engine:
         base = self.workspace.data_ptr()
         self._ws_ptr = (base + 255) // 256 * 256
         self.theta = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
-        self.grad = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+        # gradient and the 4 result scalars share one buffer so that data-parallel runs need ONE all-reduce per step
+        self.gradbuf = torch.zeros(self.n_theta + 4, dtype=torch.float64, device=dev)
+        self.grad = self.gradbuf[:self.n_theta]
         self.adam_m = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
         self.adam_v = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
-        self.out4 = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.out4 = self.gradbuf[self.n_theta:]
         h = C.c_void_p()
         torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_create(self.ctx.handle, C.byref(self.desc), n_max, s_max, ptr(self.theta),

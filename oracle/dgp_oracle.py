@@ -438,8 +438,8 @@ def init_layers_linear(X, Y, Z, kern_specs, num_outputs=None, final_mean="zero",
 # --------------------------------------------------------------------------------------------------
 def adam_step(theta, grad, m, v, t, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
     """theta <- theta - lr_t * m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t). t counts from 1."""
-    m[:] = b1 * m + (1 - b1) * grad
-    v[:] = b2 * v + (1 - b2) * grad * grad
+    m[...] = b1 * m + (1 - b1) * grad
+    v[...] = b2 * v + (1 - b2) * grad * grad
     lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-    theta[:] = theta - lr_t * m / (np.sqrt(v) + eps)
+    theta[...] = theta - lr_t * m / (np.sqrt(v) + eps)
     return theta

@@ -82,34 +82,22 @@ def elbo_and_grad(spec, state, X, Y, zs, num_samples, num_data=None):
     return float(val.detach()), grads
 
 
+def elbo_and_grad_sharded(spec, state, X, Y, zs, num_samples, data_scale, kl_weight):
+    """One data-parallel rank's term  data_scale * sum E_log_p_Y - kl_weight * sum KL  and its gradient, flattened in
+    sorted-key order (the layout contract of distributed.allreduce_flat: [grad | elbo])."""
+    import torch
+    leaves = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in state.items()}
+    m = build(O.TH, spec, leaves, num_samples, None)
+    Xt, Yt = torch.as_tensor(np.asarray(X, float)), torch.as_tensor(np.asarray(Y, float))
+    zs_t = [torch.as_tensor(np.asarray(z, dtype=np.float64)) for z in zs]
+    L = O.TH.sum(m.E_log_p_Y(O.TH, Xt, Yt, zs_t))
+    KL = sum(layer.KL(O.TH) for layer in m.layers)
+    val = L * data_scale - kl_weight * KL
+    val.backward()
+    flat = np.concatenate([leaves[k].grad.numpy().ravel() for k in sorted(leaves)] + [[float(val.detach())]])
+    return flat
+
+
 def propagate(spec, state, X, zs, S, full_cov=False):
     m = build(O.NP, spec, state, S)
     return m.propagate(O.NP, np.asarray(X, float), zs, full_cov=full_cov, S=S)
-
-
-def make_synthetic(name, seed=0):
-    """Synthetic datasets of SURVEY §8d shapes (real UCI/MNIST data cannot be downloaded)."""
-    rng = np.random.default_rng(seed)
-    if name == "kin8nm":
-        n, d = 7372, 8
-    elif name == "protein":
-        n, d = 41157, 9
-    elif name == "tiny":
-        n, d = 200, 3
-    else:
-        raise ValueError(name)
-    X = rng.standard_normal((n, d))
-    w1, w2 = rng.standard_normal(d), rng.standard_normal(d)
-    Y = np.sin(X @ w1) + 0.1 * (X @ w2) ** 2 + 0.1 * rng.standard_normal(n)
-    Y = ((Y - Y.mean()) / (Y.std() + 1e-6))[:, None]
-    return X, Y
-
-
-def default_Z(X, M, seed=0):
-    """kmeans2(minit='points') as demos/run_regression.py:57, with a permutation fallback."""
-    try:
-        from scipy.cluster.vq import kmeans2
-        return kmeans2(X, M, minit="points", seed=seed)[0]
-    except Exception:
-        rng = np.random.default_rng(seed)
-        return X[rng.permutation(X.shape[0])[:M]].copy()
