@@ -11,8 +11,59 @@
 // A-operands with 128-B coalesced reads; the activations never leave registers because the D layout of
 // v_mfma_f64_16x16x4_f64 (row = 4*reg + lane/16) is exactly the B-operand layout of the next product's four k-steps.
 #include "layer.hpp"
+#include <stdlib.h>
 
-size_t layer_fwd_lds_bytes(int Mp, int D_in) { return (size_t)(Mp * D_in + 4 * 16 * (D_in + 1)) * sizeof(double); }
+// LDS: [zs Mp*Din][xs 4*16*(Din+1)] (padded to 16 B) [two weight-panel buffers of 16 x (Mp+16) doubles]
+static inline size_t chain_front_doubles(int Mp, int D_in) { return (size_t)round_up(Mp * D_in + 4 * 16 * (D_in + 1), 2); }
+size_t layer_fwd_lds_bytes(int Mp, int D_in) {
+  return (chain_front_doubles(Mp, D_in) + 2 * 16 * (size_t)(Mp + 16)) * sizeof(double);
+}
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Weight-panel pipeline shared by the 4 waves of a workgroup.  A panel is 16 consecutive rows (the k-block of an MFMA
+// product) of an Mp x Mp row-major weight matrix.  Every thread owns one (row, MPB-column) slot: it loads the slot of
+// panel p+1 from L2/HBM into registers before the MFMAs of panel p are issued and stores it to the other LDS buffer
+// afterwards — one barrier per panel, global latency hidden behind a whole panel of MFMAs, and each weight element
+// crosses the L2->CU path once per workgroup instead of once per wave.  Row stride Mp+16 doubles keeps the four
+// 16-lane groups of an A-fragment read on disjoint banks.
+template <int MPB>
+struct PanelPipe {
+  static constexpr int Mp = MPB * 16, LDW = Mp + 16, PANEL = 16 * LDW;
+  double* buf;
+  int cur;
+  int row, col0, blk;
+  bool have;
+  d2 pre[MPB / 2];
+  __device__ __forceinline__ PanelPipe(double* b, int tid) : buf(b), cur(0), have(false) {
+    row = tid >> 4;
+    col0 = (tid & 15) * MPB;
+    blk = col0 >> 4;
+  }
+  // issue the loads of panel `kb` of W, column blocks [lo, hi]
+  __device__ __forceinline__ void prefetch(const double* __restrict__ W, int kb, int lo, int hi) {
+    have = (blk >= lo && blk <= hi);
+    if (have) {
+      const d2* __restrict__ src = reinterpret_cast<const d2*>(W + (int64_t)(16 * kb + row) * Mp + col0);
+#pragma unroll
+      for (int j = 0; j < MPB / 2; ++j) pre[j] = src[j];
+    }
+  }
+  // publish the prefetched panel and make it current
+  __device__ __forceinline__ void commit() {
+    if (have) {
+      d2* dst = reinterpret_cast<d2*>(buf + (cur ^ 1) * PANEL + row * LDW + col0);
+#pragma unroll
+      for (int j = 0; j < MPB / 2; ++j) dst[j] = pre[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // A-operand fragment: W[16 kb + 4 s + g][16 ib + c]
+  __device__ __forceinline__ double frag(int s, int ib, int g, int c) const {
+    return buf[cur * PANEL + (4 * s + g) * LDW + 16 * ib + c];
+  }
+};
 
 // scaled squared distances between the wave's 16 rows (LDS xs, lane column c) and all Mp inducing points (LDS zs),
 // in D layout: r2[kb][t] <-> m = 16 kb + g + 4 t.
@@ -34,7 +85,7 @@ __device__ __forceinline__ void sqdist_tile(const double* __restrict__ zs, const
 }
 
 template <int MPB, int KIND, bool WHITE>
-__global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
+__global__ __launch_bounds__(256, (MPB <= 8 ? 2 : 1)) void k_layer_fwd(const LayerFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16;
   const int Din = a.D_in;
@@ -42,6 +93,8 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
   const int g = lane >> 4, c = lane & 15;
   double* zs = smem;
   double* xs = smem + Mp * Din + wave * 16 * (Din + 1);
+  PanelPipe<MPB> P(smem + (size_t)((Mp * Din + 4 * 16 * (Din + 1) + 1) / 2 * 2), tid);
+  P.prefetch(a.LinvT, 0, 0, MPB - 1);
   const double* ils = a.hyp + HYP_ILS;
   for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
@@ -51,8 +104,8 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
     if (row > a.Rin - 1) row = a.Rin - 1;
     xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
   }
-  __syncthreads();
-  if (r0 >= a.Rin) return;
+  P.commit();   // barrier: zs/xs and panel 0 of Lu^{-T} visible
+  // NOTE: no early exit — every wave takes part in the panel barriers; out-of-range rows are clamped and never stored.
   const int64_t r = r0 + c;
   const bool rvalid = r < a.Rin;
   const int64_t rc = rvalid ? r : a.Rin - 1;
@@ -67,20 +120,23 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
     for (int t = 0; t < 4; ++t)
       kreg[kb][t] = (16 * kb + g + 4 * t < a.M) ? kern_val<KIND>(kreg[kb][t], s2) : 0.0;
 
-  // --- a1 = Lu^{-1} k   (layers.py:186)   A-operand element [i][k] = Linv[i][k] = LinvT[k][i]
+  // --- a1 = Lu^{-1} k   (layers.py:186)   A-operand element [i][k] = Linv[i][k] = LinvT[k][i], i-blocks >= k-block
   d4 a1[MPB];
 #pragma unroll
   for (int ib = 0; ib < MPB; ++ib) a1[ib] = (d4){0, 0, 0, 0};
-  {
-    const double* __restrict__ pT = a.LinvT + g * Mp + c;
 #pragma unroll
-    for (int kb = 0; kb < MPB; ++kb)
+  for (int kb = 0; kb < MPB; ++kb) {
+    if (kb + 1 < MPB)
+      P.prefetch(a.LinvT, kb + 1, kb + 1, MPB - 1);
+    else
+      P.prefetch(WHITE ? a.Tp : a.Linv, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double bv = kreg[kb][s];
+    for (int s = 0; s < 4; ++s) {
+      const double bv = kreg[kb][s];
 #pragma unroll
-        for (int ib = kb; ib < MPB; ++ib) a1[ib] = mfma_f64(pT[(16 * kb + 4 * s) * Mp + 16 * ib], bv, a1[ib]);
-      }
+      for (int ib = kb; ib < MPB; ++ib) a1[ib] = mfma_f64(P.frag(s, ib, g, c), bv, a1[ib]);
+    }
+    P.commit();
   }
   double s1 = 0.0;
 #pragma unroll
@@ -89,7 +145,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
     for (int t = 0; t < 4; ++t) s1 = fma(a1[ib][t], a1[ib][t], s1);
   s1 = sum_groups(s1);
 
-  // --- a = Lu^{-T} a1   (layers.py:188, non-white)   A-operand element [i][k] = Linv[k][i]
+  // --- a = Lu^{-T} a1   (layers.py:188, non-white)   A-operand element [i][k] = Linv[k][i], i-blocks <= k-block
   d4 av[MPB];
   if (WHITE) {
 #pragma unroll
@@ -97,17 +153,22 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
   } else {
 #pragma unroll
     for (int ib = 0; ib < MPB; ++ib) av[ib] = (d4){0, 0, 0, 0};
-    const double* __restrict__ pL = a.Linv + g * Mp + c;
 #pragma unroll
-    for (int kb = 0; kb < MPB; ++kb)
+    for (int kb = 0; kb < MPB; ++kb) {
+      if (kb + 1 < MPB)
+        P.prefetch(a.Linv, kb + 1, 0, kb + 1);
+      else
+        P.prefetch(a.Tp, 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double bv = a1[kb][s];
 #pragma unroll
-        for (int ib = 0; ib <= kb; ++ib) av[ib] = mfma_f64(pL[(16 * kb + 4 * s) * Mp + 16 * ib], bv, av[ib]);
+        for (int ib = 0; ib <= kb; ++ib) av[ib] = mfma_f64(P.frag(s, ib, g, c), bv, av[ib]);
       }
+      P.commit();
+    }
   }
-  if (a.Asave) {
+  if (a.Asave && r0 < a.ldA) {
 #pragma unroll
     for (int ib = 0; ib < MPB; ++ib)
 #pragma unroll
@@ -120,15 +181,22 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
     d4 cacc[MPB];
 #pragma unroll
     for (int ib = 0; ib < MPB; ++ib) cacc[ib] = (d4){0, 0, 0, 0};
-    const double* __restrict__ pTd = a.Tp + (int64_t)d * Mp * Mp + g * Mp + c;
+    const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
+    const bool more = d + 1 < a.D_out;
 #pragma unroll
-    for (int kb = 0; kb < MPB; ++kb)
+    for (int kb = 0; kb < MPB; ++kb) {
+      if (kb + 1 < MPB)
+        P.prefetch(Td, kb + 1, 0, kb + 1);
+      else if (more)
+        P.prefetch(Td + (int64_t)Mp * Mp, 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double bv = av[kb][s];
 #pragma unroll
-        for (int ib = 0; ib <= kb; ++ib) cacc[ib] = mfma_f64(pTd[(16 * kb + 4 * s) * Mp + 16 * ib], bv, cacc[ib]);
+        for (int ib = 0; ib <= kb; ++ib) cacc[ib] = mfma_f64(P.frag(s, ib, g, c), bv, cacc[ib]);
       }
+      if (kb + 1 < MPB || more) P.commit();
+    }
     double s2sum = 0.0, mu = 0.0;
 #pragma unroll
     for (int ib = 0; ib < MPB; ++ib)
@@ -149,11 +217,11 @@ __global__ __launch_bounds__(256) void k_layer_fwd(const LayerFwdArgs a) {
     }
     if (rvalid) {
       for (int s = g; s < a.rep; s += 4) {
-        const int64_t o = ((int64_t)s * a.Rin + r) * a.D_out + d;
+        const int64_t orow = (int64_t)s * a.Rin + r;
+        const int64_t o = orow * a.D_out + d;
         if (a.mean) a.mean[o] = mu;
         if (a.var) a.var[o] = var;
         if (a.F && a.z) {
-          const int64_t orow = (int64_t)s * a.Rin + r;
           const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
           a.F[o] = mu + zv * sqrt(var + a.jitter);                             // utils.py:41 (no clamp)
         }
@@ -166,17 +234,22 @@ template <int MPB, int KIND>
 static int fwd_dispatch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int white) {
   const int Mp = MPB * 16;
   const size_t lds = layer_fwd_lds_bytes(Mp, a.D_in);
-  if (lds > 64 * 1024) {
-    dsdgp_set_error("layer_fwd: D_in=%d with M_pad=%d needs %zu B LDS (>64 KiB): large-D_in path not built yet", a.D_in,
+  if (lds > 160 * 1024) {
+    dsdgp_set_error("layer_fwd: D_in=%d with M_pad=%d needs %zu B LDS (>160 KiB): large-D_in path not built yet", a.D_in,
                     Mp, lds);
     return DSDGP_ERR_UNSUPPORTED;
   }
   const int nblk = ceil_div(a.Rin, 64);
   ProfScope ps(ctx, "layer_fwd");
-  if (white)
+  if (white) {
+    if (lds > 64 * 1024)
+      DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd<MPB, KIND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_layer_fwd<MPB, KIND, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-  else
+  } else {
+    if (lds > 64 * 1024)
+      DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd<MPB, KIND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_layer_fwd<MPB, KIND, false>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -208,8 +281,8 @@ int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kin
 //   dl/dq_mu     =  sum_r a_r mbar_r^T        -> k_wgrad(A, MB)
 //   GW = kbar ∘ dk/dr2 drives dl/dX (here), dl/dZ (k_wgrad(GW, [X|1])) and the lengthscale / variance partials.
 // ------------------------------------------------------------------------------------------------------
-template <int MPB, int KIND>
-__global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
+template <int MPB, int KIND, int OCC, bool WHITE>
+__global__ __launch_bounds__(256, OCC) void k_layer_bwd(const LayerBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16;
   const int Din = a.D_in;
@@ -217,6 +290,8 @@ __global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
   const int g = lane >> 4, c = lane & 15;
   double* zs = smem;
   double* xs = smem + Mp * Din + wave * 16 * (Din + 1);
+  PanelPipe<MPB> P(smem + (size_t)((Mp * Din + 4 * 16 * (Din + 1) + 1) / 2 * 2), tid);
+  P.prefetch(a.Sd, 0, 0, MPB - 1);
   const double* ils = a.hyp + HYP_ILS;
   for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
   const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
@@ -227,10 +302,10 @@ __global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
     if (row > a.Rin - 1) row = a.Rin - 1;
     xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
   }
-  __syncthreads();
-  if (r0 >= a.ldA) return;
-  const int64_t r = r0 + c;
-  const bool rvalid = r < a.Rin;
+  P.commit();
+  const bool wactive = r0 < a.ldA;          // waves beyond the padded row count only keep the panel barriers alive
+  const int64_t r = wactive ? r0 + c : 0;
+  const bool rvalid = wactive && (r < a.Rin);
   const double s2 = a.hyp[HYP_VAR];
 
   d4 av[MPB], acc[MPB];
@@ -245,15 +320,22 @@ __global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
     const double vd = a.VB[(int64_t)d * a.ldA + r];
     gsum += vd;
     const double vd2 = 2.0 * vd;
-    const double* __restrict__ pS = a.Sd + (int64_t)d * Mp * Mp + g * Mp + c;
+    const double* __restrict__ Sd = a.Sd + (int64_t)d * Mp * Mp;
+    const double* __restrict__ nxt = (d + 1 < a.D_out) ? Sd + (int64_t)Mp * Mp : (WHITE ? a.Linv : a.Kinv);
 #pragma unroll
-    for (int kb = 0; kb < MPB; ++kb)
+    for (int kb = 0; kb < MPB; ++kb) {
+      if (kb + 1 < MPB)
+        P.prefetch(Sd, kb + 1, 0, MPB - 1);
+      else
+        P.prefetch(nxt, 0, 0, (WHITE && d + 1 >= a.D_out) ? 0 : MPB - 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double bv = av[kb][s] * vd2;
 #pragma unroll
-        for (int ib = 0; ib < MPB; ++ib) acc[ib] = mfma_f64(pS[(16 * kb + 4 * s) * Mp + 16 * ib], bv, acc[ib]);
+        for (int ib = 0; ib < MPB; ++ib) acc[ib] = mfma_f64(P.frag(s, ib, g, c), bv, acc[ib]);
       }
+      P.commit();
+    }
   }
   for (int sp = 0; sp < a.DP4 / 4; ++sp) {
     const double bv = a.MB[(int64_t)(4 * sp + g) * a.ldA + r];
@@ -263,24 +345,45 @@ __global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
   d4 bb[MPB];
 #pragma unroll
   for (int ib = 0; ib < MPB; ++ib) bb[ib] = (d4){0, 0, 0, 0};
-  {
-    const double* __restrict__ pK = a.Kinv + g * Mp + c;
+  if (WHITE) {
+    // white: var_d = kdiag - |a1|^2 + a1^T S_d a1, so a1bar = acc - 2 g a1 and kbar = Lu^{-T} a1bar (i-blocks <= k-block)
 #pragma unroll
-    for (int kb = 0; kb < MPB; ++kb)
+    for (int ib = 0; ib < MPB; ++ib)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[ib][t] -= 2.0 * gsum * av[ib][t];
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb) {
+      if (kb + 1 < MPB) P.prefetch(a.Linv, kb + 1, 0, kb + 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double bv = acc[kb][s];
 #pragma unroll
-        for (int ib = 0; ib < MPB; ++ib) bb[ib] = mfma_f64(pK[(16 * kb + 4 * s) * Mp + 16 * ib], bv, bb[ib]);
+        for (int ib = 0; ib <= kb; ++ib) bb[ib] = mfma_f64(P.frag(s, ib, g, c), bv, bb[ib]);
       }
+      if (kb + 1 < MPB) P.commit();
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < MPB; ++kb) {
+      if (kb + 1 < MPB) P.prefetch(a.Kinv, kb + 1, 0, MPB - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = acc[kb][s];
+#pragma unroll
+        for (int ib = 0; ib < MPB; ++ib) bb[ib] = mfma_f64(P.frag(s, ib, g, c), bv, bb[ib]);
+      }
+      if (kb + 1 < MPB) P.commit();
+    }
   }
+  if (!wactive) return;   // no barriers below
 #pragma unroll
   for (int ib = 0; ib < MPB; ++ib)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double e = bb[ib][t] - gsum * av[ib][t];
+      // non-white: E = b - g a with dl/dKu = -sym(E A^T), kbar = E - g a ;  white: E = kbar with dl/dLu = -tril(E A1^T)
+      const double e = WHITE ? bb[ib][t] : bb[ib][t] - gsum * av[ib][t];
       a.E[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = e;
-      bb[ib][t] = e - gsum * av[ib][t];  // kbar
+      bb[ib][t] = WHITE ? e : e - gsum * av[ib][t];  // kbar
     }
 
   // recompute the Kuf tile and its r2-derivative; GW = kbar * dk/dr2
@@ -334,30 +437,36 @@ __global__ __launch_bounds__(256) void k_layer_bwd(const LayerBwdArgs a) {
   }
 }
 
-template <int MPB, int KIND>
+template <int MPB, int KIND, bool WHITE>
 static int bwd_dispatch(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
   const int Mp = MPB * 16;
   const size_t lds = layer_fwd_lds_bytes(Mp, a.D_in);
-  if (lds > 64 * 1024) {
+  if (lds > 160 * 1024) {
     dsdgp_set_error("layer_bwd: D_in=%d too large for the fused path", a.D_in);
     return DSDGP_ERR_UNSUPPORTED;
   }
   const int nblk = ceil_div(a.ldA, 64);
   ProfScope ps(ctx, "layer_bwd");
-  hipLaunchKernelGGL((k_layer_bwd<MPB, KIND>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  static const int occ2 = getenv("DSDGP_BWD_OCC2") ? atoi(getenv("DSDGP_BWD_OCC2")) : 0;
+  if (occ2 && MPB <= 8) {
+    hipLaunchKernelGGL((k_layer_bwd<MPB, KIND, (MPB <= 8 ? 2 : 1), WHITE>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  } else {
+    if (lds > 64 * 1024)
+      DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MPB, KIND, 1, WHITE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_layer_bwd<MPB, KIND, 1, WHITE>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
 
 int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
-  if (white) {
-    dsdgp_set_error("layer_bwd: gradients for white=True are not built yet (forward/predict are)");
-    return DSDGP_ERR_UNSUPPORTED;
-  }
-#define BWD_CASE(MPB)                                                                   \
-  case MPB * 16:                                                                        \
-    return kern_kind == DSDGP_KERN_RBF ? bwd_dispatch<MPB, DSDGP_KERN_RBF>(ctx, a)      \
-                                       : bwd_dispatch<MPB, DSDGP_KERN_MATERN52>(ctx, a);
+#define BWD_CASE(MPB)                                                                                          \
+  case MPB * 16:                                                                                               \
+    if (white)                                                                                                 \
+      return kern_kind == DSDGP_KERN_RBF ? bwd_dispatch<MPB, DSDGP_KERN_RBF, true>(ctx, a)                     \
+                                         : bwd_dispatch<MPB, DSDGP_KERN_MATERN52, true>(ctx, a);               \
+    return kern_kind == DSDGP_KERN_RBF ? bwd_dispatch<MPB, DSDGP_KERN_RBF, false>(ctx, a)                      \
+                                       : bwd_dispatch<MPB, DSDGP_KERN_MATERN52, false>(ctx, a);
   switch (Mp) {
     BWD_CASE(2)
     BWD_CASE(4)

@@ -37,62 +37,58 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
 
-  for (int b = b0; b < b1; ++b) {
+  // software pipeline over (batch, k-tile) steps: the global loads of step t+1 are issued before the MFMAs of step t
+  const int ksteps = (P.k + GK - 1) / GK;
+  const int nsteps = (b1 - b0) * ksteps;
+  double ra[4], rb[4];
+  auto gload = [&](int step) {
+    const int b = b0 + step / ksteps, k0 = (step % ksteps) * GK;
     const double* A = P.A + (int64_t)b * P.sA;
     const double* B = P.B + (int64_t)b * P.sB;
-    for (int k0 = 0; k0 < P.k; k0 += GK) {
-      if (!P.transA) {
-        const int kk = tid & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int mm = (tid >> 4) + 16 * i;
-          double v = 0.0;
-          if (m0 + mm < P.m && k0 + kk < P.k) v = A[(int64_t)(m0 + mm) * P.lda + k0 + kk];
-          As[kk * GLD + mm] = v;
-        }
-      } else {
-        const int mm = tid & 63;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kk = (tid >> 6) + 4 * i;
-          double v = 0.0;
-          if (m0 + mm < P.m && k0 + kk < P.k) v = A[(int64_t)(k0 + kk) * P.lda + m0 + mm];
-          As[kk * GLD + mm] = v;
-        }
-      }
-      if (!P.transB) {
-        const int nn = tid & 63;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kk = (tid >> 6) + 4 * i;
-          double v = 0.0;
-          if (n0 + nn < P.n && k0 + kk < P.k) v = B[(int64_t)(k0 + kk) * P.ldb + n0 + nn];
-          Bs[kk * GLD + nn] = v;
-        }
-      } else {
-        const int kk = tid & 15;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int nn = (tid >> 4) + 16 * i;
-          double v = 0.0;
-          if (n0 + nn < P.n && k0 + kk < P.k) v = B[(int64_t)(n0 + nn) * P.ldb + k0 + kk];
-          Bs[kk * GLD + nn] = v;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k4 = 0; k4 < GK; k4 += 4) {
-        const double a0 = As[(k4 + g) * GLD + wr * 32 + c];
-        const double a1 = As[(k4 + g) * GLD + wr * 32 + 16 + c];
-        const double b0v = Bs[(k4 + g) * GLD + wc * 32 + c];
-        const double b1v = Bs[(k4 + g) * GLD + wc * 32 + 16 + c];
-        acc[0][0] = mfma_f64(a0, b0v, acc[0][0]);
-        acc[0][1] = mfma_f64(a0, b1v, acc[0][1]);
-        acc[1][0] = mfma_f64(a1, b0v, acc[1][0]);
-        acc[1][1] = mfma_f64(a1, b1v, acc[1][1]);
-      }
-      __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      int mm, kk;
+      if (!P.transA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; } else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+      double v = 0.0;
+      if (m0 + mm < P.m && k0 + kk < P.k)
+        v = P.transA ? A[(int64_t)(k0 + kk) * P.lda + m0 + mm] : A[(int64_t)(m0 + mm) * P.lda + k0 + kk];
+      ra[i] = v;
+      int nn, k2;
+      if (!P.transB) { nn = tid & 63; k2 = (tid >> 6) + 4 * i; } else { k2 = tid & 15; nn = (tid >> 4) + 16 * i; }
+      double w = 0.0;
+      if (n0 + nn < P.n && k0 + k2 < P.k)
+        w = P.transB ? B[(int64_t)(n0 + nn) * P.ldb + k0 + k2] : B[(int64_t)(k0 + k2) * P.ldb + n0 + nn];
+      rb[i] = w;
     }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int mm, kk;
+      if (!P.transA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; } else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+      As[kk * GLD + mm] = ra[i];
+      int nn, k2;
+      if (!P.transB) { nn = tid & 63; k2 = (tid >> 6) + 4 * i; } else { k2 = tid & 15; nn = (tid >> 4) + 16 * i; }
+      Bs[k2 * GLD + nn] = rb[i];
+    }
+  };
+  if (nsteps > 0) gload(0);
+  for (int step = 0; step < nsteps; ++step) {
+    lstore();
+    __syncthreads();
+    if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+    for (int k4 = 0; k4 < GK; k4 += 4) {
+      const double a0 = As[(k4 + g) * GLD + wr * 32 + c];
+      const double a1 = As[(k4 + g) * GLD + wr * 32 + 16 + c];
+      const double b0v = Bs[(k4 + g) * GLD + wc * 32 + c];
+      const double b1v = Bs[(k4 + g) * GLD + wc * 32 + 16 + c];
+      acc[0][0] = mfma_f64(a0, b0v, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1v, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0v, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1v, acc[1][1]);
+    }
+    __syncthreads();
   }
   double* C = P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC);
 #pragma unroll
@@ -134,18 +130,30 @@ int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_til
 // ------------------------------------------------------------------------------------------------------
 // Blocked Cholesky + triangular inverse, one 256-thread workgroup per matrix, NB = 16.
 // ------------------------------------------------------------------------------------------------------
+// INLDS: the working matrix lives in LDS (n <= 128: n x (n+4) doubles <= 135 KB of the 160 KB), so the ~35 dependent
+// phases of the factorisation pay LDS latency instead of L2 round trips; the result is written back at the end.
+template <bool INLDS>
 __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict__ items) {
-  __shared__ double Ld[16 * 17];
-  __shared__ double Xd[16 * 17];
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* Ld = dyn;               // 16 x 17
+  double* Xd = dyn + 16 * 17;     // 16 x 17
+  double* s_red = dyn + 2 * 16 * 17;   // 4
   __shared__ int s_info;
-  __shared__ double s_red[4];
   const PotrfItem it = items[blockIdx.x];
-  const int n = it.n, ld = it.ld, nb = n / 16;
-  double* __restrict__ W = it.W;
+  const int n = it.n, nb = n / 16;
+  const int ld = INLDS ? n + 4 : it.ld;
+  double* __restrict__ W = INLDS ? dyn + 2 * 16 * 17 + 8 : it.W;
   double* __restrict__ Linv = it.Linv;
+  const int ldi = it.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   if (tid == 0) s_info = 0;
+  if (INLDS) {
+    for (int idx = tid; idx < n * n; idx += 256) {
+      const int i = idx / n, j = idx % n;
+      W[i * ld + j] = it.W[(int64_t)i * it.ld + j];
+    }
+  }
   __syncthreads();
 
   for (int jb = 0; jb < nb; ++jb) {
@@ -156,11 +164,13 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       double a[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) a[j] = W[(int64_t)(j0 + i) * ld + j0 + j];
+      double myinv = 0.0;   // 1 / L_ii of this lane's row, reused by the triangular inverse (no f64 divisions)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double ajj = __shfl(a[j], j, 64);
         if (!(ajj > 0.0) && lane == 0 && s_info == 0) s_info = j0 + j + 1;
-        const double inv = 1.0 / sqrt(ajj);
+        const double inv = rsqrt(ajj);
+        if (i == j) myinv = inv;
         const double lij = (i >= j) ? a[j] * inv : 0.0;
         a[j] = lij;
 #pragma unroll
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
           Ld[i * 17 + j] = v;
           W[(int64_t)(j0 + i) * ld + j0 + j] = v;
         }
+        Ld[i * 17 + 16] = myinv;
       }
     }
     __syncthreads();
@@ -187,12 +198,12 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
         double s = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= Ld[i * 17 + k] * x[k];
-        x[i] = s / Ld[i * 17 + i];
+        x[i] = s * Ld[i * 17 + 16];
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         Xd[i * 17 + lane] = x[i];
-        if (Linv) Linv[(int64_t)(j0 + i) * ld + j0 + lane] = x[i];
+        if (Linv) Linv[(int64_t)(j0 + i) * ldi + j0 + lane] = x[i];
       }
     }
     __syncthreads();
@@ -230,11 +241,13 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     }
     __syncthreads();
   }
-  // zero the strict upper triangle of L
+  // zero the strict upper triangle of L (and write the factor back when it lived in LDS)
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx / n, j = idx % n;
     if (j > i) W[(int64_t)i * ld + j] = 0.0;
+    if (INLDS) it.W[(int64_t)i * it.ld + j] = (j > i) ? 0.0 : W[(int64_t)i * ld + j];
   }
+  __syncthreads();
   // logdet over the real (unpadded) part
   {
     double s = 0.0;
@@ -257,18 +270,18 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const double a = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
-          const double b = Linv[(int64_t)(kb * 16 + 4 * s + g) * ld + jb2 * 16 + c];
+          const double b = Linv[(int64_t)(kb * 16 + 4 * s + g) * ldi + jb2 * 16 + c];
           S = mfma_f64(a, b, S);
         }
       }
       d4 R = (d4){0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const double a = -Linv[(int64_t)(ib * 16 + c) * ld + ib * 16 + 4 * s + g];
+        const double a = -Linv[(int64_t)(ib * 16 + c) * ldi + ib * 16 + 4 * s + g];
         R = mfma_f64(a, S[s], R);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Linv[(int64_t)(ib * 16 + g + 4 * r) * ld + jb2 * 16 + c] = R[r];
+      for (int r = 0; r < 4; ++r) Linv[(int64_t)(ib * 16 + g + 4 * r) * ldi + jb2 * 16 + c] = R[r];
     }
     __syncthreads();
   }
@@ -276,16 +289,24 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     const int i = idx / n, j = idx % n;
     double v = 0.0;
     if (j <= i)
-      v = Linv[(int64_t)i * ld + j];
+      v = Linv[(int64_t)i * ldi + j];
     else
-      Linv[(int64_t)i * ld + j] = 0.0;
-    if (it.LinvT) it.LinvT[(int64_t)j * ld + i] = v;
+      Linv[(int64_t)i * ldi + j] = 0.0;
+    if (it.LinvT) it.LinvT[(int64_t)j * ldi + i] = v;
   }
 }
 
-int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems) {
+int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max) {
   ProfScope ps(ctx, "potrf");
-  hipLaunchKernelGGL(k_potrf_trtri, dim3(nitems), dim3(256), 0, ctx->stream, dev_items);
+  const size_t base = (2 * 16 * 17 + 8) * sizeof(double);
+  if (n_max <= 128) {
+    const size_t lds = base + (size_t)n_max * (n_max + 4) * sizeof(double);
+    if (lds > 64 * 1024)
+      DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items);
+  } else {
+    hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -332,7 +353,7 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   DS_HIP(hipMemcpyAsync(items_d, items.data(), batch * sizeof(PotrfItem), hipMemcpyHostToDevice, ctx->stream));
   DS_HIP(hipStreamSynchronize(ctx->stream));  // items vector is stack-lifetime
   hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
-  DS_TRY(potrf_launch(ctx, items_d, batch));
+  DS_TRY(potrf_launch(ctx, items_d, batch, np));
   hipLaunchKernelGGL(k_unpad, dim3(ceil_div(n * n, 256), batch), dim3(256), 0, ctx->stream, P, np, A, lda, stride, n);
   DS_HIP(hipGetLastError());
   if (info) {
@@ -370,8 +391,10 @@ extern "C" int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, 
 
 // B <- L^{-1} B (trans=0) or L^{-T} B (trans=1): explicit blocked inverse of L (k_potrf_trtri's second half would need
 // the factor; here L is given, so pad it, invert it with the same blocked recurrence, then one MFMA GEMM).
-__global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ W, double* __restrict__ Linv, int n) {
-  // W: padded lower-triangular L (n multiple of 16, identity pad). Reuses the recurrence of k_potrf_trtri.
+__global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ Wb, double* __restrict__ Linvb, int n, int64_t stride) {
+  // W: padded lower-triangular L (n multiple of 16, identity pad), one matrix per workgroup. Recurrence of k_potrf_trtri.
+  double* __restrict__ W = Wb + (int64_t)blockIdx.x * stride;
+  double* __restrict__ Linv = Linvb + (int64_t)blockIdx.x * stride;
   __shared__ double Ld[16 * 17];
   const int ld = n, nb = n / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -450,7 +473,7 @@ extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const 
   double* Bc = (double*)((char*)scr + 2 * mat);
   GemmProblem* Pd = (GemmProblem*)((char*)scr + 2 * mat + rhs);
   hipLaunchKernelGGL(k_pad_tril, dim3(ceil_div(np * np, 256)), dim3(256), 0, ctx->stream, L, ldl, n, Lp, np);
-  hipLaunchKernelGGL(k_trtri_only, dim3(1), dim3(256), 0, ctx->stream, Lp, Li, np);
+  hipLaunchKernelGGL(k_trtri_only, dim3(1), dim3(256), 0, ctx->stream, Lp, Li, np, (int64_t)0);
   const int nblk = (int)std::min<int64_t>(4096, ceil_div((int64_t)n * nrhs, 256));
   hipLaunchKernelGGL(k_copy2d, dim3(nblk), dim3(256), 0, ctx->stream, B, ldb, Bc, nrhs, n, nrhs);
   GemmProblem P{};
@@ -463,4 +486,10 @@ extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const 
   DS_HIP(hipMemcpyAsync(Pd, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
   DS_HIP(hipStreamSynchronize(ctx->stream));
   return gemm_launch(ctx, Pd, 1, total);
+}
+
+int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch) {
+  hipLaunchKernelGGL(k_trtri_only, dim3(batch), dim3(256), 0, ctx->stream, W, Linv, n, stride);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
 }

@@ -29,4 +29,7 @@ struct PotrfItem {
 int gemm_plan(GemmProblem* host, int nprob);
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles);
-int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems);
+// n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant
+int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max);
+// batched inverse of padded lower-triangular matrices (n multiple of 16, identity pad), one workgroup each
+int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch);

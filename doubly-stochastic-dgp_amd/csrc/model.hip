@@ -20,7 +20,12 @@ struct LayerDev {
   double *V, *nL, *Sd, *klv;
   double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
   double *bigred, *thinq, *thinz, *hyp_red;
+  double *klpart, *hyp2part;   // [NPART] KL partial sums ; [NPART][D_in + 2] Ku-side hyper-parameter partials
+  double *wLbar, *wH, *wY, *wX;  // white=True: Cholesky-adjoint temporaries (Mp x Mp each)
+  // natural-gradient temporaries, (D_out x Mp x Mp) each unless noted
+  double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngSplus, *ngTheta1 /* D_out x Mp */, *ngScal /* 4 x D_out */;
 };
+#define NPART 32
 
 struct RedJob {
   const double* part;
@@ -38,6 +43,9 @@ struct LayerState {
   double *A, *E, *GW, *VB, *MB, *XT1;
   double *F, *mean, *var, *zbuf, *dF;
   double *part_big, *part_thin, *hyp_part;
+  GemmProblem* ng_gp;  // device: 5 natural-gradient GEMM problems (H, Sinv | Y | X | Splus)
+  PotrfItem* ng_items; // device: 2 * D_out factorisation items (A_d, then Splus_d)
+  int ng_t1, ng_t2, ng_t3, ng_t4;
   WgradJob* wj;        // device: (1 + D_out) big jobs followed by 2 thin jobs, rebuilt when (n, S) changes
   int ns_big, ns_thin, tot_big, tot_thin;
   // z actually used by the last forward (for the backward pass)
@@ -64,8 +72,8 @@ struct dsdgp_model {
   double *lik_dmean, *lik_dvar;
   double* scal4;       // internal copy of out
   PotrfItem* potrf_items;
-  GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2;
-  int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2;
+  GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2, *gp_w1, *gp_w2, *gp_w3;
+  int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
   RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
   int rjobs_cap, n_red, red_blocks;
   int64_t plan_n;
@@ -115,6 +123,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->gp_fwd = b.take<GemmProblem>(4 * D.L);
   m->gp_bwd1 = b.take<GemmProblem>(3 * D.L);
   m->gp_bwd2 = b.take<GemmProblem>(D.L);
+  m->gp_w1 = b.take<GemmProblem>(2 * D.L); m->gp_w2 = b.take<GemmProblem>(D.L); m->gp_w3 = b.take<GemmProblem>(D.L);
   m->rjobs_cap = 0;
   for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 4;
   m->rjobs = b.take<RedJob>(m->rjobs_cap);
@@ -139,11 +148,19 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.V = b.take<double>(d.D_out * MM); v.nL = b.take<double>(Mp * v.DP4); v.Sd = b.take<double>(d.D_out * MM);
     v.klv = b.take<double>(8);
     v.U = b.take<double>(d.D_out * MM); v.n4 = b.take<double>(Mp * v.DP4); v.PT = b.take<double>(d.D_out * MM);
-    v.UU = b.take<double>(MM); v.Kbar = b.take<double>(MM); v.wm = b.take<double>(MM); v.wk = b.take<double>(MM);
+    v.UU = b.take<double>(d.D_out * MM); v.Kbar = b.take<double>(MM); v.wm = b.take<double>(MM); v.wk = b.take<double>(MM);
     v.bigred = b.take<double>((1 + d.D_out) * MM);
     v.thinq = b.take<double>(Mp * v.DP16);
     v.thinz = b.take<double>(Mp * v.DinP16);
     v.hyp_red = b.take<double>(d.D_in + 2 + 8);
+    v.klpart = b.take<double>(64);
+    v.ngTI = b.take<double>(d.D_out * MM); v.ngTinv = b.take<double>(d.D_out * MM); v.ngTbar = b.take<double>(d.D_out * MM);
+    v.ngH = b.take<double>(d.D_out * MM); v.ngY = b.take<double>(d.D_out * MM); v.ngX = b.take<double>(d.D_out * MM);
+    v.ngSinv = b.take<double>(d.D_out * MM); v.ngA = b.take<double>(d.D_out * MM); v.ngLAinv = b.take<double>(d.D_out * MM);
+    v.ngLAinvT = b.take<double>(d.D_out * MM); v.ngSplus = b.take<double>(d.D_out * MM);
+    v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
+    v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
+    v.hyp2part = b.take<double>(64 * (d.D_in + 2));
     S.R_max = (int64_t)m->s_max * m->n_max;
     const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
     S.ld_max = round_up(Rin_max, 16);
@@ -162,6 +179,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
     S.hyp_part = b.take<double>((size_t)(S.ld_max / 16) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 3);
+    S.ng_gp = b.take<GemmProblem>(5);
+    S.ng_items = b.take<PotrfItem>(2 * d.D_out);
   }
   *total = (size_t)round_up((int64_t)b.off, 256);
 }
@@ -244,29 +263,36 @@ __device__ double block_sum_256(double x, double* sh) {
 }
 
 // SVGP_Layer.KL (layers.py:221-246); V = Lu^-1 q_sqrt_d and nL = Lu^-1 q_mu come from the grouped GEMM.
-__global__ __launch_bounds__(256) void k_kl(const LayerDev* __restrict__ layers) {
+// grid (NPART, L): deterministic two-stage reduction.
+__global__ __launch_bounds__(256) void k_kl_part(const LayerDev* __restrict__ layers) {
   __shared__ double sh[4];
-  const LayerDev v = layers[blockIdx.x];
-  const int Mp = v.Mp, M = v.M, tid = threadIdx.x;
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp, M = v.M;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)NPART * 256;
   double acc = 0.0;
-  for (int idx = tid; idx < v.D_out * M; idx += 256) {
-    const int d = idx / M, i = idx % M;
+  for (int64_t idx = t0; idx < (int64_t)v.D_out * M; idx += nth) {
+    const int d = (int)(idx / M), i = (int)(idx % M);
     const double t = v.Tp[((int64_t)d * Mp + i) * Mp + i];
     acc -= 0.5 * log(t * t);                                            // layers.py:235
   }
   if (!v.white) {
-    for (int64_t idx = tid; idx < (int64_t)v.D_out * Mp * Mp; idx += 256) acc += 0.5 * v.V[idx] * v.V[idx];   // :239
-    for (int idx = tid; idx < Mp * v.DP4; idx += 256) acc += 0.5 * v.nL[idx] * v.nL[idx];                     // :240-241
+    for (int64_t idx = t0; idx < (int64_t)v.D_out * Mp * Mp; idx += nth) acc = fma(0.5 * v.V[idx], v.V[idx], acc);   // :239
+    for (int64_t idx = t0; idx < (int64_t)Mp * v.DP4; idx += nth) acc = fma(0.5 * v.nL[idx], v.nL[idx], acc);       // :240-241
   } else {
-    for (int64_t idx = tid; idx < (int64_t)v.D_out * Mp * Mp; idx += 256) acc += 0.5 * v.Tp[idx] * v.Tp[idx];  // :243
-    for (int idx = tid; idx < Mp * v.D_out; idx += 256) acc += 0.5 * v.qmu[idx] * v.qmu[idx];                  // :244
+    for (int64_t idx = t0; idx < (int64_t)v.D_out * Mp * Mp; idx += nth) acc = fma(0.5 * v.Tp[idx], v.Tp[idx], acc);  // :243
+    for (int64_t idx = t0; idx < (int64_t)Mp * v.D_out; idx += nth) acc = fma(0.5 * v.qmu[idx], v.qmu[idx], acc);    // :244
   }
   const double tot = block_sum_256(acc, sh);
-  if (tid == 0) {
-    double kl = tot - 0.5 * v.D_out * M;                                // layers.py:234
-    if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                      // layers.py:238 (sum log diag Lu = logdet/2)
-    v.klv[0] = kl;
-  }
+  if (threadIdx.x == 0) v.klpart[blockIdx.x] = tot;
+}
+__global__ void k_kl_final(const LayerDev* __restrict__ layers, int L) {
+  const int l = threadIdx.x;
+  if (l >= L) return;
+  const LayerDev v = layers[l];
+  double kl = -0.5 * v.D_out * v.M;                                     // layers.py:234
+  for (int b = 0; b < NPART; ++b) kl += v.klpart[b];
+  if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                        // layers.py:238 (sum log diag Lu = logdet/2)
+  v.klv[0] = kl;
 }
 
 // [UPSTREAM] Gaussian.variational_expectations (dgp.py:89-90) and its adjoints w.r.t. the last layer's mean/var.
@@ -369,18 +395,20 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
                            const double* __restrict__ var, const double* __restrict__ X, int64_t Rin, int rep, int D_in,
                            int D_out, int DP16, int DinP16, double jitter, int64_t ld, double* __restrict__ MB,
                            double* __restrict__ VB, double* __restrict__ XT1) {
+  // grid: x over rows, y over the d / j index (max(DP16, DinP16) slices)
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ld) return;
   const bool ok = r < Rin;
-  for (int d = 0; d < DP16; ++d) {
+  const int d = blockIdx.y;
+  if (d < DP16) {
     double mb = 0.0, vb = 0.0;
     if (ok && d < D_out) {
       for (int s = 0; s < rep; ++s) {
-        const int64_t o = ((int64_t)s * Rin + r) * D_out + d;
+        const int64_t orow = (int64_t)s * Rin + r;
+        const int64_t o = orow * D_out + d;
         if (dF) {
           const double f = dF[o];
           mb += f;
-          const int64_t orow = (int64_t)s * Rin + r;
           vb += f * z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d] / (2.0 * sqrt(var[o] + jitter));
         }
         if (dmean) {
@@ -392,10 +420,10 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
     MB[(int64_t)d * ld + r] = mb;
     VB[(int64_t)d * ld + r] = vb;
   }
-  for (int j = 0; j < DinP16; ++j) {
+  if (d < DinP16) {
     double v = 0.0;
-    if (ok) v = (j < D_in) ? X[r * D_in + j] : (j == D_in ? 1.0 : 0.0);
-    XT1[(int64_t)j * ld + r] = v;
+    if (ok) v = (d < D_in) ? X[r * D_in + d] : (d == D_in ? 1.0 : 0.0);
+    XT1[(int64_t)d * ld + r] = v;
   }
 }
 
@@ -405,9 +433,14 @@ __global__ void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs) {
   const RedJob J = jobs[jb];
   const int64_t i = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
   if (i >= J.count) return;
-  double s = 0.0;
-  for (int sp = 0; sp < J.nsplit; ++sp) s += J.part[(int64_t)sp * J.count + i];
-  J.out[i] = s;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int sp = 0;
+  for (; sp + 8 <= J.nsplit; sp += 8) {     // eight independent loads in flight; fixed order -> deterministic
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.count + i];
+  }
+  for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.count + i];
+  J.out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu
@@ -421,10 +454,18 @@ __global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
     const int i = idx / Mp, j = idx % Mp;
     double kb = 0.0, wm = 0.0, wk = 0.0;
     if (i < M && j < M) {
-      double nn = 0.0;
-      for (int d = 0; d < v.D_out; ++d) nn += v.n4[i * v.DP4 + d] * v.n4[j * v.DP4 + d];
-      kb = -0.5 * (G[i * Mp + j] + G[j * Mp + i]) +
-           kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * v.UU[idx] - 0.5 * nn);
+      double nn = 0.0, uu = 0.0;
+      if (!v.white)
+        for (int d = 0; d < v.D_out; ++d) {
+          nn += v.n4[i * v.DP4 + d] * v.n4[j * v.DP4 + d];
+          uu += v.UU[(int64_t)d * Mp * Mp + idx];
+        }
+      if (v.white) {
+        kb = 0.5 * (v.wX[i * Mp + j] + v.wX[j * Mp + i]);   // KL(white) does not depend on Ku (layers.py:243-244)
+      } else {
+        kb = -0.5 * (G[i * Mp + j] + G[j * Mp + i]) +
+             kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
+      }
       double r2 = 0.0;
       for (int q = 0; q < v.D_in; ++q) {
         const double df = (v.Zp[i * v.D_in + q] - v.Zp[j * v.D_in + q]) * ils[q];
@@ -444,68 +485,110 @@ __global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
   }
 }
 
-// final assembly of d loss / d theta for one layer (one workgroup per layer)
-__global__ __launch_bounds__(256) void k_asm_final(const LayerDev* __restrict__ layers, const double* __restrict__ theta,
-                                                   double* __restrict__ grad, double kl_w) {
-  __shared__ double sh[4];
-  const LayerDev v = layers[blockIdx.x];
-  const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out, tid = threadIdx.x;
+// white=True helpers: Lu_bar = -tril(G) ; Phi(H) = tril(H) with halved diagonal (in place)
+__global__ void k_white_lbar(const LayerDev* __restrict__ layers) {
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
+    const int i = idx / Mp, j = idx % Mp;
+    v.wLbar[idx] = (i < v.M && j <= i) ? -v.bigred[idx] : 0.0;
+  }
+}
+__global__ void k_white_phi(const LayerDev* __restrict__ layers) {
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
+    const int i = idx / Mp, j = idx % Mp;
+    const double h = v.wH[idx];
+    v.wH[idx] = (j < i) ? h : (j == i ? 0.5 * h : 0.0);
+  }
+}
+
+// final assembly of d loss / d theta: elementwise part, grid (blocks, L)
+__global__ void k_asm_params(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w) {
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   const double* ils = v.hyp + HYP_ILS;
   // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
-  for (int64_t idx = tid; idx < (int64_t)Dout * M * M; idx += 256) {
+  for (int64_t idx = t0; idx < (int64_t)Dout * M * M; idx += nth) {
     const int d = (int)(idx / ((int64_t)M * M)), rem = (int)(idx % ((int64_t)M * M)), i = rem / M, j = rem % M;
     double gq = 0.0;
     if (j <= i) {
       const int64_t p = ((int64_t)d * Mp + i) * Mp + j;
-      gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
+      gq = 2.0 * v.PT[p] + kl_w * ((v.white ? v.Tp[p] : v.U[p]) - (i == j ? 1.0 / v.Tp[p] : 0.0));
     }
     grad[v.off_q_sqrt + idx] = gq;
   }
   // q_mu: A mbar + kl_w Ku^-1 q_mu
-  for (int idx = tid; idx < M * Dout; idx += 256) {
-    const int i = idx / Dout, d = idx % Dout;
-    grad[v.off_q_mu + idx] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
+  for (int64_t idx = t0; idx < (int64_t)M * Dout; idx += nth) {
+    const int i = (int)(idx / Dout), d = (int)(idx % Dout);
+    grad[v.off_q_mu + idx] = v.thinq[i * v.DP16 + d] + kl_w * (v.white ? v.qmu4[i * v.DP4 + d] : v.n4[i * v.DP4 + d]);
   }
   // Z: through Kuf (GW [X|1]) and through Ku (wm)
-  for (int idx = tid; idx < M * Din; idx += 256) {
-    const int i = idx / Din, q = idx % Din;
+  for (int64_t idx = t0; idx < (int64_t)M * Din; idx += nth) {
+    const int i = (int)(idx / Din), q = (int)(idx % Din);
     const double zi = v.Zp[i * Din + q];
     double s = 0.0;
     for (int j = 0; j < M; ++j) s = fma(v.wm[i * Mp + j], zi - v.Zp[j * Din + q], s);
     const double il2 = ils[q] * ils[q];
     grad[v.off_Z + idx] = 4.0 * il2 * s - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
   }
-  // kernel variance
+}
+
+// Ku-side hyper-parameter partial sums, grid (NPART, L): part[b] = { sum wk, trace Kbar, sum_q wm (z_i-z_j)_q^2 ... }
+__global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict__ layers) {
+  __shared__ double sh[4];
+  const LayerDev v = layers[blockIdx.y];
+  const int Mp = v.Mp, M = v.M, Din = v.D_in;
+  const int t0 = blockIdx.x * 256 + threadIdx.x, nth = NPART * 256;
+  double* out = v.hyp2part + (int64_t)blockIdx.x * (Din + 2);
   double a = 0.0, tr = 0.0;
-  for (int idx = tid; idx < M * M; idx += 256) {
+  for (int idx = t0; idx < M * M; idx += nth) {
     const int i = idx / M, j = idx % M;
     a += v.wk[i * Mp + j];
     if (i == j) tr += v.Kbar[i * Mp + i];
   }
   a = block_sum_256(a, sh);
   tr = block_sum_256(tr, sh);
-  if (tid == 0) {
-    grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
-    if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
+  if (threadIdx.x == 0) {
+    out[0] = a;
+    out[1] = tr;
   }
-  // lengthscales
-  double iso = 0.0;
   for (int q = 0; q < Din; ++q) {
     double s = 0.0;
-    for (int idx = tid; idx < M * M; idx += 256) {
+    for (int idx = t0; idx < M * M; idx += nth) {
       const int i = idx / M, j = idx % M;
       const double df = v.Zp[i * Din + q] - v.Zp[j * Din + q];
       s = fma(v.wm[i * Mp + j], df * df, s);
     }
     s = block_sum_256(s, sh);
-    const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
-    if (v.ard) {
-      if (tid == 0) grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
-    } else {
-      iso += gl;
-    }
+    if (threadIdx.x == 0) out[2 + q] = s;
   }
-  if (!v.ard && tid == 0) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
+}
+__global__ void k_asm_hyp_final(const LayerDev* __restrict__ layers, double* __restrict__ grad) {
+  const LayerDev v = layers[blockIdx.x];
+  const int Din = v.D_in;
+  const double* ils = v.hyp + HYP_ILS;
+  if (threadIdx.x != 0) return;
+  double a = 0.0, tr = 0.0;
+  for (int b = 0; b < NPART; ++b) {
+    a += v.hyp2part[b * (Din + 2)];
+    tr += v.hyp2part[b * (Din + 2) + 1];
+  }
+  grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
+  if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
+  double iso = 0.0;
+  for (int q = 0; q < Din; ++q) {
+    double s = 0.0;
+    for (int b = 0; b < NPART; ++b) s += v.hyp2part[b * (Din + 2) + 2 + q];
+    const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
+    if (v.ard)
+      grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
+    else
+      iso += gl;
+  }
+  if (!v.ard) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
 }
 
 __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
@@ -591,7 +674,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   const int L = desc->L;
   std::vector<LayerDev> ld(L);
   std::vector<PotrfItem> items(L);
-  std::vector<GemmProblem> gf, g1, g2;
+  std::vector<GemmProblem> gf, g1, g2, w1, w2, w3;
   for (int l = 0; l < L; ++l) {
     const LayerDev& v = m->L[l].dev;
     ld[l] = v;
@@ -613,12 +696,47 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     g1.push_back(P);
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
     g1.push_back(P);
-    fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, 0, 1);               // sum U U^T
+    fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);              // U_d U_d^T
     g2.push_back(P);
+    // white=True: d l/d Ku from d l/d Lu = -tril(G) through the Cholesky adjoint  Ku_bar = sym(Lu^-T Phi(Lu^T Lu_bar) Lu^-1)
+    fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
+    w1.push_back(P);
+    fill_gemm(P, v.Kp, v.wLbar, v.wH, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, 1, 0, 0, 0, 0);                  // Lu^T Lu_bar
+    w1.push_back(P);
+    fill_gemm(P, v.wH, v.Linv, v.wY, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, 1, 0, 0, 0, 0);                   // Phi Lu^-1
+    w2.push_back(P);
+    fill_gemm(P, v.Linv, v.wY, v.wX, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, 1, 0, 0, 0, 0);                   // Lu^-T (Phi Lu^-1)
+    w3.push_back(P);
+    {
+      LayerState& St = m->L[l];
+      GemmProblem ng[5];
+      fill_gemm(ng[0], v.ngTI, v.ngTbar, v.ngH, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);        // T^T Tbar
+      fill_gemm(ng[1], v.ngTinv, v.ngTinv, v.ngSinv, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);   // S^-1
+      St.ng_t1 = gemm_plan(ng, 2);
+      fill_gemm(ng[2], v.ngH, v.ngTinv, v.ngY, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);         // Phi T^-1
+      St.ng_t2 = gemm_plan(ng + 2, 1);
+      fill_gemm(ng[3], v.ngTinv, v.ngY, v.ngX, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);         // T^-T Phi T^-1
+      St.ng_t3 = gemm_plan(ng + 3, 1);
+      fill_gemm(ng[4], v.ngLAinvT, v.ngLAinv, v.ngSplus, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);  // S+
+      St.ng_t4 = gemm_plan(ng + 4, 1);
+      DS_HIP(hipMemcpyAsync(St.ng_gp, ng, sizeof(ng), hipMemcpyHostToDevice, st));
+      std::vector<PotrfItem> it(2 * v.D_out);
+      for (int d = 0; d < v.D_out; ++d) {
+        it[d] = PotrfItem{v.ngA + d * MM, v.ngLAinv + d * MM, v.ngLAinvT + d * MM, v.ngScal + 2 * d, Mp, Mp, v.M, 0};
+        it[v.D_out + d] = PotrfItem{v.ngSplus + d * MM, nullptr, nullptr, v.ngScal + 2 * v.D_out + 2 * d, Mp, Mp, v.M, 0};
+      }
+      DS_HIP(hipMemcpyAsync(St.ng_items, it.data(), it.size() * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
+      DS_HIP(hipStreamSynchronize(st));
+    }
   }
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
   m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
   m->n_bwd2 = (int)g2.size(); m->t_bwd2 = gemm_plan(g2.data(), m->n_bwd2);
+  m->n_w = L;
+  m->t_w1 = gemm_plan(w1.data(), 2 * L); m->t_w2 = gemm_plan(w2.data(), L); m->t_w3 = gemm_plan(w3.data(), L);
+  DS_HIP(hipMemcpyAsync(m->gp_w1, w1.data(), w1.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->gp_w2, w2.data(), w2.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  DS_HIP(hipMemcpyAsync(m->gp_w3, w3.data(), w3.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
   DS_HIP(hipMemcpyAsync(m->layers_dev, ld.data(), L * sizeof(LayerDev), hipMemcpyHostToDevice, st));
   DS_HIP(hipMemcpyAsync(m->potrf_items, items.data(), L * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
   DS_HIP(hipMemcpyAsync(m->gp_fwd, gf.data(), gf.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
@@ -663,9 +781,12 @@ static int prepare_async(dsdgp_model* m) {
                      m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0);
   hipLaunchKernelGGL(k_kuu_pad, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
   DS_HIP(hipGetLastError());
-  DS_TRY(potrf_launch(ctx, m->potrf_items, L));
+  int mp_max = 0;
+  for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
+  DS_TRY(potrf_launch(ctx, m->potrf_items, L, mp_max));
   DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd));
-  hipLaunchKernelGGL(k_kl, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev);
+  hipLaunchKernelGGL(k_kl_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
+  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, ctx->stream, m->layers_dev, L);
   DS_HIP(hipGetLastError());
   m->prepared = true;
   return DSDGP_OK;
@@ -826,7 +947,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     const bool last = (l == L - 1);
     const int64_t Rin = St.Rin_used, ld = St.ld_used;
     const int rep = St.rep_used;
-    hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
+    hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                        last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
                        St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
                        St.MB, St.VB, St.XT1);
@@ -846,10 +967,20 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   }
   hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red);
   DS_HIP(hipGetLastError());
-  DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1));
-  DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2));
+  if (m->desc.white) {
+    hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+    DS_TRY(gemm_launch(ctx, m->gp_w1, 2 * L, m->t_w1));
+    hipLaunchKernelGGL(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+    DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
+    DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
+  } else {
+    DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1));
+    DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2));
+  }
   hipLaunchKernelGGL(k_asm_kbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
-  hipLaunchKernelGGL(k_asm_final, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev, m->theta, m->grad, kl_weight);
+  hipLaunchKernelGGL(k_asm_params, dim3(64, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
+  hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
+  hipLaunchKernelGGL(k_asm_hyp_final, dim3(L), dim3(64), 0, ctx->stream, m->layers_dev, m->grad);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -865,10 +996,6 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   }
   if (with_grad) {
     DS_CHECK_ARG(m->grad != nullptr);
-    if (m->desc.white) {
-      dsdgp_set_error("gradients for white=True are not built yet");
-      return DSDGP_ERR_UNSUPPORTED;
-    }
   }
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
@@ -942,4 +1069,128 @@ extern "C" int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const do
 extern "C" int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out) {
   DS_CHECK_ARG(ctx && out && count > 0);
   return randn_async(ctx, seed, stream, count, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Natural-gradient step on one layer's (q_mu, q_sqrt)  — [UPSTREAM] gpflow.training.NatGradOptimizer(gamma)
+// (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100).
+// Per output d:  Sbar = sym(T^-T Phi(T^T Tbar) T^-1);  theta1 = S^-1 m - gamma (mbar - 2 Sbar m);
+//                A = S^-1 + 2 gamma Sbar (= -2 theta2);  S+ = A^-1;  m+ = S+ theta1;  T+ = chol(S+).
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_ng_prep(const LayerDev* __restrict__ layers, int l, const double* __restrict__ grad) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp, M = v.M;
+  const int64_t tot = (int64_t)v.D_out * Mp * Mp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx / ((int64_t)Mp * Mp)), rem = (int)(idx % ((int64_t)Mp * Mp)), i = rem / Mp, j = rem % Mp;
+    const bool in = i < M && j <= i;
+    v.ngTbar[idx] = in ? grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+    v.ngTI[idx] = (i < M) ? v.Tp[idx] : (i == j ? 1.0 : 0.0);
+  }
+}
+__global__ void k_ng_phi(const LayerDev* __restrict__ layers, int l) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp;
+  const int64_t tot = (int64_t)v.D_out * Mp * Mp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int rem = (int)(idx % ((int64_t)Mp * Mp)), i = rem / Mp, j = rem % Mp;
+    const double h = v.ngH[idx];
+    v.ngH[idx] = (j < i) ? h : (j == i ? 0.5 * h : 0.0);
+  }
+}
+// A = S^-1 + 2 gamma Sbar with identity pad ; Sbar stored (symmetrised) into ngY
+__global__ void k_ng_assemble(const LayerDev* __restrict__ layers, int l, double gamma) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp, M = v.M;
+  const int64_t MM = (int64_t)Mp * Mp, tot = (int64_t)v.D_out * MM;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t base = idx / MM * MM;
+    const int rem = (int)(idx % MM), i = rem / Mp, j = rem % Mp;
+    double sb = 0.0, a = (i == j) ? 1.0 : 0.0;
+    if (i < M && j < M) {
+      sb = 0.5 * (v.ngX[base + i * Mp + j] + v.ngX[base + j * Mp + i]);
+      a = v.ngSinv[idx] + 2.0 * gamma * sb;
+    }
+    v.ngY[idx] = sb;
+    v.ngA[idx] = a;
+  }
+}
+__global__ void k_ng_theta1(const LayerDev* __restrict__ layers, int l, const double* __restrict__ grad, double gamma) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp, M = v.M;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= v.D_out * M) return;
+  const int d = idx / M, i = idx % M;
+  const double* Sinv = v.ngSinv + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
+  const double* Sbar = v.ngY + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < M; ++j) {
+    const double mj = v.qmu[j * v.D_out + d];
+    s1 = fma(Sinv[j], mj, s1);
+    s2 = fma(Sbar[j], mj, s2);
+  }
+  v.ngTheta1[d * Mp + i] = s1 - gamma * (grad[v.off_q_mu + (int64_t)i * v.D_out + d] - 2.0 * s2);
+}
+__global__ void k_ng_mu(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp, M = v.M;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= v.D_out * M) return;
+  const int d = idx / M, i = idx % M;
+  const double* Sp = v.ngSplus + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
+  double s = 0.0;
+  for (int j = 0; j < M; ++j) s = fma(Sp[j], v.ngTheta1[d * Mp + j], s);
+  theta[v.off_q_mu + (int64_t)i * v.D_out + d] = s;
+}
+__global__ void k_ng_write(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
+  const LayerDev v = layers[l];
+  const int Mp = v.Mp, M = v.M;
+  const int64_t tot = (int64_t)v.D_out * M * M;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx / ((int64_t)M * M)), rem = (int)(idx % ((int64_t)M * M)), i = rem / M, j = rem % M;
+    theta[v.off_q_sqrt + idx] = (j <= i) ? v.ngSplus[((int64_t)d * Mp + i) * Mp + j] : 0.0;
+  }
+}
+
+extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info) {
+  DS_CHECK_ARG(m && m->grad && l >= 0 && l < m->desc.L && gamma > 0);
+  dsdgp_ctx* ctx = m->ctx;
+  LayerState& St = m->L[l];
+  const LayerDev& v = St.dev;
+  const int64_t MM = (int64_t)v.Mp * v.Mp;
+  const int nb = (int)std::min<int64_t>(1024, ceil_div(v.D_out * MM, 256));
+  // Tp / qmu must reflect the current theta
+  if (!m->prepared) DS_TRY(prepare_async(m));
+  hipLaunchKernelGGL(k_ng_prep, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad);
+  DS_HIP(hipGetLastError());
+  DS_TRY(trtri_launch(ctx, v.ngTI, v.ngTinv, v.Mp, MM, v.D_out));
+  DS_TRY(gemm_launch(ctx, St.ng_gp, 2, St.ng_t1));
+  hipLaunchKernelGGL(k_ng_phi, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l);
+  DS_TRY(gemm_launch(ctx, St.ng_gp + 2, 1, St.ng_t2));
+  DS_TRY(gemm_launch(ctx, St.ng_gp + 3, 1, St.ng_t3));
+  hipLaunchKernelGGL(k_ng_assemble, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, gamma);
+  hipLaunchKernelGGL(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
+                     gamma);
+  DS_HIP(hipGetLastError());
+  DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
+  DS_TRY(gemm_launch(ctx, St.ng_gp + 4, 1, St.ng_t4));
+  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
+  DS_HIP(hipGetLastError());
+  DS_TRY(potrf_launch(ctx, St.ng_items + v.D_out, v.D_out, v.Mp));
+  hipLaunchKernelGGL(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
+  DS_HIP(hipGetLastError());
+  m->prepared = false;
+  if (info) {
+    std::vector<double> sc(4 * v.D_out);
+    DS_HIP(hipMemcpyAsync(sc.data(), v.ngScal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+    *info = 0;
+    for (int d = 0; d < 2 * v.D_out; ++d)
+      if (sc[2 * d + 1] != 0.0 && *info == 0) *info = (int)sc[2 * d + 1];
+    if (*info) {
+      dsdgp_set_error("natural-gradient step left q(u) covariance non-SPD (gamma too large?): pivot %d", *info);
+      return DSDGP_ERR_NOT_SPD;
+    }
+  }
+  return DSDGP_OK;
 }

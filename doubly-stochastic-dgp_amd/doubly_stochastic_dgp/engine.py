@@ -330,6 +330,14 @@ class Engine:
         self._dev_dirty = True
         self._needs_prepare = True
 
+    def natgrad_step(self, l, gamma, check=True):
+        """[UPSTREAM] NatGradOptimizer(gamma) step on layer l's (q_mu, q_sqrt) from the gradient of the last
+        elbo(with_grad=True)."""
+        info = C.c_int(0)
+        _lib.check(self.lib.dsdgp_model_natgrad_step(self.model, l, float(gamma), C.byref(info) if check else None))
+        self._dev_dirty = True
+        self._needs_prepare = True
+
     def layer_kl(self, l):
         self._prepare_checked()
         out = self.ctx.empty(1)

@@ -151,6 +151,12 @@ int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n
 /* [UPSTREAM] tf.train.AdamOptimizer step on theta using grad (t counts from 1). Non-trainable entries are skipped. */
 int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t);
 
+/* [UPSTREAM] gpflow.training.NatGradOptimizer(gamma) step on layer l's (q_mu, q_sqrt), using the loss gradient left in
+ * `grad` by the last dsdgp_model_elbo(with_grad=1) (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100):
+ * per output, natural parameters theta <- theta - gamma dL/d eta, then back to (mean, Cholesky factor).
+ * info (host, may be NULL): non-zero if the updated covariance is not SPD. */
+int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info);
+
 /* SVGP_Layer.KL (layers.py:221-246) of layer l after dsdgp_model_prepare; out: device scalar. */
 int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out);
 

@@ -443,3 +443,32 @@ def adam_step(theta, grad, m, v, t, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
     lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
     theta[...] = theta - lr_t * m / (np.sqrt(v) + eps)
     return theta
+
+
+# --------------------------------------------------------------------------------------------------
+# [UPSTREAM] gpflow.training.NatGradOptimizer(gamma) step on one layer's (q_mu, q_sqrt)   (SURVEY §8f row 1,
+# Appendix C; used at demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100)
+# --------------------------------------------------------------------------------------------------
+def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
+    """One natural-gradient step of a *minimised* loss on D independent Gaussians N(q_mu[:,d], T_d T_d^T).
+    g_mu (M,D), g_sqrt (D,M,M): d loss / d q_mu, d loss / d q_sqrt (lower-triangular).  Returns (q_mu+, q_sqrt+)."""
+    M, D = q_mu.shape
+    mu_new, sq_new = np.empty_like(q_mu), np.empty_like(q_sqrt)
+    for d in range(D):
+        T = np.tril(q_sqrt[d])
+        m = q_mu[:, d]
+        Tinv = _sla.solve_triangular(T, np.eye(M), lower=True)
+        H = T.T @ np.tril(g_sqrt[d])
+        Phi = np.tril(H) - 0.5 * np.diag(np.diag(H))
+        Sbar = Tinv.T @ Phi @ Tinv
+        Sbar = 0.5 * (Sbar + Sbar.T)                        # d loss / d S  (Cholesky adjoint)
+        g1 = g_mu[:, d] - 2.0 * Sbar @ m                    # d loss / d eta_1 ; d loss / d eta_2 = Sbar
+        Sinv = Tinv.T @ Tinv
+        theta1 = Sinv @ m - gamma * g1
+        A = Sinv + 2.0 * gamma * Sbar                       # -2 theta_2
+        LA = np.linalg.cholesky(A)
+        LAinv = _sla.solve_triangular(LA, np.eye(M), lower=True)
+        Splus = LAinv.T @ LAinv
+        mu_new[:, d] = Splus @ theta1
+        sq_new[d] = np.linalg.cholesky(Splus)
+    return mu_new, sq_new

@@ -248,6 +248,19 @@ def test_gradients_three_layers(kind):
     _grad_check(X, Y, spec, state, model, zs, 3, num_data=1000)
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_gradients_white(kind):
+    # white=True: dl/dKu goes through the Cholesky adjoint instead of the Ku^-1 shortcut
+    rng = np.random.RandomState(9)
+    N, D, M, S = 120, 3, 30, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec(kind, D, 1.1, 0.9, white_variance=0.03), kern_spec(kind, D, 0.8, 1.2)]
+    spec, state, model = make_case(X, Y, Z, specs, white=True, S=S, num_data=600)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=600)
+
+
 def test_gradients_cfg2_shape_slice():
     X, Y, spec, state, model, zs = _three_layer(N=64, D=8, M=128, S=4, num_data=7372, seed=3)
     _grad_check(X, Y, spec, state, model, zs, 4, num_data=7372)
@@ -332,3 +345,51 @@ def test_minibatch_gather_pairs_rows():
         Xb, Yb = model.next_minibatch()
         assert Xb.shape == (64, 3)
         assert np.array_equal(Yb.cpu().numpy(), Xb.cpu().numpy()[:, :1] * 2.0)
+
+
+# ---------------------------------------------------------------- natural gradients
+@pytest.mark.parametrize("white", [False, True])
+def test_natgrad_step_matches_oracle(white):
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(12)
+    N, D, M, S = 80, 2, 20, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 3)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 1.0), kern_spec("rbf", D, 1.2, 0.8)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=300)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 3)]
+    _, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=300)
+    mu, sq = O.natgrad_step(state["l1.q_mu"], state["l1.q_sqrt"], -g["l1.q_mu"], -g["l1.q_sqrt"], 0.1)
+    last = model.layers[-1]
+    NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    assert_allclose(last.q_mu.value, mu, rtol=1e-7, atol=1e-9)
+    assert_allclose(last.q_sqrt.value, sq, rtol=1e-7, atol=1e-9)
+    state2 = dict(state)
+    state2["l1.q_mu"], state2["l1.q_sqrt"] = mu, sq
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, state2, X, Y, zs, S, num_data=300), rtol=1e-8)
+
+
+def test_natgrad_gamma1_gives_collapsed_bound():
+    # tests/test_collapsed.py:57-104 on the device: gamma = 1, Gaussian likelihood, one step => SGPR collapsed bound
+    import math
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(8)
+    N, M, s2 = 40, 9, 0.2
+    X = rng.uniform(size=(N, 1)) * 4
+    Y = np.sin(2 * X) + 0.3 * rng.randn(N, 1)
+    Z = np.linspace(0, 4, M)[:, None]
+    specs = [kern_spec("rbf", 1, 1.3, 0.7)]
+    spec, state, model = make_case(X, Y, Z, specs, S=1, lik_var=s2)
+    zs = [np.zeros((1, N, 1))]
+    layer = model.layers[0]
+    NatGradOptimizer(1.0).minimize(model, var_list=[[layer.q_mu, layer.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    elbo = model.compute_log_likelihood(X, Y, zs=zs)
+    kern = O.Kern("rbf", 1, variance=1.3, lengthscales=0.7)
+    Kuu = kern.K(O.NP, Z) + 1e-6 * np.eye(M)
+    Kuf = kern.K(O.NP, Z, X)
+    Qff = Kuf.T @ np.linalg.solve(Kuu, Kuf)
+    Cm = Qff + s2 * np.eye(N)
+    _, ld = np.linalg.slogdet(Cm)
+    bound = (-0.5 * Y.T @ np.linalg.solve(Cm, Y)).item() - 0.5 * ld - 0.5 * N * math.log(2 * math.pi) \
+        - 0.5 / s2 * (kern.Kdiag(O.NP, X).sum() - np.trace(Qff))
+    assert_allclose(elbo, bound, rtol=1e-7)

@@ -248,3 +248,34 @@ def test_adam_known_answer():
     O.adam_step(th, g, m, v, 1, lr=0.01)
     # first Adam step moves each coordinate by lr*sign(g) (up to eps)
     assert_allclose(th, [1.0 - 0.01, -2.0 + 0.01], atol=1e-7)
+
+
+# T4 — one natural-gradient step with gamma=1 on the last layer of a Gaussian-likelihood model lands on the collapsed
+# (SGPR) bound (tests/test_collapsed.py:57-104; bound formula layers.py:371-402 re-stated in dense textbook form)
+@pytest.mark.parametrize("white", [False, True])
+def test_T4_natgrad_gamma1_gives_collapsed_bound(white):
+    rng = np.random.RandomState(8)
+    N, M, s2 = 40, 9, 0.2
+    X = rng.uniform(size=(N, 1)) * 4
+    Y = np.sin(2 * X) + 0.3 * rng.randn(N, 1)
+    Z = np.linspace(0, 4, M)[:, None]
+    specs = [dict(kind="rbf", input_dim=1, variance=1.3, lengthscales=0.7, ARD=False, white_variance=None)]
+    lds = O.init_layers_linear(X, Y, Z, specs, white=white)
+    lds[0]["q_mu"] = 0.3 * rng.randn(M, 1)
+    sl, state = OM.state_from_layers(lds, lik_variance=s2)
+    spec = dict(jitter=1e-6, white=white, likelihood="gaussian", layers=sl)
+    zs = [np.zeros((1, N, 1))]
+    _, g = OM.elbo_and_grad(spec, state, X, Y, zs, 1)
+    mu, sq = O.natgrad_step(state["l0.q_mu"], state["l0.q_sqrt"], -g["l0.q_mu"], -g["l0.q_sqrt"], 1.0)
+    state2 = dict(state)
+    state2["l0.q_mu"], state2["l0.q_sqrt"] = mu, sq
+    elbo = OM.elbo(spec, state2, X, Y, zs, 1)
+    kern = O.Kern("rbf", 1, variance=1.3, lengthscales=0.7)
+    Kuu = kern.K(NP, Z) + 1e-6 * np.eye(M)
+    Kuf = kern.K(NP, Z, X)
+    Qff = Kuf.T @ np.linalg.solve(Kuu, Kuf)
+    C = Qff + s2 * np.eye(N)
+    _, ld = np.linalg.slogdet(C)
+    bound = (-0.5 * Y.T @ np.linalg.solve(C, Y)).item() - 0.5 * ld - 0.5 * N * math.log(2 * math.pi) \
+        - 0.5 / s2 * (kern.Kdiag(NP, X).sum() - np.trace(Qff))
+    assert_allclose(elbo, bound, rtol=1e-7)
