@@ -121,6 +121,15 @@ __device__ __forceinline__ double sum_wave(double x) {
   return sum_groups(x);
 }
 
+// broadcast of lane `L` (compile-time constant) of a double through two v_readlane_b32 (far cheaper than the
+// ds_bpermute pair behind __shfl)
+template <int L>
+__device__ __forceinline__ double bcast_lane(double x) {
+  const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(x), L);
+  const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(x), L);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
 // hyper-parameter block layout (device doubles) produced by k_prep for every layer:
 //   hyp[0]=variance hyp[1]=white_variance hyp[2]=kdiag (=variance+white) hyp[3]=sigmoid(raw var) hyp[4]=sigmoid(raw white)
 //   hyp[8 + j]            = 1/lengthscale_j                   (j < D_in)

@@ -132,17 +132,53 @@ int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_til
 // ------------------------------------------------------------------------------------------------------
 // INLDS: the working matrix lives in LDS (n <= 128: n x (n+4) doubles <= 135 KB of the 160 KB), so the ~35 dependent
 // phases of the factorisation pay LDS latency instead of L2 round trips; the result is written back at the end.
+template <int J, int K>
+struct Chol16Upd {
+  static __device__ __forceinline__ void run(double (&a)[16], double lij) {
+    const double lkj = bcast_lane<K>(lij);
+    a[K] -= lij * lkj;
+    Chol16Upd<J, K + 1>::run(a, lij);
+  }
+};
+template <int J>
+struct Chol16Upd<J, 16> {
+  static __device__ __forceinline__ void run(double (&)[16], double) {}
+};
+template <int J>
+struct Chol16 {
+  static __device__ __forceinline__ void run(double (&a)[16], int i, double& myinv, int& bad) {
+    const double ajj = bcast_lane<J>(a[J]);
+    if (!(ajj > 0.0) && bad == 0) bad = J + 1;
+    const double inv = rsqrt(ajj);
+    if (i == J) myinv = inv;
+    const double lij = (i >= J) ? a[J] * inv : 0.0;
+    a[J] = lij;
+    Chol16Upd<J, J + 1>::run(a, lij);
+    Chol16<J + 1>::run(a, i, myinv, bad);
+  }
+};
+template <>
+struct Chol16<16> {
+  static __device__ __forceinline__ void run(double (&)[16], int, double&, int&) {}
+};
+
+// INLDS: the working matrix lives in LDS (n <= 128: n x (n+4) doubles <= 135 KB of the 160 KB), so the dependent phases
+// of the factorisation pay LDS latency instead of L2 round trips; the factor is written back at the end.
+// Triangular inverse: block-column forward substitution — wave w owns block columns {w, nb-1-w, ...} of X = L^-1 and keeps
+// them in registers (the D layout of one 16x16 product is the B operand of the next), so there is no inter-wave
+// dependency and no barrier:  X_jj = Ljj^-1,  X_ij = -Lii^-1 * sum_{k=j}^{i-1} L_ik X_kj.
+#define POTRF_MAXNB 16
 template <bool INLDS>
-__global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict__ items) {
+__global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict__ items, int nb_max) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
-  double* Ld = dyn;               // 16 x 17
-  double* Xd = dyn + 16 * 17;     // 16 x 17
-  double* s_red = dyn + 2 * 16 * 17;   // 4
+  double* Ld = dyn;                     // 16 x 17 : current diagonal block (+ reciprocal diagonal in column 16)
+  double* s_red = dyn + 16 * 17;        // 4
+  double* Xdall = dyn + 16 * 17 + 8;    // nb x 16 x 17 : inverses of all diagonal blocks
   __shared__ int s_info;
   const PotrfItem it = items[blockIdx.x];
   const int n = it.n, nb = n / 16;
   const int ld = INLDS ? n + 4 : it.ld;
-  double* __restrict__ W = INLDS ? dyn + 2 * 16 * 17 + 8 : it.W;
+  double* __restrict__ W = INLDS ? Xdall + nb_max * 16 * 17 : it.W;
   double* __restrict__ Linv = it.Linv;
   const int ldi = it.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,27 +194,17 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 
   for (int jb = 0; jb < nb; ++jb) {
     const int j0 = jb * 16;
-    // (a) diagonal block: wave 0, lane i (<16) owns row i in registers; columns eliminated with cross-lane shuffles.
+    double* Xd = Xdall + jb * 16 * 17;
+    // (a) diagonal block: wave 0, lane i (<16) owns row i in registers; pivots/columns broadcast with v_readlane
     if (wave == 0) {
       const int i = c;
       double a[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) a[j] = W[(int64_t)(j0 + i) * ld + j0 + j];
-      double myinv = 0.0;   // 1 / L_ii of this lane's row, reused by the triangular inverse (no f64 divisions)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double ajj = __shfl(a[j], j, 64);
-        if (!(ajj > 0.0) && lane == 0 && s_info == 0) s_info = j0 + j + 1;
-        const double inv = rsqrt(ajj);
-        if (i == j) myinv = inv;
-        const double lij = (i >= j) ? a[j] * inv : 0.0;
-        a[j] = lij;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = __shfl(lij, k, 64);
-          a[k] -= lij * lkj;
-        }
-      }
+      double myinv = 0.0;
+      int bad = 0;
+      Chol16<0>::run(a, i, myinv, bad);
+      if (bad && lane == 0 && s_info == 0) s_info = j0 + bad;
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     }
     __syncthreads();
     if (wave == 0 && lane < 16) {
-      // column `lane` of X = L_jj^{-1} by forward substitution (LDS reads are broadcasts)
+      // column `lane` of X = L_jj^{-1} by forward substitution (LDS reads are broadcasts; no divisions)
       double x[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -201,10 +227,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
         x[i] = s * Ld[i * 17 + 16];
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        Xd[i * 17 + lane] = x[i];
-        if (Linv) Linv[(int64_t)(j0 + i) * ldi + j0 + lane] = x[i];
-      }
+      for (int i = 0; i < 16; ++i) Xd[i * 17 + lane] = x[i];
     }
     __syncthreads();
     // (b) panel: L_ij = A_ij * L_jj^{-T}   (16x16 MFMA products)
@@ -241,13 +264,6 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     }
     __syncthreads();
   }
-  // zero the strict upper triangle of L (and write the factor back when it lived in LDS)
-  for (int idx = tid; idx < n * n; idx += 256) {
-    const int i = idx / n, j = idx % n;
-    if (j > i) W[(int64_t)i * ld + j] = 0.0;
-    if (INLDS) it.W[(int64_t)i * it.ld + j] = (j > i) ? 0.0 : W[(int64_t)i * ld + j];
-  }
-  __syncthreads();
   // logdet over the real (unpadded) part
   {
     double s = 0.0;
@@ -260,52 +276,67 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       it.scal[1] = (double)s_info;
     }
   }
-  if (!Linv) return;
-  __syncthreads();
-  // blocked triangular inverse: Linv_ij = -Linv_ii * sum_{k=j}^{i-1} L_ik Linv_kj
-  for (int ib = 1; ib < nb; ++ib) {
-    for (int jb2 = wave; jb2 < ib; jb2 += 4) {
-      d4 S = (d4){0, 0, 0, 0};
-      for (int kb = jb2; kb < ib; ++kb) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double a = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
-          const double b = Linv[(int64_t)(kb * 16 + 4 * s + g) * ldi + jb2 * 16 + c];
-          S = mfma_f64(a, b, S);
-        }
-      }
-      d4 R = (d4){0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double a = -Linv[(int64_t)(ib * 16 + c) * ldi + ib * 16 + 4 * s + g];
-        R = mfma_f64(a, S[s], R);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Linv[(int64_t)(ib * 16 + g + 4 * r) * ldi + jb2 * 16 + c] = R[r];
-    }
-    __syncthreads();
-  }
+  // write the factor back (LDS variant) with a zeroed strict upper triangle
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx / n, j = idx % n;
-    double v = 0.0;
-    if (j <= i)
-      v = Linv[(int64_t)i * ldi + j];
-    else
-      Linv[(int64_t)i * ldi + j] = 0.0;
-    if (it.LinvT) it.LinvT[(int64_t)j * ldi + i] = v;
+    const double v = (j > i) ? 0.0 : W[(int64_t)i * ld + j];
+    it.W[(int64_t)i * it.ld + j] = v;
+  }
+  if (!Linv) return;
+  // block-column forward substitution, columns paired (w, nb-1-w, w+4, ...) so the four waves carry equal work
+  for (int q = 0; q < (nb + 3) / 4; ++q) {
+    const int jcol = ((q & 1) == 0) ? (q / 2) * 8 + wave : (q / 2) * 8 + 7 - wave;
+    if (jcol >= nb) continue;
+    d4 x[POTRF_MAXNB];
+#pragma unroll
+    for (int rel = 0; rel < POTRF_MAXNB; ++rel) {
+      const int ib = jcol + rel;
+      if (ib < nb) {
+        const double* Xi = Xdall + ib * 16 * 17;
+        if (rel == 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) x[0][t] = Xi[(g + 4 * t) * 17 + c];
+        } else {
+          d4 S0 = (d4){0, 0, 0, 0}, S1 = (d4){0, 0, 0, 0};
+#pragma unroll
+          for (int r2 = 0; r2 < rel; ++r2) {
+            const int kb = jcol + r2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double a = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
+              if (r2 & 1)
+                S1 = mfma_f64(a, x[r2][s], S1);
+              else
+                S0 = mfma_f64(a, x[r2][s], S0);
+            }
+          }
+          S0 += S1;
+          d4 R = (d4){0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) R = mfma_f64(-Xi[c * 17 + 4 * s + g], S0[s], R);
+          x[rel] = R;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          Linv[(int64_t)(ib * 16 + g + 4 * t) * ldi + jcol * 16 + c] = x[rel][t];
+          if (it.LinvT) it.LinvT[(int64_t)(jcol * 16 + c) * ldi + ib * 16 + g + 4 * t] = x[rel][t];
+        }
+      }
+    }
   }
 }
 
 int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max) {
   ProfScope ps(ctx, "potrf");
-  const size_t base = (2 * 16 * 17 + 8) * sizeof(double);
+  const int nb_max = n_max / 16;
+  const size_t base = (16 * 17 + 8 + (size_t)nb_max * 16 * 17) * sizeof(double);
   if (n_max <= 128) {
     const size_t lds = base + (size_t)n_max * (n_max + 4) * sizeof(double);
     if (lds > 64 * 1024)
       DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items);
+    hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items, nb_max);
   } else {
-    hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items);
+    hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items, nb_max);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;

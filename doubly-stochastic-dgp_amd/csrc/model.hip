@@ -3,7 +3,10 @@
 // between kernels except reading the final scalars when the caller asks for them.
 #include "layer.hpp"
 #include "linalg.hpp"
+#include <stdlib.h>
 
+int multiclass_launch(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int64_t R, int K,
+                      int mode, double wgt, double* out, double* dmean, double* dvar, int y_override);
 int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const double* X2, int64_t n2, int D,
                 const double* hyp_dev, double diag_add, int symmetric, double* out, int64_t ld);
 
@@ -32,6 +35,7 @@ struct RedJob {
   double* out;
   int64_t count;
   int32_t nsplit, blk_start;
+  int32_t wide, pad;   // wide: few outputs, many splits -> one workgroup per output element (fixed-order tree)
 };
 
 struct LayerState {
@@ -177,7 +181,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
-    S.hyp_part = b.take<double>((size_t)(S.ld_max / 16) * (d.D_in + 2));
+    S.hyp_part = b.take<double>((size_t)4 * (S.ld_max / 16 + 1) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 3);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -327,6 +331,17 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
   }
 }
 
+// block partial sums of a vector (MultiClass variational expectations), same [blocks][2] layout as k_lik_gauss
+__global__ __launch_bounds__(256) void k_partial_sum(const double* __restrict__ x, int64_t count, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double a = block_sum_256(i < count ? x[i] : 0.0, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
 // ELBO = data_scale/S * sum ve - kl_weight * sum KL   (dgp.py:92-98)
 __global__ __launch_bounds__(256) void k_finalize(const LayerDev* __restrict__ layers, int L, const double* __restrict__ part,
                                                   int nblocks, double w, double kl_weight, const double* __restrict__ lik_const,
@@ -427,10 +442,19 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
   }
 }
 
-__global__ void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs) {
+  __shared__ double sh[4];
   int jb = 0;
   while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_start) ++jb;
   const RedJob J = jobs[jb];
+  if (J.wide) {
+    const int64_t i = blockIdx.x - J.blk_start;     // one workgroup per output element
+    double s = 0.0;
+    for (int sp = threadIdx.x; sp < J.nsplit; sp += 256) s += J.part[(int64_t)sp * J.count + i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) J.out[i] = s;
+    return;
+  }
   const int64_t i = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
   if (i >= J.count) return;
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -859,7 +883,10 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
     a.Asave = save ? St.A : nullptr;
-    DS_TRY(layer_fwd_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
+    if (sm_chain_enabled())
+      DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
+    else
+      DS_TRY(layer_fwd_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
     Xin = a.F;
@@ -903,7 +930,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.out = St.part_big + (int64_t)j * ns * MM;
       J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
       start += ns * ti * ti;
-      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0});
+      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, 0});
     }
     St.tot_big = start;
     int nt = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), nch, 512);
@@ -913,16 +940,16 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, v.DinP16 / 16,
                                  v.DinP16, nt * ti * (v.DP16 / 16)};
     St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
-    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0});
-    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, (int)nch, 0});
+    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0});
+    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld) : (int)nch, 0, 1, 0});
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
   int blocks = 0;
   for (auto& r : red) {
     r.blk_start = blocks;
-    blocks += ceil_div(r.count, 256);
+    blocks += r.wide ? (int)r.count : ceil_div(r.count, 256);
   }
   if ((int)red.size() > m->rjobs_cap) {
     dsdgp_set_error("internal: reduction job list overflow");
@@ -959,7 +986,10 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
     b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
     b.hyp_part = St.hyp_part;
-    DS_TRY(layer_bwd_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
+    if (sm_chain_enabled())
+      DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
+    else
+      DS_TRY(layer_bwd_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     DS_TRY(wgrad_launch(ctx, St.wj, 1 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI));
@@ -990,10 +1020,6 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
                                 double kl_weight, int with_grad, double* out) {
   DS_CHECK_ARG(m && X && Y && out);
   DS_CHECK_ARG(!zs || zstride);
-  if (m->desc.lik_kind != DSDGP_LIK_GAUSSIAN) {
-    dsdgp_set_error("only the Gaussian likelihood is built on the device ELBO path so far");
-    return DSDGP_ERR_UNSUPPORTED;
-  }
   if (with_grad) {
     DS_CHECK_ARG(m->grad != nullptr);
   }
@@ -1004,17 +1030,27 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   LayerState& last = m->L[L - 1];
   const int DY = last.dev.D_out;
   const int64_t total = (int64_t)S * n * DY;
-  const int nblocks = ceil_div(total, 256);
+  int nblocks = ceil_div(total, 256);
   const double w = data_scale / (double)S;
-  hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
-                     w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+  if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN) {
+    hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
+                       w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+  } else {
+    // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
+    DS_CHECK_ARG(DY == m->desc.num_classes);
+    const int64_t R = (int64_t)S * n;
+    DS_TRY(multiclass_launch(ctx, last.mean, last.var, Y, n, R, DY, 0, w, last.F, with_grad ? m->lik_dmean : nullptr,
+                             with_grad ? m->lik_dvar : nullptr, -1));
+    nblocks = ceil_div(R, 256);
+    hipLaunchKernelGGL(k_partial_sum, dim3(nblocks), dim3(256), 0, ctx->stream, last.F, R, m->lik_part);
+  }
   DS_HIP(hipGetLastError());
   if (with_grad) {
     DS_HIP(hipMemsetAsync(m->grad, 0, m->desc.n_theta * sizeof(double), ctx->stream));
     DS_TRY(backward_layers(m, n, S, kl_weight));
   }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, L, m->lik_part, nblocks, w, kl_weight,
-                     m->lik_const, m->grad, m->desc.off_lik_var, with_grad, out);
+                     m->lik_const, m->grad, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, with_grad, out);
   DS_HIP(hipGetLastError());
   m->prepared = true;
   return DSDGP_OK;
@@ -1054,6 +1090,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
+  if (sm_chain_enabled()) return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
   return layer_fwd_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
 }
 

@@ -84,6 +84,9 @@ _PROTOS = {
     "dsdgp_gauss_predict_density": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                               C.c_int32, C.c_double, C.c_void_p]),
     "dsdgp_add_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p]),
+    "dsdgp_multiclass_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_int, C.c_void_p]),
+    "dsdgp_multiclass_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

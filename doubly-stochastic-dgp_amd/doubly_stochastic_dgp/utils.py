@@ -25,47 +25,62 @@ def reparameterize(mean, var, z, full_cov=False):
 
 
 class BroadcastingLikelihood:
-    """Wrapper giving every likelihood method (S,N,D) semantics with Y of shape (N,D) (utils.py:54-121).  The Gaussian
-    case is evaluated by libdsdgp; `.likelihood` is the wrapped object (`model.likelihood.likelihood.variance`)."""
+    """Wrapper giving every likelihood method (S,N,D) semantics with Y of shape (N,D) (utils.py:54-121): the Gaussian
+    broadcasts Y[None]; every other likelihood is evaluated on the flattened (S*N, D) arrays with Y tiled S times
+    (utils.py:76-86).  Evaluated by libdsdgp; `.likelihood` is the wrapped object
+    (`model.likelihood.likelihood.variance`)."""
 
     def __init__(self, likelihood):
         self.likelihood = likelihood
-        from .gpflow_compat import Gaussian
+        from .gpflow_compat import Gaussian, MultiClass
         self.needs_broadcasting = not isinstance(likelihood, Gaussian)
+        if not isinstance(likelihood, (Gaussian, MultiClass)):
+            raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
+                                      "(Gaussian, MultiClass are)")
 
-    def _gauss(self):
-        if self.needs_broadcasting:
-            raise NotImplementedError("only the Gaussian likelihood is built so far (MultiClass is SURVEY §8f rank 2)")
-        return float(self.likelihood.variance.value)
-
-    def _run(self, fn, Fmu, Fvar, Y):
+    def _run(self, mode, Fmu, Fvar, Y):
         from . import _lib
         from .engine import Context, ptr
         ctx = Context.get()
         Fmu = np.asarray(Fmu, dtype=np.float64)
         S, N, D = Fmu.shape
         m, v, y = ctx.to_device(Fmu), ctx.to_device(np.broadcast_to(Fvar, Fmu.shape)), ctx.to_device(Y)
-        out = ctx.empty(N, D)
         ctx.torch.cuda.current_stream().synchronize()
-        _lib.check(getattr(ctx.lib, fn)(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, self._gauss(), ptr(out)))
+        if not self.needs_broadcasting:
+            out = ctx.empty(N, D)
+            fn = ctx.lib.dsdgp_gauss_var_exp if mode == 0 else ctx.lib.dsdgp_gauss_predict_density
+            _lib.check(fn(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, float(self.likelihood.variance.value), ptr(out)))
+        else:
+            out = ctx.empty(N, 1)
+            _lib.check(ctx.lib.dsdgp_multiclass_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, ptr(out)))
         ctx.sync()
         return out.cpu().numpy()
 
     def variational_expectations_mean(self, Fmu, Fvar, Y):
         """reduce_mean over S of variational_expectations (dgp.py:89-90)."""
-        return self._run("dsdgp_gauss_var_exp", Fmu, Fvar, Y)
+        return self._run(0, Fmu, Fvar, Y)
 
     def predict_density_logmeanexp(self, Fmu, Fvar, Y):
         """logsumexp_S(predict_density) - log S (dgp.py:124-126)."""
-        return self._run("dsdgp_gauss_predict_density", Fmu, Fvar, Y)
+        return self._run(1, Fmu, Fvar, Y)
 
     def predict_mean_and_var(self, Fmu, Fvar):
         from . import _lib
         from .engine import Context, ptr
         ctx = Context.get()
-        v = ctx.to_device(np.asarray(Fvar, dtype=np.float64))
-        out = ctx.empty(*v.shape)
+        Fmu = np.asarray(Fmu, dtype=np.float64)
+        v = ctx.to_device(np.broadcast_to(np.asarray(Fvar, dtype=np.float64), Fmu.shape))
         ctx.torch.cuda.current_stream().synchronize()
-        _lib.check(ctx.lib.dsdgp_add_scalar(ctx.handle, ptr(v), self._gauss(), v.numel(), ptr(out)))
+        if not self.needs_broadcasting:
+            out = ctx.empty(*v.shape)
+            _lib.check(ctx.lib.dsdgp_add_scalar(ctx.handle, ptr(v), float(self.likelihood.variance.value), v.numel(),
+                                                ptr(out)))
+            ctx.sync()
+            return Fmu, out.cpu().numpy()
+        S, N, K = Fmu.shape
+        m = ctx.to_device(Fmu)
+        om, ov = ctx.empty(S, N, K), ctx.empty(S, N, K)
+        ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(ctx.lib.dsdgp_multiclass_predict(ctx.handle, ptr(m), ptr(v), S * N, K, ptr(om), ptr(ov)))
         ctx.sync()
-        return np.asarray(Fmu, dtype=np.float64), out.cpu().numpy()
+        return om.cpu().numpy(), ov.cpu().numpy()

@@ -183,6 +183,15 @@ int dsdgp_gauss_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, c
 /* DGP_Base.predict_density, Gaussian (dgp.py:121-126): out[i,d] = logsumexp_s log N(Y | mean, var + lik_var) - log S. */
 int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
                                 int32_t S, int32_t DY, double lik_var, double* out);
+/* [UPSTREAM] MultiClass(K)/RobustMax through BroadcastingLikelihood (utils.py:76-93):
+ * mode 0: out[i] = mean_s variational expectation ; mode 1: out[i] = logsumexp_s log density - log S.
+ * mean/var: (S*n x K); Y: (n x 1) class labels stored as doubles; out: (n x 1). */
+int dsdgp_multiclass_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int32_t S,
+                             int32_t K, int mode, double* out);
+/* MultiClass.predict_mean_and_var: out_mean[r,k] = predictive class probability, out_var = p - p^2; R rows. */
+int dsdgp_multiclass_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t R, int32_t K, double* out_mean,
+                             double* out_var);
+
 /* out = in + value (Gaussian.predict_mean_and_var adds the noise variance, dgp.py:116-119). */
 int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out);
 

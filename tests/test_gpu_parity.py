@@ -393,3 +393,29 @@ def test_natgrad_gamma1_gives_collapsed_bound():
     bound = (-0.5 * Y.T @ np.linalg.solve(Cm, Y)).item() - 0.5 * ld - 0.5 * N * math.log(2 * math.pi) \
         - 0.5 / s2 * (kern.Kdiag(O.NP, X).sum() - np.trace(Qff))
     assert_allclose(elbo, bound, rtol=1e-7)
+
+
+# ---------------------------------------------------------------- MultiClass / RobustMax
+@pytest.mark.parametrize("white", [True, False])
+def test_multiclass_elbo_gradients_and_predictions(white):
+    # shapes of tests/test_dgp.py:56-63 (K = 3 classes, num_outputs = K), two layers
+    rng = np.random.RandomState(21)
+    N, D, M, S, K = 60, 2, 19, 3, 3
+    X = rng.uniform(size=(N, D))
+    Y = rng.choice([0.0, 1.0, 2.0], N).reshape(N, 1)
+    Z = X[:M].copy()
+    specs = [kern_spec("matern52", D, 1.0, 0.5), kern_spec("matern52", D, 1.0, 0.5)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=200, num_classes=K)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, K)]
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=200)
+    om = OM.build(O.NP, spec, state, S, 200)
+    assert_allclose(model.E_log_p_Y(X, Y, zs=zs), om.E_log_p_Y(O.NP, X, Y, zs), rtol=1e-9, atol=1e-11)
+    _, Fm, Fv = om.propagate(O.NP, X, zs, S=S)
+    m, v = model._build_predict(X, S=S, zs=zs)
+    assert_allclose(model.likelihood.predict_density_logmeanexp(m, v, Y), om.predict_density(O.NP, X, Y, zs, S), rtol=1e-9,
+                    atol=1e-11)
+    pm, pv = model.likelihood.predict_mean_and_var(m, v)
+    rm, rv = om.likelihood.predict_mean_and_var(O.NP, Fm[-1], Fv[-1])
+    assert_allclose(pm, rm, rtol=1e-9, atol=1e-12)
+    assert_allclose(pv, rv, rtol=1e-8, atol=1e-12)
+    assert_allclose(pm.sum(-1), 1.0, atol=2e-3)      # RobustMax probabilities ~ sum to one
