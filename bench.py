@@ -182,7 +182,9 @@ def main():
     torch.cuda.synchronize()
     predict_rows_per_s = 20 * 100 * 1000 / (time.perf_counter() - t1)
 
-    # per-kernel HIP-event timing on the ctx stream (separate loop: events perturb the pipeline slightly)
+    # per-kernel HIP-event timing on the launch streams (separate loop: events perturb the pipeline slightly); the
+    # wgrad/backward side-stream overlap is switched off here so that each duration is the kernel's own
+    os.environ["DSDGP_NO_OVERLAP"] = "1"
     ctx.prof_enable(True)
     nprof = 20
     for _ in range(nprof):
@@ -193,14 +195,28 @@ def main():
         ms, cnt = ctx.prof_read(name)
         prof[name] = dict(ms_per_step=ms / nprof, launches_per_step=cnt / nprof)
     ctx.prof_enable(False)
+    os.environ["DSDGP_NO_OVERLAP"] = "0"
     fl = algorithmic_flops(cfg)
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md: 2*FETCH_SIZE + WRITE_SIZE,
+    # same command, gfx950 correction of MI355X_MICROARCH.md); None when the profile is not shipped
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("wgrad", "k_wgrad<4, 4>")):
+            hit = [v for k, v in pmc.items() if k.startswith(key)]
+            if hit:
+                traffic[name] = round(hit[0]["traffic_MB_per_launch"] * 1e6)
+    except Exception:
+        pass
     roof_all = {}
     for name in ("layer_fwd", "layer_bwd", "wgrad"):
         ms = prof[name]["ms_per_step"]
         ach = fl[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof_all[name] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                              frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                              ms_per_step=round(ms, 4), algorithmic_gflop_per_step=round(fl[name] / 1e9, 3))
+                              frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name),
+                              ms_per_step=round(ms, 4), launches_per_step=prof[name]["launches_per_step"],
+                              algorithmic_gflop_per_step=round(fl[name] / 1e9, 3))
     dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])
     roofline = dict(roof_all[dominant], kernel=dominant)
 

@@ -65,16 +65,17 @@ struct ProfScope {
   dsdgp_ctx* ctx;
   const char* name;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(dsdgp_ctx* c, const char* n) : ctx(c), name(n) {
+  hipStream_t st;
+  ProfScope(dsdgp_ctx* c, const char* n, hipStream_t stream = nullptr) : ctx(c), name(n), st(stream ? stream : c->stream) {
     if (ctx->prof_on) {
       hipEventCreate(&a);
       hipEventCreate(&b);
-      hipEventRecord(a, ctx->stream);
+      hipEventRecord(a, st);
     }
   }
   ~ProfScope() {
     if (a) {
-      hipEventRecord(b, ctx->stream);
+      hipEventRecord(b, st);
       ctx->prof[name].pending.push_back({a, b});
     }
   }

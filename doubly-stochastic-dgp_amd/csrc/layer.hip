@@ -540,12 +540,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
 }
 
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                 int NI, int NJ) {
-  ProfScope ps(ctx, "wgrad");
+                 int NI, int NJ, hipStream_t stream) {
+  hipStream_t st = stream ? stream : ctx->stream;
+  ProfScope ps(ctx, "wgrad", st);
   const dim3 grid(ceil_div(total_tasks, 4)), blk(256);
 #define WG_CASE(I, Jn)                                                                                              \
   if (NI == I && NJ == Jn) {                                                                                        \
-    hipLaunchKernelGGL((k_wgrad<I, Jn>), grid, blk, 0, ctx->stream, jobs_dev, njobs, nsplit, ld, Rp, total_tasks); \
+    hipLaunchKernelGGL((k_wgrad<I, Jn>), grid, blk, 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks); \
     DS_HIP(hipGetLastError());                                                                                      \
     return DSDGP_OK;                                                                                                \
   }

@@ -64,7 +64,7 @@ int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kin
 int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
 // jobs_dev: device copy of `njobs` jobs with task_start filled (tasks = nsplit*ti*tj each); NI/NJ in {4,2}/{4,2,1}
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                 int NI, int NJ);
+                 int NI, int NJ, hipStream_t stream = nullptr);
 size_t layer_fwd_lds_bytes(int Mp, int D_in);
 // split-M variants (layer_sm.hip): 4 waves cooperate on one block of 16*CB rows
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);

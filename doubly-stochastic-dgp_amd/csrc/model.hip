@@ -83,6 +83,11 @@ struct dsdgp_model {
   int64_t plan_n;
   int plan_S;
   bool prepared;
+  // side stream: the weight-gradient products of layer l overlap the backward chain of layer l-1 (disjoint buffers)
+  hipStream_t side;
+  hipEvent_t ev_bwd[DSDGP_MAX_LAYERS];
+  hipEvent_t ev_side;
+  bool overlap;
 };
 
 struct Bump {
@@ -783,6 +788,10 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, desc->trainable_lik_var);
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DS_HIP(hipStreamSynchronize(st));
+  m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
+  DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+  for (int l = 0; l < L; ++l) DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
   m->prepared = false;
   m->plan_n = -1;
   m->plan_S = -1;
@@ -793,6 +802,10 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
 extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
   if (m) {
     hipStreamSynchronize(m->ctx->stream);
+    hipStreamSynchronize(m->side);
+    for (int l = 0; l < m->desc.L; ++l) hipEventDestroy(m->ev_bwd[l]);
+    hipEventDestroy(m->ev_side);
+    hipStreamDestroy(m->side);
     delete m;
   }
   return DSDGP_OK;
@@ -968,6 +981,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(ensure_plan(m, n, S));
+  const char* no = getenv("DSDGP_NO_OVERLAP");   // read per call so that a profiler can serialise the kernels
+  const bool overlap = m->overlap && !(no && atoi(no));
   for (int l = L - 1; l >= 0; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -992,8 +1007,18 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_TRY(layer_bwd_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
-    DS_TRY(wgrad_launch(ctx, St.wj, 1 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI));
-    DS_TRY(wgrad_launch(ctx, St.wj + 1 + v.D_out, 2, St.tot_thin, St.ns_thin, ld, ld, NI, 1));
+    hipStream_t ws = ctx->stream;
+    if (overlap) {
+      DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
+      DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
+      ws = m->side;
+    }
+    DS_TRY(wgrad_launch(ctx, St.wj, 1 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
+    DS_TRY(wgrad_launch(ctx, St.wj + 1 + v.D_out, 2, St.tot_thin, St.ns_thin, ld, ld, NI, 1, ws));
+  }
+  if (overlap) {
+    DS_HIP(hipEventRecord(m->ev_side, m->side));
+    DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
   }
   hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red);
   DS_HIP(hipGetLastError());
@@ -1230,4 +1255,148 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
     }
   }
   return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// full_cov=True: SVGP_Layer.conditional_ND(full_cov=True) (layers.py:206-209,216-219) and
+// reparameterize(full_cov=True) (utils.py:43-51).  Plot-sized inputs; composed from the gram / grouped-GEMM / potrf
+// kernels (same algebra as the diagonal path: var_d = Kff - A1^T A1 + (T_d^T A)^T (T_d^T A)).
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_fullcov_combine(const double* __restrict__ Kff, const double* __restrict__ Q, const double* __restrict__ P,
+                                  int64_t n, int D, double* __restrict__ var) {
+  const int64_t tot = n * n * D;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % D);
+    const int64_t ij = idx / D;
+    var[idx] = Kff[ij] - Q[ij] + P[(int64_t)d * n * n + ij];      // (n, n, D) layout, layers.py:216-217
+  }
+}
+__global__ void k_add_mean_fn(double* __restrict__ mean, const double* __restrict__ X, int64_t n, int D_in, int D_out,
+                              int mean_kind, const double* __restrict__ A) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * D_out; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / D_out;
+    const int d = (int)(idx % D_out);
+    double v = mean[idx];
+    if (mean_kind == DSDGP_MEAN_IDENTITY) {
+      v += X[i * D_in + d];
+    } else if (mean_kind == DSDGP_MEAN_LINEAR) {
+      for (int j = 0; j < D_in; ++j) v = fma(X[i * D_in + j], A[j * D_out + d], v);
+    }
+    mean[idx] = v;
+  }
+}
+
+static int run_gemms(dsdgp_ctx* ctx, std::vector<GemmProblem>& probs, GemmProblem* dev) {
+  const int total = gemm_plan(probs.data(), (int)probs.size());
+  DS_HIP(hipMemcpyAsync(dev, probs.data(), probs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, ctx->stream));
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  return gemm_launch(ctx, dev, (int)probs.size(), total);
+}
+
+extern "C" int dsdgp_model_layer_conditional_full(dsdgp_model* m, int32_t l, const double* X, int64_t n, double* mean,
+                                                  double* var) {
+  DS_CHECK_ARG(m && X && mean && var && l >= 0 && l < m->desc.L && n > 0);
+  if (!m->prepared) DS_TRY(prepare_async(m));
+  dsdgp_ctx* ctx = m->ctx;
+  LayerState& St = m->L[l];
+  const LayerDev& v = St.dev;
+  const int Mp = v.Mp, D = v.D_out;
+  const int64_t MN = (int64_t)Mp * n, NN = n * n;
+  // scratch: Kuf, A1, A (Mp x n) | C (D x Mp x n) | Kff, Q (n x n) | P (D x n x n) | gemm problem list
+  const size_t bytes = (size_t)((3 + D) * MN + (2 + D) * NN) * sizeof(double) + 8 * sizeof(GemmProblem) + 256;
+  void* scr;
+  DS_TRY(ctx_scratch(ctx, bytes, &scr));
+  double* Kuf = (double*)scr;
+  double* A1 = Kuf + MN;
+  double* A = A1 + MN;
+  double* Cd = A + MN;
+  double* Kff = Cd + (int64_t)D * MN;
+  double* Q = Kff + NN;
+  double* P = Q + NN;
+  GemmProblem* gp = (GemmProblem*)(((uintptr_t)(P + (int64_t)D * NN) + 255) & ~(uintptr_t)255);
+  DS_HIP(hipMemsetAsync(Kuf, 0, MN * sizeof(double), ctx->stream));
+  DS_TRY(gram_launch(ctx, v.kern_kind, v.Zp, v.M, X, n, v.D_in, v.hyp, 0.0, 0, Kuf, n));                 // layers.py:184
+  // Kff = kern.K(X) (layers.py:209): White contributes on the diagonal, no jitter.  hyp[HYP_WVAR] lives on the device:
+  // build with diag_add = 0 and add the white variance in the combine step through Q (subtract a negative).
+  DS_TRY(gram_launch(ctx, v.kern_kind, X, n, X, n, v.D_in, v.hyp, 0.0, 1, Kff, n));
+  std::vector<GemmProblem> g1(1), g2, g3;
+  fill_gemm(g1[0], v.Linv, Kuf, A1, Mp, (int)n, Mp, Mp, (int)n, (int)n, 0, 0, 1, 0, 0, 0, 0);            // layers.py:186
+  DS_TRY(run_gemms(ctx, g1, gp));
+  const double* Ause = A1;
+  if (!m->desc.white) {
+    std::vector<GemmProblem> ga(1);
+    fill_gemm(ga[0], v.LinvT, A1, A, Mp, (int)n, Mp, Mp, (int)n, (int)n, 0, 0, 1, 0, 0, 0, 0);           // layers.py:188
+    DS_TRY(run_gemms(ctx, ga, gp));
+    Ause = A;
+  }
+  GemmProblem pm, pc, pq;
+  fill_gemm(pm, Ause, v.qmu, mean, (int)n, D, Mp, (int)n, D, D, 1, 0, 1, 0, 0, 0, 0);                    // layers.py:190
+  fill_gemm(pc, v.Tp, Ause, Cd, Mp, (int)n, Mp, Mp, (int)n, (int)n, 1, 0, D, (int64_t)Mp * Mp, 0, MN, 0);  // q_sqrt_d^T A
+  fill_gemm(pq, A1, A1, Q, (int)n, (int)n, Mp, (int)n, (int)n, (int)n, 1, 0, 1, 0, 0, 0, 0);             // A1^T A1
+  g2 = {pm, pc, pq};
+  DS_TRY(run_gemms(ctx, g2, gp));
+  GemmProblem pp;
+  fill_gemm(pp, Cd, Cd, P, (int)n, (int)n, Mp, (int)n, (int)n, (int)n, 1, 0, D, MN, MN, NN, 0);
+  g3 = {pp};
+  DS_TRY(run_gemms(ctx, g3, gp));
+  const int nb = (int)std::min<int64_t>(2048, ceil_div(NN * D, 256));
+  hipLaunchKernelGGL(k_fullcov_combine, dim3(nb), dim3(256), 0, ctx->stream, Kff, Q, P, n, D, var);
+  hipLaunchKernelGGL(k_add_mean_fn, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, mean, X, n, v.D_in, D,
+                     St.d.mean_kind, St.d.mean_A);
+  DS_HIP(hipGetLastError());
+  if (v.has_white) {
+    // add the White variance on the diagonal of every output's covariance (Kff of a Sum kernel)
+    extern __global__ void k_add_diag_dev(double*, int64_t, int, const double*);
+    hipLaunchKernelGGL(k_add_diag_dev, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, var, n, D, v.hyp + HYP_WVAR);
+    DS_HIP(hipGetLastError());
+  }
+  return DSDGP_OK;
+}
+
+__global__ void k_add_diag_dev(double* __restrict__ var, int64_t n, int D, const double* __restrict__ val) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * D) return;
+  const int64_t i = idx / D;
+  const int d = (int)(idx % D);
+  var[(i * n + i) * D + d] += val[0];
+}
+
+// reparameterize(full_cov=True) (utils.py:43-51): f[s,:,d] = mean[s,:,d] + chol(var[s,:,:,d] + jitter I) z[s,:,d]
+__global__ void k_fullcov_gather(const double* __restrict__ var, int64_t n, int D, int S, double jitter, double* __restrict__ out) {
+  const int64_t tot = (int64_t)S * D * n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx % n, i = (idx / n) % n, d = (idx / (n * n)) % D, s = idx / (n * n * D);
+    out[idx] = var[((s * n + i) * n + j) * D + d] + (i == j ? jitter : 0.0);          // SNND -> SDNN (+ jitter I)
+  }
+}
+__global__ void k_fullcov_sample(const double* __restrict__ Lc, const double* __restrict__ mean, const double* __restrict__ z,
+                                 int64_t n, int D, int S, double* __restrict__ out) {
+  const int64_t tot = (int64_t)S * n * D;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t d = idx % D, i = (idx / D) % n, s = idx / (D * n);
+    const double* Lrow = Lc + ((s * D + d) * n + i) * n;
+    double acc = mean[idx];
+    for (int64_t j = 0; j <= i; ++j) acc = fma(Lrow[j], z[(s * n + j) * D + d], acc);
+    out[idx] = acc;
+  }
+}
+
+extern "C" int dsdgp_reparameterize_full(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,
+                                         int64_t n, int32_t D, int32_t S, double* out) {
+  DS_CHECK_ARG(ctx && mean && var && z && out && n > 0 && D > 0 && S > 0);
+  const int64_t nmat = (int64_t)S * D;
+  double* Lc = nullptr;
+  DS_HIP(hipMallocAsync((void**)&Lc, nmat * n * n * sizeof(double), ctx->stream));
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(nmat * n * n, 256));
+  hipLaunchKernelGGL(k_fullcov_gather, dim3(nb), dim3(256), 0, ctx->stream, var, n, D, S, jitter, Lc);
+  DS_HIP(hipGetLastError());
+  int info = 0;
+  int rc = dsdgp_potrf(ctx, (int)nmat, (int)n, Lc, n, n * n, &info);
+  if (rc == DSDGP_OK) {
+    hipLaunchKernelGGL(k_fullcov_sample, dim3(ceil_div((int64_t)S * n * D, 256)), dim3(256), 0, ctx->stream, Lc, mean, z, n, D, S,
+                       out);
+    if (hipGetLastError() != hipSuccess) rc = DSDGP_ERR_HIP;
+  }
+  hipFreeAsync(Lc, ctx->stream);
+  return rc;
 }

@@ -76,6 +76,9 @@ _PROTOS = {
     "dsdgp_model_natgrad_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int)]),
     "dsdgp_model_layer_kl": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dsdgp_model_layer_conditional": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dsdgp_model_layer_conditional_full": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dsdgp_reparameterize_full": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_int32,
+                                            C.c_int32, C.c_void_p]),
     "dsdgp_reparameterize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p]),
     "dsdgp_randn": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "dsdgp_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

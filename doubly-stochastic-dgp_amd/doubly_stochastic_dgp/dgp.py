@@ -100,9 +100,17 @@ class DGP_Base(Parameterized):
 
     # ------------------------------------------------------------------ dgp.py:61-76
     def propagate(self, X, full_cov=False, S=1, zs=None):
-        if full_cov:
-            raise NotImplementedError("full_cov=True propagation is a 'next' row (SURVEY §8f), not built yet")
         eng = self.engine()
+        if full_cov:
+            # plotting path (dgp.py:104-114): the layer loop of dgp.py:69-74 with (S,N,N,D) covariances; every piece of
+            # arithmetic is a libdsdgp call (layers.py / utils.py mirrors), the loop itself stays on the host
+            F = np.tile(np.asarray(X, dtype=np.float64)[None], [int(S), 1, 1])
+            Fs, Fmeans, Fvars = [], [], []
+            zs = zs or [None] * len(self.layers)
+            for layer, z in zip(self.layers, zs):
+                F, Fmean, Fvar = layer.sample_from_conditional(F, z=z, full_cov=True)
+                Fs.append(F); Fmeans.append(Fmean); Fvars.append(Fvar)
+            return Fs, Fmeans, Fvars
         Fs, Fmeans, Fvars = eng.propagate(X, int(S), zs=zs, seed=self._next_seed())
         eng.ctx.sync()
         return self._np(Fs), self._np(Fmeans), self._np(Fvars)
@@ -110,7 +118,8 @@ class DGP_Base(Parameterized):
     # dgp.py:78-81
     def _build_predict(self, X, full_cov=False, S=1, zs=None):
         if full_cov:
-            raise NotImplementedError("full_cov=True is a 'next' row (SURVEY §8f), not built yet")
+            _, Fmeans, Fvars = self.propagate(X, full_cov=True, S=S, zs=zs)
+            return Fmeans[-1], Fvars[-1]
         eng = self.engine()
         _, Fmeans, Fvars = eng.propagate(X, int(S), zs=zs, seed=self._next_seed(), want=("mean", "var"))
         eng.ctx.sync()

@@ -366,6 +366,18 @@ class Engine:
         self.ctx.sync()
         return out.cpu().numpy().reshape(shape)
 
+    def layer_conditional_full(self, l, X):
+        """conditional_ND(X, full_cov=True): mean (n, D), var (n, n, D) (layers.py:206-209)."""
+        Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
+        n = Xd.shape[0]
+        self._ensure(max(n, 1), 1)
+        self._prepare_checked()
+        D = self.layers[l].num_outputs
+        mean, var = self.ctx.empty(n, D), self.ctx.empty(n, n, D)
+        self.ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.dsdgp_model_layer_conditional_full(self.model, l, ptr(Xd), n, ptr(mean), ptr(var)))
+        return mean, var
+
     def gradient_dict(self):
         """d loss / d (unconstrained) parameters of the last elbo(with_grad=True), keyed like oracle/model.py."""
         self.ctx.sync()

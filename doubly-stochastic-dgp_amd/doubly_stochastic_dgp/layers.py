@@ -41,9 +41,10 @@ class Layer(Parameterized):
 
     # layers.py:52-74
     def conditional_SND(self, X, full_cov=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True propagation is a 'next' row (SURVEY §8f), not built yet")
         X = np.asarray(X, dtype=np.float64)
+        if full_cov:                                              # tf.map_fn over S, layers.py:66-69
+            ms, vs = zip(*[self.conditional_ND(X[s], full_cov=True) for s in range(X.shape[0])])
+            return np.stack(ms), np.stack(vs)
         S, N, D = X.shape
         mean, var = self.conditional_ND(X.reshape(S * N, D))
         return mean.reshape(S, N, self.num_outputs), var.reshape(S, N, self.num_outputs)
@@ -92,9 +93,11 @@ class SVGP_Layer(Layer):
 
     # layers.py:178-219
     def conditional_ND(self, X, full_cov=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True is a 'next' row (SURVEY §8f), not built yet")
         eng = self._engine()
+        if full_cov:                                              # layers.py:206-209: var is (N, N, D_out)
+            mean, var = eng.layer_conditional_full(self._index(), np.asarray(X, dtype=np.float64))
+            eng.ctx.sync()
+            return mean.cpu().numpy(), var.cpu().numpy()
         mean, var = eng.layer_conditional(self._index(), np.asarray(X, dtype=np.float64))
         eng.ctx.sync()
         return mean.cpu().numpy(), var.cpu().numpy()

@@ -10,11 +10,20 @@ def reparameterize(mean, var, z, full_cov=False):
     """mean + z * sqrt(var + jitter) for the diagonal case (utils.py:40-41); var=None returns mean (utils.py:37-38)."""
     if var is None:
         return mean
-    if full_cov:
-        raise NotImplementedError("full_cov reparameterisation is a 'next' row (SURVEY §8f)")
     from . import _lib
     from .engine import Context, ptr
     ctx = Context.get()
+    if full_cov:                                                  # utils.py:43-51
+        mean = np.asarray(mean, dtype=np.float64)
+        S, N, D = mean.shape
+        m, v = ctx.to_device(mean), ctx.to_device(var)
+        zz = ctx.to_device(np.broadcast_to(z, mean.shape))
+        out = ctx.empty(S, N, D)
+        ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(ctx.lib.dsdgp_reparameterize_full(ctx.handle, ptr(m), ptr(v), ptr(zz), float(settings.jitter), N, D, S,
+                                                     ptr(out)))
+        ctx.sync()
+        return out.cpu().numpy()
     m, v, zz = (ctx.to_device(np.broadcast_to(a, np.shape(mean))) for a in (mean, var, z))
     out = ctx.empty(*np.shape(mean))
     ctx.torch.cuda.current_stream().synchronize()

@@ -164,6 +164,13 @@ int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out);
  * mean, var: (n x D_out_l). */
 int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const double* X, int64_t n, double* mean, double* var);
 
+/* SVGP_Layer.conditional_ND(X, full_cov=True) (layers.py:206-209,216-219): mean (n x D_out), var (n x n x D_out). */
+int dsdgp_model_layer_conditional_full(dsdgp_model* m, int32_t l, const double* X, int64_t n, double* mean, double* var);
+/* utils.reparameterize, full covariance (utils.py:43-51): mean, z, out (S x n x D); var (S x n x n x D):
+ * out[s,:,d] = mean[s,:,d] + chol(var[s,:,:,d] + jitter I) z[s,:,d]. */
+int dsdgp_reparameterize_full(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,
+                              int64_t n, int32_t D, int32_t S, double* out);
+
 /* utils.reparameterize, diagonal case (utils.py:40-41): out = mean + z * sqrt(var + jitter), count elements. */
 int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,
                          int64_t count, double* out);

@@ -419,3 +419,32 @@ def test_multiclass_elbo_gradients_and_predictions(white):
     assert_allclose(pm, rm, rtol=1e-9, atol=1e-12)
     assert_allclose(pv, rv, rtol=1e-8, atol=1e-12)
     assert_allclose(pm.sum(-1), 1.0, atol=2e-3)      # RobustMax probabilities ~ sum to one
+
+
+# ---------------------------------------------------------------- full_cov=True
+@pytest.mark.parametrize("white", [False, True])
+def test_full_cov_propagation(white):
+    # dgp.py:104-114 / layers.py:206-209 / utils.py:43-51; reference check: tests/test_dgp.py:99,116-117
+    rng = np.random.RandomState(31)
+    N, D, M, S = 33, 2, 19, 2
+    X = rng.uniform(size=(50, D))
+    Y = rng.randn(50, 3)
+    Z = X[:M].copy()
+    specs = [kern_spec("rbf", D, 1.0, 0.6, white_variance=0.01), kern_spec("matern52", D, 1.2, 0.5)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S)
+    Xs = rng.uniform(size=(N, D))
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 3)]
+    Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, Xs, zs, S, full_cov=True)
+    Fs, Fm, Fv = model.propagate(Xs, full_cov=True, S=S, zs=zs)
+    for l in range(2):
+        assert Fv[l].shape == (S, N, N, Fm[l].shape[-1])
+        assert_allclose(Fm[l], Fm_o[l], rtol=1e-8, atol=1e-9)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-8, atol=1e-9)
+        assert_allclose(Fs[l], Fs_o[l], rtol=1e-6, atol=1e-7)       # Cholesky of an N x N covariance with jitter 1e-6
+    m, v = model.predict_f_full_cov(Xs, 1)
+    assert m.shape == (1, N, 3) and v.shape == (1, N, N, 3)
+    # diagonal of the full covariance == the diagonal-path variance
+    md, vd = model.layers[0].conditional_ND(Xs)
+    mf, vf = model.layers[0].conditional_ND(Xs, full_cov=True)
+    assert_allclose(np.einsum("iid->id", vf), vd, rtol=1e-9, atol=1e-11)
+    assert_allclose(mf, md, rtol=1e-10, atol=1e-12)
