@@ -9,6 +9,7 @@ struct LayerFwdArgs {
   int32_t rep;       // S for layer 0 (tf.tile of dgp.py:63 is never materialised), 1 otherwise
   int32_t D_in, D_out, M;
   const double* Zp;     // (Mp x D_in), rows >= M zero
+  const double* Zs;     // (Mp x D_in)  Z / lengthscale (split-M kernels read it through L1/L2 instead of staging it in LDS)
   const double* hyp;    // see common.hpp HYP_*
   const double* LinvT;  // (Mp x Mp)  Lu^{-T}
   const double* Linv;   // (Mp x Mp)  Lu^{-1}
@@ -32,6 +33,7 @@ struct LayerBwdArgs {
   int64_t Rin;
   int32_t D_in, D_out, M, DP4;
   const double* Zp;
+  const double* Zs;     // (Mp x D_in)  Z / lengthscale
   const double* hyp;
   const double* Kinv;   // (Mp x Mp)
   const double* Linv;   // (Mp x Mp)   (white path)

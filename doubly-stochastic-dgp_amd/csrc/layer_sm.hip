@@ -22,18 +22,16 @@ struct Own {
   static __device__ __forceinline__ bool active(int wave) { return MPB >= 4 || wave < MPB; }
 };
 
-// LDS carve (doubles): zs | xs | actA | actB | red
+// LDS carve (doubles): xs | act | red      (Z/l is read through L1/L2; ONE in-place activation buffer)
 struct SmLds {
-  int zs, xs, actA, actB, red, total;
+  int xs, act, red, total;
 };
 static inline SmLds sm_lds(int Mp, int D_in, int D_out, int CB) {
   SmLds L;
   int o = 0;
-  L.zs = o; o += Mp * D_in;
   L.xs = o; o += 16 * CB * (D_in + 1);
   o = (int)round_up(o, 2);
-  L.actA = o; o += CB * Mp * 16;
-  L.actB = o; o += CB * Mp * 16;
+  L.act = o; o += CB * Mp * 16;
   L.red = o;
   const int red_fwd = 4 * CB * 16 * (1 + D_out) + 2 * 4 * CB * 16;      // s1 + mu[D_out] + 2 x s2
   const int red_bwd = 4 * CB * 16 * D_in;                               // dX partials
@@ -49,15 +47,14 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  double* zs = smem + L.zs;
+  const double* __restrict__ zs = a.Zs;
   double* xs = smem + L.xs;
-  double* actA = smem + L.actA;
-  double* actB = smem + L.actB;
+  double* actA = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
+  double* actB = actA;
   double* red_s1 = smem + L.red;                          // [4][CB][16]
   double* red_mu = red_s1 + 4 * CB * 16;                  // [4][CB][Dout][16]
   double* red_s2 = red_mu + 4 * CB * 16 * Dout;           // [2][4][CB][16]
   const double* ils = a.hyp + HYP_ILS;
-  for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
   const int64_t r0 = (int64_t)blockIdx.x * 16 * CB;
   for (int idx = tid; idx < 16 * CB * Din; idx += 256) {
     const int rr = idx / Din, j = idx % Din;
@@ -69,7 +66,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
   const bool act = Own<MPB>::active(wave);
   const double s2 = a.hyp[HYP_VAR];
 
-  // --- Kuf tile (layers.py:184): own row-blocks -> actA
+  // --- Kuf tile (layers.py:184): own row-blocks -> act
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -126,6 +123,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
       if (g == 0) red_s1[(wave * CB + cb) * 16 + c] = act ? p[cb] : 0.0;
     }
   }
+  __syncthreads();   // every wave has finished reading k before a1 overwrites it in place
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -159,6 +157,13 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
               acc[q][cb] = mfma_f64(av, actB[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c], acc[q][cb]);
           }
         }
+      }
+    }
+    __syncthreads();   // a1 fully consumed -> overwrite with a
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB>::ib(wave, q);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -285,13 +290,12 @@ __global__ __launch_bounds__(256) void k_layer_bwd_sm(const LayerBwdArgs a, cons
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  double* zs = smem + L.zs;
+  const double* __restrict__ zs = a.Zs;
   double* xs = smem + L.xs;
-  double* actA = smem + L.actA;
-  double* actB = smem + L.actB;
+  double* actA = smem + L.act;
+  double* actB = actA;
   double* redx = smem + L.red;                            // [4][CB][Din][16]
   const double* ils = a.hyp + HYP_ILS;
-  for (int idx = tid; idx < Mp * Din; idx += 256) zs[idx] = a.Zp[idx] * ils[idx % Din];
   const int64_t r0 = (int64_t)blockIdx.x * 16 * CB;
   for (int idx = tid; idx < 16 * CB * Din; idx += 256) {
     const int rr = idx / Din, j = idx % Din;
@@ -367,6 +371,9 @@ __global__ __launch_bounds__(256) void k_layer_bwd_sm(const LayerBwdArgs a, cons
         }
       }
     }
+  }
+  __syncthreads();   // "a" fully consumed from LDS -> overwrite with abar in place
+  if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB>::ib(wave, q);

@@ -18,7 +18,7 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
 struct LayerDev {
   int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, pad0;
   int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
-  double *Zp, *hyp, *Tp, *qmu, *qmu4;
+  double *Zp, *Zs, *hyp, *Tp, *qmu, *qmu4;
   double *Kp, *Linv, *LinvT, *Kinv, *scal;
   double *V, *nL, *Sd, *klv;
   double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
@@ -148,6 +148,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.off_kvar = d.off_kvar; v.off_kls = d.off_kls; v.off_wvar = d.off_wvar;
     const size_t Mp = v.Mp, MM = Mp * Mp;
     v.Zp = b.take<double>(Mp * d.D_in);
+    v.Zs = b.take<double>(Mp * d.D_in);
     v.hyp = b.take<double>(HYP_ILS + 2 * d.D_in + 8);
     v.Tp = b.take<double>(d.D_out * MM);
     v.qmu = b.take<double>(Mp * d.D_out);
@@ -228,7 +229,12 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
     }
   }
   const int Mp = v.Mp, M = v.M;
-  for (int idx = tid0; idx < Mp * v.D_in; idx += nth) v.Zp[idx] = (idx / v.D_in < M) ? theta[v.off_Z + idx] : 0.0;
+  for (int idx = tid0; idx < Mp * v.D_in; idx += nth) {
+    const double z = (idx / v.D_in < M) ? theta[v.off_Z + idx] : 0.0;
+    const double rl = theta[v.off_kls + (v.ard ? idx % v.D_in : 0)];
+    v.Zp[idx] = z;
+    v.Zs[idx] = z / (softplus_d(rl) + SOFTPLUS_LOWER);
+  }
   for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
     const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
     v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
@@ -876,7 +882,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     LayerFwdArgs a{};
     a.X = Xin; a.Rin = Rin; a.rep = rep;
     a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
-    a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+    a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
     a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
     a.jitter = m->desc.jitter;
     a.n_inner = n;
@@ -996,7 +1002,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipGetLastError());
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
-    b.Zp = v.Zp; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.Sd = v.Sd; b.qmu4 = v.qmu4;
+    b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.Sd = v.Sd; b.qmu4 = v.qmu4;
     b.Asave = St.A; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = St.E; b.GW = St.GW;
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
     b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
@@ -1109,7 +1115,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   LayerFwdArgs a{};
   a.X = X; a.Rin = n; a.rep = 1;
   a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
-  a.Zp = v.Zp; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+  a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
   a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
   a.jitter = m->desc.jitter;
   a.n_inner = n;
