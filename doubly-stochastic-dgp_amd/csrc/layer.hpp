@@ -26,6 +26,7 @@ struct LayerFwdArgs {
   double* var;          // (rep*Rin x D_out) or NULL
   double* Asave;        // (Mp x ldA): A = Ku^{-1} Kuf (white: Lu^{-1} Kuf), kept for the backward pass, or NULL
   int64_t ldA;
+  int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
 };
 
 struct LayerBwdArgs {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
     actIn = actA;
   }
   // acc now holds this wave's rows of "a": save for the backward pass, and the partial mean a . q_mu (layers.py:190)
-  if (act && a.Asave) {
+  if (act && a.Asave && blockIdx.y == 0) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB>::ib(wave, q);
@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
   __syncthreads();
 
   const double kdiag = a.hyp[HYP_KDIAG];
-  for (int d = 0; d < Dout; ++d) {
+  // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
+  const int dchunk = (Dout + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
+  for (int d = d_lo; d < d_hi; ++d) {
     // --- c_d = q_sqrt_d^T a ; |c_d|^2 (replaces SK/B of layers.py:195-212): out block ib sums kb >= ib
     d4 cacc[NQ][CB];
 #pragma unroll
@@ -520,7 +523,10 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   if (lds > 64 * 1024)
     DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, KIND, WHITE, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(ctx, "layer_fwd");
-  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, KIND, WHITE, CB>), dim3(ceil_div(a.Rin, 16 * CB)), dim3(256), lds, ctx->stream, a, L);
+  const int nrow = ceil_div(a.Rin, 16 * CB);
+  int ds = a.d_split > 0 ? a.d_split : 1;
+  if (ds > a.D_out) ds = a.D_out;
+  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, KIND, WHITE, CB>), dim3(nrow, ds), dim3(256), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

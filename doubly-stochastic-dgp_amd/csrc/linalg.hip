@@ -149,7 +149,11 @@ struct Chol16 {
   static __device__ __forceinline__ void run(double (&a)[16], int i, double& myinv, int& bad) {
     const double ajj = bcast_lane<J>(a[J]);
     if (!(ajj > 0.0) && bad == 0) bad = J + 1;
-    const double inv = rsqrt(ajj);
+    // hardware v_rsq_f64 seed + two Newton steps (the library rsqrt() expands to a ~800-cycle sqrt + divide chain,
+    // 16 of them in sequence per diagonal block dominated the whole factorisation)
+    double inv = __builtin_amdgcn_rsq(ajj);
+    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
     if (i == J) myinv = inv;
     const double lij = (i >= J) ? a[J] * inv : 0.0;
     a[J] = lij;
@@ -183,6 +187,9 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
   const int ldi = it.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
+  long long tph[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#define PH(i) do { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; } while (0)
   if (tid == 0) s_info = 0;
   if (INLDS) {
     for (int idx = tid; idx < n * n; idx += 256) {
@@ -216,20 +223,24 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       }
     }
     __syncthreads();
+    PH(0);
     if (wave == 0 && lane < 16) {
-      // column `lane` of X = L_jj^{-1} by forward substitution (LDS reads are broadcasts; no divisions)
-      double x[16];
+      // column `lane` of X = L_jj^{-1} by forward substitution, column-oriented so that the 15 updates after each
+      // solved entry are independent (critical path 16 steps instead of 136 chained FMAs); LDS reads are broadcasts
+      double x[16], sacc[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double s = (i == lane) ? 1.0 : 0.0;
+      for (int i = 0; i < 16; ++i) sacc[i] = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= Ld[i * 17 + k] * x[k];
-        x[i] = s * Ld[i * 17 + 16];
+      for (int k = 0; k < 16; ++k) {
+        x[k] = sacc[k] * Ld[k * 17 + 16];
+#pragma unroll
+        for (int i = k + 1; i < 16; ++i) sacc[i] = fma(-Ld[i * 17 + k], x[k], sacc[i]);
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) Xd[i * 17 + lane] = x[i];
     }
     __syncthreads();
+    PH(1);
     // (b) panel: L_ij = A_ij * L_jj^{-T}   (16x16 MFMA products)
     for (int ib = jb + 1 + wave; ib < nb; ib += 4) {
       d4 acc = (d4){0, 0, 0, 0};
@@ -242,27 +253,49 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       for (int r = 0; r < 4; ++r) W[(int64_t)(ib * 16 + g + 4 * r) * ld + j0 + c] = acc[r];
     }
     __syncthreads();
+    PH(2);
     // (c) trailing update (syrk): A_ik -= L_ij L_kj^T for jb < kb <= ib
     const int nt = nb - jb - 1;
     const int cnt = nt * (nt + 1) / 2;
-    for (int idx = wave; idx < cnt; idx += 4) {
-      int ib2 = 0;
-      while ((ib2 + 1) * (ib2 + 2) / 2 <= idx) ++ib2;
-      const int kb2 = idx - ib2 * (ib2 + 1) / 2;
-      const int ib = jb + 1 + ib2, kb = jb + 1 + kb2;
-      d4 acc;
+    for (int idx = wave; idx < cnt; idx += 8) {
+      // two independent (ib, kb) blocks per iteration: their 4-MFMA dependency chains interleave
+      int ibv[2], kbv[2];
+      bool okv[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c];
+      for (int u = 0; u < 2; ++u) {
+        const int id = idx + 4 * u;
+        okv[u] = id < cnt;
+        int ib2 = 0;
+        while ((ib2 + 1) * (ib2 + 2) / 2 <= id) ++ib2;
+        const int kb2 = id - ib2 * (ib2 + 1) / 2;
+        ibv[u] = okv[u] ? jb + 1 + ib2 : jb + 1;
+        kbv[u] = okv[u] ? jb + 1 + kb2 : jb + 1;
+      }
+      d4 acc[2];
+      double av[2][4], bv[2][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double a = W[(int64_t)(ib * 16 + c) * ld + j0 + 4 * s + g];
-        const double b = W[(int64_t)(kb * 16 + c) * ld + j0 + 4 * s + g];
-        acc = mfma_f64(-a, b, acc);
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = W[(int64_t)(ibv[u] * 16 + g + 4 * r) * ld + kbv[u] * 16 + c];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          av[u][s] = W[(int64_t)(ibv[u] * 16 + c) * ld + j0 + 4 * s + g];
+          bv[u][s] = W[(int64_t)(kbv[u] * 16 + c) * ld + j0 + 4 * s + g];
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c] = acc[r];
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = mfma_f64(-av[u][s], bv[u][s], acc[u]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (okv[u]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) W[(int64_t)(ibv[u] * 16 + g + 4 * r) * ld + kbv[u] * 16 + c] = acc[u][r];
+        }
     }
     __syncthreads();
+    PH(3);
   }
   // logdet over the real (unpadded) part
   {
@@ -276,13 +309,15 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       it.scal[1] = (double)s_info;
     }
   }
-  // write the factor back (LDS variant) with a zeroed strict upper triangle
+  // write the factor back (LDS variant) with a zeroed strict upper triangle — unless the caller never reads it
+  if (!(INLDS && (it.pad & 8)))
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx / n, j = idx % n;
     const double v = (j > i) ? 0.0 : W[(int64_t)i * ld + j];
     it.W[(int64_t)i * it.ld + j] = v;
   }
   if (!Linv) return;
+  PH(4);
   // block-column forward substitution, columns paired (w, nb-1-w, w+4, ...) so the four waves carry equal work
   for (int q = 0; q < (nb + 3) / 4; ++q) {
     const int jcol = ((q & 1) == 0) ? (q / 2) * 8 + wave : (q / 2) * 8 + 7 - wave;
@@ -324,6 +359,10 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       }
     }
   }
+  PH(5);
+  if (tid == 0 && it.pad == 7)
+    for (int q = 0; q < 6; ++q) it.scal[2 + q] = (double)tph[q];
+#undef PH
 }
 
 int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max) {

@@ -429,15 +429,32 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
   if (d < DP16) {
     double mb = 0.0, vb = 0.0;
     if (ok && d < D_out) {
-      for (int s = 0; s < rep; ++s) {
-        const int64_t orow = (int64_t)s * Rin + r;
-        const int64_t o = orow * D_out + d;
-        if (dF) {
-          const double f = dF[o];
-          mb += f;
-          vb += f * z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d] / (2.0 * sqrt(var[o] + jitter));
+      if (dF) {
+        // all `rep` samples of layer 0 share var (the S input copies are identical): hoist the rsqrt, keep 4 loads in flight
+        const double hv = 0.5 * rsqrt(var[r * D_out + d] + jitter);
+        double m4[4] = {0, 0, 0, 0}, v4[4] = {0, 0, 0, 0};
+        int s = 0;
+        for (; s + 4 <= rep; s += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t orow = (int64_t)(s + u) * Rin + r;
+            const double f = dF[orow * D_out + d];
+            m4[u] += f;
+            v4[u] = fma(f, z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d], v4[u]);
+          }
         }
-        if (dmean) {
+        for (; s < rep; ++s) {
+          const int64_t orow = (int64_t)s * Rin + r;
+          const double f = dF[orow * D_out + d];
+          m4[0] += f;
+          v4[0] = fma(f, z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d], v4[0]);
+        }
+        mb = (m4[0] + m4[1]) + (m4[2] + m4[3]);
+        vb = ((v4[0] + v4[1]) + (v4[2] + v4[3])) * hv;
+      }
+      if (dmean) {
+        for (int s = 0; s < rep; ++s) {
+          const int64_t o = ((int64_t)s * Rin + r) * D_out + d;
           mb += dmean[o];
           vb += dvar[o];
         }
@@ -560,14 +577,21 @@ __global__ void k_asm_params(const LayerDev* __restrict__ layers, double* __rest
     const int i = (int)(idx / Dout), d = (int)(idx % Dout);
     grad[v.off_q_mu + idx] = v.thinq[i * v.DP16 + d] + kl_w * (v.white ? v.qmu4[i * v.DP4 + d] : v.n4[i * v.DP4 + d]);
   }
-  // Z: through Kuf (GW [X|1]) and through Ku (wm)
-  for (int64_t idx = t0; idx < (int64_t)M * Din; idx += nth) {
-    const int i = (int)(idx / Din), q = (int)(idx % Din);
-    const double zi = v.Zp[i * Din + q];
-    double s = 0.0;
-    for (int j = 0; j < M; ++j) s = fma(v.wm[i * Mp + j], zi - v.Zp[j * Din + q], s);
-    const double il2 = ils[q] * ils[q];
-    grad[v.off_Z + idx] = 4.0 * il2 * s - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
+  // Z: through Kuf (GW [X|1]) and through Ku (wm): one wavefront per (i, q), lanes stride over j
+  {
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = t0 >> 6, nw = nth >> 6;
+    for (int64_t idx = w0; idx < (int64_t)M * Din; idx += nw) {
+      const int i = (int)(idx / Din), q = (int)(idx % Din);
+      const double zi = v.Zp[i * Din + q];
+      double s = 0.0;
+      for (int j = lane; j < M; j += 64) s = fma(v.wm[i * Mp + j], zi - v.Zp[j * Din + q], s);
+      s = sum_wave(s);
+      if (lane == 0) {
+        const double il2 = ils[q] * ils[q];
+        grad[v.off_Z + idx] = 4.0 * il2 * s - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
+      }
+    }
   }
 }
 
@@ -713,7 +737,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   for (int l = 0; l < L; ++l) {
     const LayerDev& v = m->L[l].dev;
     ld[l] = v;
-    items[l] = PotrfItem{v.Kp, v.Linv, v.LinvT, v.scal, v.Mp, v.Mp, v.M, 0};
+    items[l] = PotrfItem{v.Kp, v.Linv, v.LinvT, v.scal, v.Mp, v.Mp, v.M,
+                         getenv("DSDGP_POTRF_TIMING") ? 7 : (desc->white ? 0 : 8) /* Lu itself is only read by the white adjoint */};
     const int Mp = v.Mp;
     const int64_t MM = (int64_t)Mp * Mp;
     GemmProblem P;
@@ -838,6 +863,13 @@ static int prepare_async(dsdgp_model* m) {
 static int read_info(dsdgp_model* m, int* info) {
   if (!info) return DSDGP_OK;
   *info = 0;
+  if (getenv("DSDGP_POTRF_TIMING")) {   // debug aid: per-phase shader cycles of layer 0's factorisation
+    double sc[8];
+    hipMemcpyAsync(sc, m->L[0].dev.scal, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream);
+    hipStreamSynchronize(m->ctx->stream);
+    fprintf(stderr, "[potrf cycles] factor %.0f inverse %.0f panel %.0f trailing %.0f logdet+writeback %.0f trtri %.0f\n", sc[2],
+            sc[3], sc[4], sc[5], sc[6], sc[7]);
+  }
   for (int l = 0; l < m->desc.L; ++l) {
     double sc[2];
     DS_HIP(hipMemcpyAsync(sc, m->L[l].dev.scal, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream));
@@ -902,6 +934,10 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
     a.Asave = save ? St.A : nullptr;
+    {
+      const int64_t nblk = (Rin + 15) / 16;
+      a.d_split = (nblk < 256) ? (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk)) : 1;
+    }
     if (sm_chain_enabled())
       DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
     else
