@@ -154,8 +154,10 @@ struct Chol16 {
     double inv = __builtin_amdgcn_rsq(ajj);
     inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
     inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
-    if (i == J) myinv = inv;
-    const double lij = (i >= J) ? a[J] * inv : 0.0;
+    myinv = (i == J) ? inv : myinv;
+    // no (i >= J) masking here: lanes above the diagonal carry garbage that never reaches a lower lane and is
+    // zeroed when the block is stored — keeps the 16-pivot chain free of exec-mask branches
+    const double lij = a[J] * inv;
     a[J] = lij;
     Chol16Upd<J, J + 1>::run(a, lij);
     Chol16<J + 1>::run(a, i, myinv, bad);
@@ -192,12 +194,28 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 #define PH(i) do { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; } while (0)
   if (tid == 0) s_info = 0;
   if (INLDS) {
-    for (int idx = tid; idx < n * n; idx += 256) {
-      const int i = idx / n, j = idx % n;
-      W[i * ld + j] = it.W[(int64_t)i * it.ld + j];
+    // stage the lower triangle (the factorisation never reads above the diagonal blocks): 16-byte loads, 8 in flight
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const int halfn = n / 2, tot = n * halfn;
+    for (int base = 0; base < tot; base += 256 * 8) {
+      d2v v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int i = idx / halfn, j2 = idx % halfn;
+        v[u] = (d2v){0.0, 0.0};
+        if (idx < tot && 2 * j2 <= (i | 15)) v[u] = *reinterpret_cast<const d2v*>(it.W + (int64_t)i * it.ld + 2 * j2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int i = idx / halfn, j2 = idx % halfn;
+        if (idx < tot && 2 * j2 <= (i | 15)) *reinterpret_cast<d2v*>(W + i * ld + 2 * j2) = v[u];
+      }
     }
   }
   __syncthreads();
+  PH(5);
 
   for (int jb = 0; jb < nb; ++jb) {
     const int j0 = jb * 16;

@@ -867,7 +867,7 @@ static int read_info(dsdgp_model* m, int* info) {
     double sc[8];
     hipMemcpyAsync(sc, m->L[0].dev.scal, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream);
     hipStreamSynchronize(m->ctx->stream);
-    fprintf(stderr, "[potrf cycles] factor %.0f inverse %.0f panel %.0f trailing %.0f logdet+writeback %.0f trtri %.0f\n", sc[2],
+    fprintf(stderr, "[potrf cycles] factor %.0f inverse %.0f panel %.0f trailing %.0f logdet+writeback %.0f copyin+trtri %.0f\n", sc[2],
             sc[3], sc[4], sc[5], sc[6], sc[7]);
   }
   for (int l = 0; l < m->desc.L; ++l) {

@@ -23,6 +23,19 @@ class Minibatch:
         self._perm = None
         self._pos = 0
 
+    def next_span(self):
+        """(epoch permutation, start) of the next minibatch when it lies inside one epoch, else None (caller falls back to
+        next_indices).  Lets the device keep one uploaded permutation per epoch instead of one index upload per step."""
+        if self._perm is None or self._pos >= self.n_rows:
+            self._perm = self.rng.permutation(self.n_rows)
+            self._pos = 0
+            self._epoch = getattr(self, "_epoch", 0) + 1
+        if self._pos + self.batch_size > self.n_rows:
+            return None
+        start = self._pos
+        self._pos += self.batch_size
+        return self._perm, start, self._epoch
+
     def next_indices(self):
         out = []
         need = self.batch_size
@@ -84,13 +97,20 @@ class DGP_Base(Parameterized):
             return Xd, Yd
         eng = self.engine()
         ctx = eng.ctx
-        idx = ctx.torch.as_tensor(self._minibatch.next_indices()).to(Xd.device)
-        n = idx.shape[0]
+        span = self._minibatch.next_span()
+        if span is not None:
+            perm, start, epoch = span
+            if getattr(self, "_perm_epoch", None) != epoch:          # one index upload per epoch
+                self._perm_dev = ctx.torch.as_tensor(perm.astype(np.int64)).to(Xd.device)
+                self._perm_epoch = epoch
+            idx, off, n = self._perm_dev, start, self.minibatch_size
+        else:                                                      # minibatch straddles an epoch boundary
+            idx = ctx.torch.as_tensor(self._minibatch.next_indices()).to(Xd.device)
+            off, n = 0, idx.shape[0]
         Xb, Yb = ctx.empty(n, Xd.shape[1]), ctx.empty(n, Yd.shape[1])
-        ctx.torch.cuda.current_stream().synchronize()
         for src, dst in ((Xd, Xb), (Yd, Yb)):
             _lib.check(ctx.lib.dsdgp_gather_rows(ctx.handle, C.c_void_p(src.data_ptr()), src.shape[1],
-                                                 C.c_void_p(idx.data_ptr()), n, 0, C.c_void_p(dst.data_ptr())))
+                                                 C.c_void_p(idx.data_ptr()), n, off, C.c_void_p(dst.data_ptr())))
         self._keep_idx = idx
         return Xb, Yb
 

@@ -32,9 +32,14 @@ class Context:
         self.lib = _lib.load()
         self.device = torch.cuda.current_device() if device is None else device
         self.torch = torch
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # ONE stream for everything: torch's default stream has handle 0, which the C-ABI reads as "create a private
+        # stream", and a private stream is not ordered with torch's copies nor with the RCCL all-reduce.  So create a
+        # dedicated stream, make it torch's current stream for this process, and give its handle to libdsdgp: kernels,
+        # H2D/D2H copies and collectives are then ordered by the stream itself.
+        self.tstream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.tstream)
         h = C.c_void_p()
-        _lib.check(self.lib.dsdgp_ctx_create(C.byref(h), self.device, C.c_void_p(stream)))
+        _lib.check(self.lib.dsdgp_ctx_create(C.byref(h), self.device, C.c_void_p(self.tstream.cuda_stream)))
         self.handle = h
 
     @classmethod
@@ -237,7 +242,6 @@ class Engine:
         self.adam_v = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
         self.out4 = self.gradbuf[self.n_theta:]
         h = C.c_void_p()
-        torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_create(self.ctx.handle, C.byref(self.desc), n_max, s_max, ptr(self.theta),
                                                ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
                                                C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
@@ -300,7 +304,6 @@ class Engine:
                 ts, a = None, None
             outs[key], arrs[key] = ts, a
         zp, zst, keep = self._zs_args(zs, S, n)
-        self.ctx.torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_propagate(self.model, ptr(Xd), n, S, zp, zst, C.c_uint64(seed), arrs["F"],
                                                   arrs["mean"], arrs["var"]))
         return outs["F"], outs["mean"], outs["var"]
@@ -312,8 +315,6 @@ class Engine:
         self._ensure(n, S)
         self._upload_if_needed()
         zp, zst, keep = self._zs_args(zs, S, n)
-        if keep or not hasattr(X, "data_ptr"):
-            self.ctx.torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_elbo(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed),
                                              float(data_scale), float(kl_weight), int(with_grad), ptr(self.out4)))
         if not sync:
@@ -352,7 +353,6 @@ class Engine:
         self._prepare_checked()
         D = self.layers[l].num_outputs
         mean, var = self.ctx.empty(n, D), self.ctx.empty(n, D)
-        self.ctx.torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_layer_conditional(self.model, l, ptr(Xd), n, ptr(mean), ptr(var)))
         return mean, var
 
@@ -374,7 +374,6 @@ class Engine:
         self._prepare_checked()
         D = self.layers[l].num_outputs
         mean, var = self.ctx.empty(n, D), self.ctx.empty(n, n, D)
-        self.ctx.torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.dsdgp_model_layer_conditional_full(self.model, l, ptr(Xd), n, ptr(mean), ptr(var)))
         return mean, var
 

@@ -19,14 +19,12 @@ def reparameterize(mean, var, z, full_cov=False):
         m, v = ctx.to_device(mean), ctx.to_device(var)
         zz = ctx.to_device(np.broadcast_to(z, mean.shape))
         out = ctx.empty(S, N, D)
-        ctx.torch.cuda.current_stream().synchronize()
         _lib.check(ctx.lib.dsdgp_reparameterize_full(ctx.handle, ptr(m), ptr(v), ptr(zz), float(settings.jitter), N, D, S,
                                                      ptr(out)))
         ctx.sync()
         return out.cpu().numpy()
     m, v, zz = (ctx.to_device(np.broadcast_to(a, np.shape(mean))) for a in (mean, var, z))
     out = ctx.empty(*np.shape(mean))
-    ctx.torch.cuda.current_stream().synchronize()
     _lib.check(ctx.lib.dsdgp_reparameterize(ctx.handle, ptr(m), ptr(v), ptr(zz), float(settings.jitter), m.numel(),
                                             ptr(out)))
     ctx.sync()
@@ -54,7 +52,6 @@ class BroadcastingLikelihood:
         Fmu = np.asarray(Fmu, dtype=np.float64)
         S, N, D = Fmu.shape
         m, v, y = ctx.to_device(Fmu), ctx.to_device(np.broadcast_to(Fvar, Fmu.shape)), ctx.to_device(Y)
-        ctx.torch.cuda.current_stream().synchronize()
         if not self.needs_broadcasting:
             out = ctx.empty(N, D)
             fn = ctx.lib.dsdgp_gauss_var_exp if mode == 0 else ctx.lib.dsdgp_gauss_predict_density
@@ -79,7 +76,6 @@ class BroadcastingLikelihood:
         ctx = Context.get()
         Fmu = np.asarray(Fmu, dtype=np.float64)
         v = ctx.to_device(np.broadcast_to(np.asarray(Fvar, dtype=np.float64), Fmu.shape))
-        ctx.torch.cuda.current_stream().synchronize()
         if not self.needs_broadcasting:
             out = ctx.empty(*v.shape)
             _lib.check(ctx.lib.dsdgp_add_scalar(ctx.handle, ptr(v), float(self.likelihood.variance.value), v.numel(),
@@ -89,7 +85,6 @@ class BroadcastingLikelihood:
         S, N, K = Fmu.shape
         m = ctx.to_device(Fmu)
         om, ov = ctx.empty(S, N, K), ctx.empty(S, N, K)
-        ctx.torch.cuda.current_stream().synchronize()
         _lib.check(ctx.lib.dsdgp_multiclass_predict(ctx.handle, ptr(m), ptr(v), S * N, K, ptr(om), ptr(ov)))
         ctx.sync()
         return om.cpu().numpy(), ov.cpu().numpy()
