@@ -1,161 +1,199 @@
-// "Split-M" variant of the SVGP_Layer chain (same math as layer.hip; layers.py:178-219 + utils.py:40-41).
+// "Split-M" SVGP_Layer chain (layers.py:178-219 + utils.py:40-41; math identical to layer.hip).
 //
 // Why: v_mfma_f64_16x16x4_f64 needs >= 2 wavefronts per SIMD to run at its pipe rate (a lone wave issues one MFMA per
 // ~59 ns, two waves one per ~45 ns per SIMD — profiles/r01_mfma_f64_microbench.txt), but a 20 000-row layer only has 1250
-// sixteen-row blocks for 1024 SIMDs.  Here the 4 waves of a workgroup cooperate on ONE block of 16*CB data rows: wave w
-// owns the output row-blocks {w, 7-w, 8+w, 15-w, ...} of every product (paired so that triangular products carry equal
-// work), the activations live in a ping-pong LDS buffer in MFMA B-operand order ([k][16 rows], bank-conflict free), and
-// each wave streams only ITS weight columns from L2 — no weight element is fetched twice inside a workgroup.  That gives
-// 4x more, 4x shorter wave-tasks (5000 for cfg 2): full MFMA-pipe occupancy, ~98 % balance, and a 4x shorter critical path
-// for the small first layer.
+// sixteen-row blocks for 1024 SIMDs.  Here the NW waves of a workgroup cooperate on ONE block of 16 data rows: wave w owns
+// the output row-blocks {w, P-1-w, P+w, 2P-1-w, ...} (P = 2 NW; paired so that triangular products carry equal work), the
+// activations live in ONE in-place LDS buffer in MFMA B-operand order ([k][16 rows]: 128-B rows, bank-conflict free), each
+// wave streams only ITS weight columns from L2 (no weight element is fetched twice inside a workgroup), and Z/l is read
+// through L1.  ~23 KB of LDS and < 100 VGPRs at M = 128 => 4-5 workgroups per CU: latency is hidden by thread-level
+// parallelism (explicit prefetching was measured slower because it costs occupancy).
+//   NW = 4  : Mp <= 256          NW = 8 : Mp = 512 (64 KB activation buffer)       NW = 16 : Mp = 1024 (128 KB)
+// Wide inputs (D_in > 64, e.g. the 784-pixel first MNIST layer) stage x/l through LDS in 64-column chunks.
 #include <stdlib.h>
 
 #include "layer.hpp"
 
-template <int MPB>
+#define XCH 64   // columns of x/l staged per chunk
+
+template <int MPB, int NW>
 struct Own {
-  static constexpr int NQ = (MPB >= 4) ? MPB / 4 : 1;
+  static constexpr int NQ = (MPB >= NW) ? MPB / NW : 1;
   static __device__ __forceinline__ int ib(int wave, int q) {
-    if (MPB >= 8) return (q & 1) ? (q >> 1) * 8 + 7 - wave : (q >> 1) * 8 + wave;
+    if (NQ >= 2) return (q & 1) ? (q >> 1) * (2 * NW) + (2 * NW - 1) - wave : (q >> 1) * (2 * NW) + wave;
     return wave;
   }
-  static __device__ __forceinline__ bool active(int wave) { return MPB >= 4 || wave < MPB; }
+  static __device__ __forceinline__ bool active(int wave) { return MPB >= NW || wave < MPB; }
 };
 
-// LDS carve (doubles): xs | act | red      (Z/l is read through L1/L2; ONE in-place activation buffer)
+// LDS carve (doubles): xs | act | red
 struct SmLds {
   int xs, act, red, total;
 };
-static inline SmLds sm_lds(int Mp, int D_in, int D_out, int CB) {
+static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide) {
   SmLds L;
   int o = 0;
-  L.xs = o; o += 16 * CB * (D_in + 1);
+  const int xch = D_in < XCH ? D_in : XCH;
+  L.xs = o; o += 16 * (xch + 1);
   o = (int)round_up(o, 2);
-  L.act = o; o += CB * Mp * 16;
+  L.act = o; o += Mp * 16;
   L.red = o;
-  const int red_fwd = 4 * CB * 16 * (1 + D_out) + 2 * 4 * CB * 16;      // s1 + mu[D_out] + 2 x s2
-  const int red_bwd = 4 * CB * 16 * D_in;                               // dX partials
+  const bool mu_early = (NW == 4) && !wide;
+  const int red_fwd = NW * 16 + 2 * NW * 16 + (mu_early ? NW * 16 * D_out : 2 * NW * 16);   // s1 | 2 x s2 | mean partials
+  const int red_bwd = NW * 16 * xch;                            // dX partials of one chunk
   o += red_fwd > red_bwd ? red_fwd : red_bwd;
   L.total = o;
   return L;
 }
 
-template <int MPB, int KIND, bool WHITE, int CB>
-__global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int Mp = MPB * 16, NQ = Own<MPB>::NQ;
-  const int Din = a.D_in, Dout = a.D_out;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const double* __restrict__ zs = a.Zs;
-  double* xs = smem + L.xs;
-  double* actA = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
-  double* actB = actA;
-  double* red_s1 = smem + L.red;                          // [4][CB][16]
-  double* red_mu = red_s1 + 4 * CB * 16;                  // [4][CB][Dout][16]
-  double* red_s2 = red_mu + 4 * CB * 16 * Dout;           // [2][4][CB][16]
-  const double* ils = a.hyp + HYP_ILS;
-  const int64_t r0 = (int64_t)blockIdx.x * 16 * CB;
-  for (int idx = tid; idx < 16 * CB * Din; idx += 256) {
-    const int rr = idx / Din, j = idx % Din;
-    int64_t row = r0 + rr;
-    if (row > a.Rin - 1) row = a.Rin - 1;
-    xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
-  }
-  __syncthreads();
-  const bool act = Own<MPB>::active(wave);
-  const double s2 = a.hyp[HYP_VAR];
-
-  // --- Kuf tile (layers.py:184): own row-blocks -> act
-  if (act) {
+// scaled squared distances of this wave's inducing rows to the block's 16 data rows, D layout, chunked over D_in
+template <int NQ, int MPB, int NW>
+__device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const double* __restrict__ X,
+                                          const double* __restrict__ ils, double* xs, int Din, int64_t r0, int64_t Rin,
+                                          int tid, int wave, int g, int c, bool act, d4 (&r2)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
+  for (int q = 0; q < NQ; ++q) r2[q] = (d4){0, 0, 0, 0};
+  for (int j0 = 0; j0 < Din; j0 += XCH) {
+    const int jn = (Din - j0 < XCH) ? Din - j0 : XCH;
+    if (j0 > 0) __syncthreads();
+    for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
+      const int rr = idx / jn, j = idx % jn;
+      int64_t row = r0 + rr;
+      if (row > Rin - 1) row = Rin - 1;
+      xs[rr * (jn + 1) + j] = X[row * Din + j0 + j] * ils[j0 + j];
+    }
+    __syncthreads();
+    if (act) {
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int m = 16 * ib + g + 4 * t;
-          double r2 = 0.0;
-          for (int j = 0; j < Din; ++j) {
-            const double df = zs[m * Din + j] - xs[(cb * 16 + c) * (Din + 1) + j];
-            r2 = fma(df, df, r2);
+          const double* __restrict__ zr = zs + (int64_t)(16 * ib + g + 4 * t) * Din + j0;
+          double acc = r2[q][t];
+          for (int j = 0; j < jn; ++j) {
+            const double df = zr[j] - xs[c * (jn + 1) + j];
+            acc = fma(df, df, acc);
           }
-          actA[(cb * Mp + m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
-        }
-    }
-  }
-  __syncthreads();
-
-  d4 acc[NQ][CB];
-  // --- a1 = Lu^{-1} k (layers.py:186): out block ib sums k-blocks kb <= ib ; weights LinvT[k][i]
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) acc[q][cb] = (d4){0, 0, 0, 0};
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
-      const double* __restrict__ W = a.LinvT + 16 * ib + c + g * Mp;
-#pragma unroll 2
-      for (int kb = 0; kb <= ib; ++kb) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double av = W[(16 * kb + 4 * s) * Mp];
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-            acc[q][cb] = mfma_f64(av, actA[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c], acc[q][cb]);
+          r2[q][t] = acc;
         }
       }
     }
   }
-  {
-    double p[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      p[cb] = 0.0;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) p[cb] = fma(acc[q][cb][t], acc[q][cb][t], p[cb]);
-      p[cb] = sum_groups(p[cb]);
-      if (g == 0) red_s1[(wave * CB + cb) * 16 + c] = act ? p[cb] : 0.0;
+}
+
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
+__global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
+  const int Din = a.D_in, Dout = a.D_out;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  double* xs = smem + L.xs;
+  double* actb = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
+  double* red_s1 = smem + L.red;                          // [NW][16]
+  double* red_s2 = red_s1 + NW * 16;                      // [2][NW][16]
+  double* red_mu = red_s2 + 2 * NW * 16;                  // MU_EARLY: [NW][Dout][16] ; else [2][NW][16]
+  constexpr bool MU_EARLY = (NW == 4) && !WIDE;           // small-M kernels: all mean partials before the q_sqrt loop
+  const double* ils = a.hyp + HYP_ILS;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const bool act = Own<MPB, NW>::active(wave);
+  const double s2 = a.hyp[HYP_VAR];
+
+  // --- Kuf tile (layers.py:184): own row-blocks -> act
+  if constexpr (!WIDE) {
+    // D_in <= XCH: one staging pass, distances accumulated element by element (fewest live registers)
+    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
+      const int rr = idx / Din, j = idx % Din;
+      int64_t row = r0 + rr;
+      if (row > a.Rin - 1) row = a.Rin - 1;
+      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
     }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int m = 16 * ib + g + 4 * t;
+          const double* __restrict__ zr = a.Zs + (int64_t)m * Din;
+          double r2 = 0.0;
+          for (int j = 0; j < Din; ++j) {
+            const double df = zr[j] - xs[c * (Din + 1) + j];
+            r2 = fma(df, df, r2);
+          }
+          actb[m * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
+        }
+      }
+    }
+  } else {
+    d4 r2[NQ];
+    sm_sqdist<NQ, MPB, NW>(a.Zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int m = 16 * ib + g + 4 * t;
+          actb[m * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  d4 acc[NQ];
+  // --- a1 = Lu^{-1} k (layers.py:186): out block ib sums k-blocks kb <= ib ; weights LinvT[k][i]
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ib = Own<MPB, NW>::ib(wave, q);
+      const double* __restrict__ W = a.LinvT + 16 * ib + c + (int64_t)g * Mp;
+#pragma unroll 2
+      for (int kb = 0; kb <= ib; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc[q]);
+      }
+    }
+  }
+  {
+    double p = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p = fma(acc[q][t], acc[q][t], p);
+    p = sum_groups(p);
+    if (g == 0) red_s1[wave * 16 + c] = act ? p : 0.0;
   }
   __syncthreads();   // every wave has finished reading k before a1 overwrites it in place
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
+      const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) actB[(cb * Mp + 16 * ib + g + 4 * t) * 16 + c] = acc[q][cb][t];
+      for (int t = 0; t < 4; ++t) actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
     }
   }
   __syncthreads();
-  const double* actIn = actB;   // holds "a" for the q_sqrt stage (white: a = a1)
-  // --- a = Lu^{-T} a1 (layers.py:188): out block ib sums kb >= ib ; weights Linv[k][i]
+  // --- a = Lu^{-T} a1 (layers.py:188): out block ib sums kb >= ib ; weights Linv[k][i]   (white: a = a1)
   if (!WHITE) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[q][cb] = (d4){0, 0, 0, 0};
+    for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
     if (act) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB>::ib(wave, q);
-        const double* __restrict__ W = a.Linv + 16 * ib + c + g * Mp;
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        const double* __restrict__ W = a.Linv + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
         for (int kb = ib; kb < MPB; ++kb) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double av = W[(16 * kb + 4 * s) * Mp];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-              acc[q][cb] = mfma_f64(av, actB[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c], acc[q][cb]);
-          }
+          for (int s = 0; s < 4; ++s)
+            acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc[q]);
         }
       }
     }
@@ -163,45 +201,37 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
     if (act) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB>::ib(wave, q);
+        const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) actA[(cb * Mp + 16 * ib + g + 4 * t) * 16 + c] = acc[q][cb][t];
+        for (int t = 0; t < 4; ++t) actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
       }
     }
-    actIn = actA;
   }
-  // acc now holds this wave's rows of "a": save for the backward pass, and the partial mean a . q_mu (layers.py:190)
+  // acc holds this wave's rows of "a": save for the backward pass, and the partial mean a . q_mu (layers.py:190)
   if (act && a.Asave && blockIdx.y == 0) {
+    const int64_t r = r0 + c;
+    if (r < a.ldA) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const int64_t r = r0 + cb * 16 + c;
-        if (r < a.ldA) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = (r < a.Rin) ? acc[q][cb][t] : 0.0;
-        }
+        for (int t = 0; t < 4; ++t) a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = (r < a.Rin) ? acc[q][t] : 0.0;
       }
     }
   }
-  for (int d = 0; d < Dout; ++d) {
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
+  if constexpr (MU_EARLY) {
+    for (int d = 0; d < Dout; ++d) {
       double mu = 0.0;
       if (act) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB>::ib(wave, q);
+          const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) mu = fma(acc[q][cb][t], a.qmu[(16 * ib + g + 4 * t) * Dout + d], mu);
+          for (int t = 0; t < 4; ++t) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
         }
       }
       mu = sum_groups(mu);
-      if (g == 0) red_mu[((wave * CB + cb) * Dout + d) * 16 + c] = mu;
+      if (g == 0) red_mu[(wave * Dout + d) * 16 + c] = mu;
     }
   }
   __syncthreads();
@@ -212,70 +242,73 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
   const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
   for (int d = d_lo; d < d_hi; ++d) {
     // --- c_d = q_sqrt_d^T a ; |c_d|^2 (replaces SK/B of layers.py:195-212): out block ib sums kb >= ib
-    d4 cacc[NQ][CB];
+    d4 cacc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) cacc[q][cb] = (d4){0, 0, 0, 0};
+    for (int q = 0; q < NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
     if (act) {
       const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB>::ib(wave, q);
-        const double* __restrict__ W = Td + 16 * ib + c + g * Mp;
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        const double* __restrict__ W = Td + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
         for (int kb = ib; kb < MPB; ++kb) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double av = W[(16 * kb + 4 * s) * Mp];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-              cacc[q][cb] = mfma_f64(av, actIn[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c], cacc[q][cb]);
-          }
+          for (int s = 0; s < 4; ++s)
+            cacc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], cacc[q]);
         }
       }
     }
-    double* rs2 = red_s2 + (d & 1) * 4 * CB * 16;
+    double* rs2 = red_s2 + (d & 1) * NW * 16;
+    double* rmu = MU_EARLY ? red_mu + d * 16 : red_mu + (d & 1) * NW * 16;
+    const int rmu_stride = MU_EARLY ? Dout * 16 : 16;
+    {
+      double p = 0.0, mu = 0.0;
+      if (act) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      double p = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+          const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) p = fma(cacc[q][cb][t], cacc[q][cb][t], p);
+          for (int t = 0; t < 4; ++t) {
+            p = fma(cacc[q][t], cacc[q][t], p);
+            if constexpr (!MU_EARLY) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
+          }
+        }
+      }
       p = sum_groups(p);
-      if (g == 0) rs2[(wave * CB + cb) * 16 + c] = act ? p : 0.0;
+      if constexpr (!MU_EARLY) mu = sum_groups(mu);
+      if (g == 0) {
+        rs2[wave * 16 + c] = p;
+        if constexpr (!MU_EARLY) rmu[wave * 16 + c] = mu;
+      }
     }
     __syncthreads();
-    if (wave == (d & 3)) {
+    if (wave == (d % NW)) {
+      const int64_t r = r0 + c;
+      if (r < a.Rin) {
+        double s1 = 0.0, s2sum = 0.0, mu = 0.0;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const int64_t r = r0 + cb * 16 + c;
-        if (r < a.Rin) {
-          double s1 = 0.0, s2sum = 0.0, mu = 0.0;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            s1 += red_s1[(w * CB + cb) * 16 + c];
-            s2sum += rs2[(w * CB + cb) * 16 + c];
-            mu += red_mu[((w * CB + cb) * Dout + d) * 16 + c];
-          }
-          const double var = kdiag - s1 + s2sum;                               // layers.py:212-217
-          if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
-            mu += a.X[r * Din + d];
-          } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-            double m2 = 0.0;
-            for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[j * Dout + d], m2);
-            mu += m2;
-          }
-          for (int s = g; s < a.rep; s += 4) {
-            const int64_t orow = (int64_t)s * a.Rin + r;
-            const int64_t o = orow * Dout + d;
-            if (a.mean) a.mean[o] = mu;
-            if (a.var) a.var[o] = var;
-            if (a.F && a.z) {
-              const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
-              a.F[o] = mu + zv * sqrt(var + a.jitter);                         // utils.py:41 (no clamp)
-            }
+        for (int w = 0; w < NW; ++w) {
+          s1 += red_s1[w * 16 + c];
+          s2sum += rs2[w * 16 + c];
+          mu += rmu[w * rmu_stride + c];
+        }
+        const double var = kdiag - s1 + s2sum;                               // layers.py:212-217
+        if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
+          mu += a.X[r * Din + d];
+        } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+          double m2 = 0.0;
+          for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
+          mu += m2;
+        }
+        for (int s = g; s < a.rep; s += 4) {
+          const int64_t orow = (int64_t)s * a.Rin + r;
+          const int64_t o = orow * Dout + d;
+          if (a.mean) a.mean[o] = mu;
+          if (a.var) a.var[o] = var;
+          if (a.F && a.z) {
+            const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
+            a.F[o] = mu + zv * sqrt(var + a.jitter);                         // utils.py:41 (no clamp)
           }
         }
       }
@@ -284,94 +317,65 @@ __global__ __launch_bounds__(256) void k_layer_fwd_sm(const LayerFwdArgs a, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * 4 + wave).
+// backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * NW + wave).
 // ------------------------------------------------------------------------------------------------------
-template <int MPB, int KIND, bool WHITE, int CB>
-__global__ __launch_bounds__(256) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
+__global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int Mp = MPB * 16, NQ = Own<MPB>::NQ;
+  constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const double* __restrict__ zs = a.Zs;
   double* xs = smem + L.xs;
-  double* actA = smem + L.act;
-  double* actB = actA;
-  double* redx = smem + L.red;                            // [4][CB][Din][16]
+  double* actb = smem + L.act;
+  double* redx = smem + L.red;                            // [NW][chunk][16]
   const double* ils = a.hyp + HYP_ILS;
-  const int64_t r0 = (int64_t)blockIdx.x * 16 * CB;
-  for (int idx = tid; idx < 16 * CB * Din; idx += 256) {
-    const int rr = idx / Din, j = idx % Din;
-    int64_t row = r0 + rr;
-    if (row > a.Rin - 1) row = a.Rin - 1;
-    xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
-  }
-  const bool act = Own<MPB>::active(wave);
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const bool act = Own<MPB, NW>::active(wave);
   const double s2 = a.hyp[HYP_VAR];
-  int64_t r[CB];
-  bool rin[CB], rvalid[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) {
-    r[cb] = r0 + cb * 16 + c;
-    rin[cb] = r[cb] < a.ldA;
-    rvalid[cb] = r[cb] < a.Rin;
-  }
-  d4 av[NQ][CB], acc[NQ][CB];
+  const int64_t r = r0 + c;
+  const bool rin = r < a.ldA, rvalid = r < a.Rin;
+  d4 av[NQ], acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int ib = Own<MPB>::ib(wave, q);
+    const int ib = Own<MPB, NW>::ib(wave, q);
+    acc[q] = (d4){0, 0, 0, 0};
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      acc[q][cb] = (d4){0, 0, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double v = (act && rin[cb]) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r[cb]] : 0.0;
-        av[q][cb][t] = v;
-        if (act) actA[(cb * Mp + 16 * ib + g + 4 * t) * 16 + c] = v;
-      }
+    for (int t = 0; t < 4; ++t) {
+      const double v = (act && rin) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] : 0.0;
+      av[q][t] = v;
+      if (act) actb[(16 * ib + g + 4 * t) * 16 + c] = v;
     }
   }
   __syncthreads();
-  double gsum[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) gsum[cb] = 0.0;
+  double gsum = 0.0;
   for (int d = 0; d < Dout; ++d) {
-    double vd2[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const double vd = rin[cb] ? a.VB[(int64_t)d * a.ldA + r[cb]] : 0.0;
-      gsum[cb] += vd;
-      vd2[cb] = 2.0 * vd;
-    }
+    const double vd = rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
+    gsum += vd;
+    const double vd2 = 2.0 * vd;
     if (act) {
       const double* __restrict__ Sd = a.Sd + (int64_t)d * Mp * Mp;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB>::ib(wave, q);
-        const double* __restrict__ W = Sd + 16 * ib + c + g * Mp;
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
         for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double wv = W[(16 * kb + 4 * s) * Mp];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-              acc[q][cb] = mfma_f64(wv, actA[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c] * vd2[cb], acc[q][cb]);
-          }
+          for (int s = 0; s < 4; ++s)
+            acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c] * vd2, acc[q]);
         }
       }
     }
   }
   if (act) {
     for (int sp = 0; sp < a.DP4 / 4; ++sp) {
+      const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const double bv = rin[cb] ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r[cb]] : 0.0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB>::ib(wave, q);
-          acc[q][cb] = mfma_f64(a.qmu4[(16 * ib + c) * a.DP4 + 4 * sp + g], bv, acc[q][cb]);
-        }
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        acc[q] = mfma_f64(a.qmu4[(int64_t)(16 * ib + c) * a.DP4 + 4 * sp + g], bv, acc[q]);
       }
     }
   }
@@ -379,122 +383,139 @@ __global__ __launch_bounds__(256) void k_layer_bwd_sm(const LayerBwdArgs a, cons
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
+      const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (WHITE) acc[q][cb][t] -= 2.0 * gsum[cb] * av[q][cb][t];
-          actB[(cb * Mp + 16 * ib + g + 4 * t) * 16 + c] = acc[q][cb][t];
-        }
+      for (int t = 0; t < 4; ++t) {
+        if (WHITE) acc[q][t] -= 2.0 * gsum * av[q][t];
+        actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
+      }
     }
   }
   __syncthreads();
   // b = Ku^{-1} abar (dense)   |   white: kbar = Lu^{-T} a1bar (k-blocks >= own block)
-  d4 bb[NQ][CB];
+  d4 bb[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bb[q][cb] = (d4){0, 0, 0, 0};
+  for (int q = 0; q < NQ; ++q) bb[q] = (d4){0, 0, 0, 0};
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
-      const double* __restrict__ W = (WHITE ? a.Linv : a.Kinv) + 16 * ib + c + g * Mp;
+      const int ib = Own<MPB, NW>::ib(wave, q);
+      const double* __restrict__ W = (WHITE ? a.Linv : a.Kinv) + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
       for (int kb = (WHITE ? ib : 0); kb < MPB; ++kb) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double wv = W[(16 * kb + 4 * s) * Mp];
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-            bb[q][cb] = mfma_f64(wv, actB[(cb * Mp + 16 * kb + 4 * s + g) * 16 + c], bb[q][cb]);
-        }
+        for (int s = 0; s < 4; ++s)
+          bb[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], bb[q]);
       }
     }
   }
-  // E, kbar, GW and the hyper-parameter / input-gradient partial sums over this wave's inducing rows
+  // E, kbar; recompute the Kuf tile for GW = kbar * dk/dr2
+  d4 r2[WIDE ? NQ : 1];
+  if constexpr (WIDE) {
+    sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
+  } else {
+    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
+      const int rr = idx / Din, j = idx % Din;
+      int64_t row = r0 + rr;
+      if (row > a.Rin - 1) row = a.Rin - 1;
+      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
+    }
+    __syncthreads();
+  }
   double svar = 0.0;
   if (act) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB>::ib(wave, q);
+      const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int m = 16 * ib + g + 4 * t;
-          const double e = WHITE ? bb[q][cb][t] : bb[q][cb][t] - gsum[cb] * av[q][cb][t];
-          const double kbar = WHITE ? e : e - gsum[cb] * av[q][cb][t];
-          double r2 = 0.0;
+      for (int t = 0; t < 4; ++t) {
+        const int m = 16 * ib + g + 4 * t;
+        const double e = WHITE ? bb[q][t] : bb[q][t] - gsum * av[q][t];
+        const double kbar = WHITE ? e : e - gsum * av[q][t];
+        double r2v;
+        if constexpr (WIDE) {
+          r2v = r2[q][t];
+        } else {
+          r2v = 0.0;
           for (int j = 0; j < Din; ++j) {
-            const double df = zs[m * Din + j] - xs[(cb * 16 + c) * (Din + 1) + j];
-            r2 = fma(df, df, r2);
-          }
-          double k, dk;
-          kern_val_grad<KIND>(r2, s2, k, dk);
-          const bool ok = rvalid[cb] && (m < a.M);
-          svar += ok ? kbar * k : 0.0;
-          const double w = ok ? kbar * dk : 0.0;
-          bb[q][cb][t] = w;
-          if (rin[cb]) {
-            a.E[(int64_t)m * a.ldA + r[cb]] = e;
-            a.GW[(int64_t)m * a.ldA + r[cb]] = w;
+            const double df = zs[(int64_t)m * Din + j] - xs[c * (Din + 1) + j];
+            r2v = fma(df, df, r2v);
           }
         }
+        double k, dk;
+        kern_val_grad<KIND>(r2v, s2, k, dk);
+        const bool ok = rvalid && (m < a.M);
+        svar += ok ? kbar * k : 0.0;
+        const double w = ok ? kbar * dk : 0.0;
+        bb[q][t] = w;
+        if (rin) {
+          a.E[(int64_t)m * a.ldA + r] = e;
+          a.GW[(int64_t)m * a.ldA + r] = w;
+        }
+      }
     }
   }
   svar = sum_wave(svar);
-  double gk = 0.0;
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) gk += (rvalid[cb] && g == 0 && wave == 0) ? gsum[cb] : 0.0;
-  gk = sum_wave(gk);
-  double* hp = a.hyp_part + ((int64_t)blockIdx.x * 4 + wave) * (Din + 2);
+  const double gk = sum_wave((rvalid && g == 0 && wave == 0) ? gsum : 0.0);
+  double* hp = a.hyp_part + ((int64_t)blockIdx.x * NW + wave) * (Din + 2);
   if (lane == 0) {
     hp[0] = svar / s2;
     hp[1] = gk;
   }
-  for (int j = 0; j < Din; ++j) {
-    double sl = 0.0;
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      double sx = 0.0;
+  // lengthscale partials and d loss / d X, chunked over D_in like the distance computation
+  for (int j0 = 0; j0 < Din; j0 += XCH) {
+    const int jn = (Din - j0 < XCH) ? Din - j0 : XCH;
+    if (WIDE) {   // single-chunk kernels: xs still holds x/l staged above
+      __syncthreads();
+      for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
+        const int rr = idx / jn, j = idx % jn;
+        int64_t row = r0 + rr;
+        if (row > a.Rin - 1) row = a.Rin - 1;
+        xs[rr * (jn + 1) + j] = a.X[row * Din + j0 + j] * ils[j0 + j];
+      }
+      __syncthreads();
+    }
+    for (int j = 0; j < jn; ++j) {
+      double sx = 0.0, sl = 0.0;
       if (act) {
-        const double xv = xs[(cb * 16 + c) * (Din + 1) + j];
+        const double xv = xs[c * (jn + 1) + j];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB>::ib(wave, q);
+          const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const double df = xv - zs[(16 * ib + g + 4 * t) * Din + j];
-            const double wdf = bb[q][cb][t] * df;
+            const double df = xv - zs[(int64_t)(16 * ib + g + 4 * t) * Din + j0 + j];
+            const double wdf = bb[q][t] * df;
             sx += wdf;
             sl = fma(wdf, df, sl);
           }
         }
       }
-      sx = sum_groups(sx);
-      if (g == 0) redx[((wave * CB + cb) * Din + j) * 16 + c] = sx;
-    }
-    sl = sum_wave(sl);
-    if (lane == 0) hp[2 + j] = -2.0 * ils[j] * sl;
-  }
-  if (!a.dX) return;
-  __syncthreads();
-  for (int idx = tid; idx < CB * 16 * Din; idx += 256) {
-    const int j = idx % Din, rr = idx / Din, cb = rr / 16, cc = rr % 16;
-    const int64_t row = r0 + rr;
-    if (row < a.Rin) {
-      double sx = 0.0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sx += redx[((w * CB + cb) * Din + j) * 16 + cc];
-      double dx = 2.0 * ils[j] * sx;
-      if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
-        dx += a.MB[(int64_t)j * a.ldA + row];
-      } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-        for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[j * Dout + d], a.MB[(int64_t)d * a.ldA + row], dx);
+      if (a.dX) {
+        sx = sum_groups(sx);
+        if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
       }
-      a.dX[row * Din + j] = dx;
+      sl = sum_wave(sl);
+      if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
+    }
+    if (a.dX) {
+      __syncthreads();
+      for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
+        const int j = idx % jn, cc = idx / jn;
+        const int64_t row = r0 + cc;
+        if (row < a.Rin) {
+          double sx = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) sx += redx[(w * jn + j) * 16 + cc];
+          double dx = 2.0 * ils[j0 + j] * sx;
+          if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
+            dx += a.MB[(int64_t)(j0 + j) * a.ldA + row];
+          } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+            for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[(int64_t)(j0 + j) * Dout + d], a.MB[(int64_t)d * a.ldA + row], dx);
+          }
+          a.dX[row * Din + j0 + j] = dx;
+        }
+      }
     }
   }
 }
@@ -502,71 +523,68 @@ __global__ __launch_bounds__(256) void k_layer_bwd_sm(const LayerBwdArgs a, cons
 // ------------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------------
-int sm_chain_cb() {
-  static const int cb = getenv("DSDGP_SM_CB") ? atoi(getenv("DSDGP_SM_CB")) : 1;
-  return cb == 2 ? 2 : 1;
-}
 int sm_chain_enabled() {
   static const int on = getenv("DSDGP_CHAIN_SM") ? atoi(getenv("DSDGP_CHAIN_SM")) : 1;
   return on;
 }
-int64_t sm_hyp_parts(int64_t ld) { return 4 * (int64_t)ceil_div(ld, 16 * sm_chain_cb()); }
+static inline int sm_nw(int Mp) { return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : 4); }
+int64_t sm_hyp_parts(int64_t ld, int Mp) { return (int64_t)sm_nw(Mp) * ceil_div(ld, 16); }
 
-template <int MPB, int KIND, bool WHITE, int CB>
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
-  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, CB);
+  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE);
   const size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) {
-    dsdgp_set_error("layer_fwd(sm): needs %zu B LDS", lds);
+    dsdgp_set_error("layer_fwd(sm): needs %zu B LDS (> 160 KiB): D_out too large for this M", lds);
     return DSDGP_ERR_UNSUPPORTED;
   }
   if (lds > 64 * 1024)
-    DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, KIND, WHITE, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(ctx, "layer_fwd");
-  const int nrow = ceil_div(a.Rin, 16 * CB);
+  const int nrow = ceil_div(a.Rin, 16);
   int ds = a.d_split > 0 ? a.d_split : 1;
   if (ds > a.D_out) ds = a.D_out;
-  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, KIND, WHITE, CB>), dim3(nrow, ds), dim3(256), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
-template <int MPB, int KIND, bool WHITE, int CB>
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
-  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, CB);
+  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE);
   const size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) {
-    dsdgp_set_error("layer_bwd(sm): needs %zu B LDS", lds);
+    dsdgp_set_error("layer_bwd(sm): needs %zu B LDS (> 160 KiB)", lds);
     return DSDGP_ERR_UNSUPPORTED;
   }
   if (lds > 64 * 1024)
-    DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, KIND, WHITE, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(ctx, "layer_bwd");
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, KIND, WHITE, CB>), dim3(ceil_div(a.ldA, 16 * CB)), dim3(256), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
 
-#define SM_DISPATCH(FN, ARGS)                                                                      \
-  const int cb = sm_chain_cb();                                                                    \
-  switch (Mp) {                                                                                    \
-    SM_CASE(FN, 2, ARGS) SM_CASE(FN, 4, ARGS) SM_CASE(FN, 8, ARGS) SM_CASE(FN, 16, ARGS)           \
-    default:                                                                                       \
-      dsdgp_set_error("layer chain (sm): padded inducing count %d not built", Mp);                 \
-      return DSDGP_ERR_UNSUPPORTED;                                                                \
+#define SM_CASE2(FN, MPB, NW, KIND, ARGS)                                                              \
+  if (wide) return white ? FN<MPB, NW, KIND, true, true> ARGS : FN<MPB, NW, KIND, false, true> ARGS;      \
+  return white ? FN<MPB, NW, KIND, true, false> ARGS : FN<MPB, NW, KIND, false, false> ARGS;
+#define SM_CASE(FN, MPB, NW, ARGS)                                           \
+  case MPB * 16:                                                             \
+    if (kern_kind == DSDGP_KERN_RBF) { SM_CASE2(FN, MPB, NW, DSDGP_KERN_RBF, ARGS) }   \
+    SM_CASE2(FN, MPB, NW, DSDGP_KERN_MATERN52, ARGS)
+#define SM_DISPATCH(FN, ARGS)                                                          \
+  switch (Mp) {                                                                        \
+    SM_CASE(FN, 2, 4, ARGS) SM_CASE(FN, 4, 4, ARGS) SM_CASE(FN, 8, 4, ARGS)            \
+    SM_CASE(FN, 16, 4, ARGS) SM_CASE(FN, 32, 8, ARGS) SM_CASE(FN, 64, 16, ARGS)        \
+    default:                                                                           \
+      dsdgp_set_error("layer chain: padded inducing count %d not built (32..1024)", Mp); \
+      return DSDGP_ERR_UNSUPPORTED;                                                    \
   }
-#define SM_CASE(FN, MPB, ARGS)                                                                     \
-  case MPB * 16:                                                                                   \
-    if (kern_kind == DSDGP_KERN_RBF) {                                                             \
-      if (white) return cb == 2 ? FN<MPB, DSDGP_KERN_RBF, true, 2> ARGS : FN<MPB, DSDGP_KERN_RBF, true, 1> ARGS;   \
-      return cb == 2 ? FN<MPB, DSDGP_KERN_RBF, false, 2> ARGS : FN<MPB, DSDGP_KERN_RBF, false, 1> ARGS;            \
-    } else {                                                                                       \
-      if (white) return cb == 2 ? FN<MPB, DSDGP_KERN_MATERN52, true, 2> ARGS : FN<MPB, DSDGP_KERN_MATERN52, true, 1> ARGS; \
-      return cb == 2 ? FN<MPB, DSDGP_KERN_MATERN52, false, 2> ARGS : FN<MPB, DSDGP_KERN_MATERN52, false, 1> ARGS;  \
-    }
 
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white) {
+  const bool wide = a.D_in > XCH;
   SM_DISPATCH(fwd_sm_go, (ctx, a))
 }
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
+  const bool wide = a.D_in > XCH;
   SM_DISPATCH(bwd_sm_go, (ctx, a))
 }

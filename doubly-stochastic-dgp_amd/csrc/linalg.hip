@@ -336,6 +336,43 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
   }
   if (!Linv) return;
   PH(4);
+  if (nb > POTRF_MAXNB) {
+    // large matrices (n > 256): block-row recurrence through global memory, one barrier per block row
+    __syncthreads();
+    for (int jb = 0; jb < nb; ++jb) {          // diagonal blocks of the inverse
+      const double* Xi = Xdall + jb * 16 * 17;
+      for (int idx = tid; idx < 256; idx += 256) {
+        const int i = idx >> 4, j = idx & 15;
+        const double v = Xi[i * 17 + j];
+        Linv[(int64_t)(jb * 16 + i) * ldi + jb * 16 + j] = v;
+        if (it.LinvT) it.LinvT[(int64_t)(jb * 16 + j) * ldi + jb * 16 + i] = v;
+      }
+    }
+    __syncthreads();
+    for (int ib = 1; ib < nb; ++ib) {
+      const double* Xi = Xdall + ib * 16 * 17;
+      for (int jb2 = wave; jb2 < ib; jb2 += 4) {
+        d4 S0 = (d4){0, 0, 0, 0};
+        for (int kb = jb2; kb < ib; ++kb) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double av = W[(int64_t)(ib * 16 + c) * ld + kb * 16 + 4 * s + g];
+            const double bv = Linv[(int64_t)(kb * 16 + 4 * s + g) * ldi + jb2 * 16 + c];
+            S0 = mfma_f64(av, bv, S0);
+          }
+        }
+        d4 R = (d4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) R = mfma_f64(-Xi[c * 17 + 4 * s + g], S0[s], R);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          Linv[(int64_t)(ib * 16 + g + 4 * t) * ldi + jb2 * 16 + c] = R[t];
+          if (it.LinvT) it.LinvT[(int64_t)(jb2 * 16 + c) * ldi + ib * 16 + g + 4 * t] = R[t];
+        }
+      }
+      __syncthreads();
+    }
+  } else
   // block-column forward substitution, columns paired (w, nb-1-w, w+4, ...) so the four waves carry equal work
   for (int q = 0; q < (nb + 3) / 4; ++q) {
     const int jcol = ((q & 1) == 0) ? (q / 2) * 8 + wave : (q / 2) * 8 + 7 - wave;
@@ -393,6 +430,8 @@ int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_m
       DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items, nb_max);
   } else {
+    if (base > 64 * 1024)
+      DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)base));
     hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items, nb_max);
   }
   DS_HIP(hipGetLastError());

@@ -187,7 +187,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
-    S.hyp_part = b.take<double>((size_t)4 * (S.ld_max / 16 + 1) * (d.D_in + 2));
+    S.hyp_part = b.take<double>((size_t)(sm_hyp_parts(S.ld_max, v.Mp) + 16) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 3);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -674,8 +674,8 @@ static int validate_desc(const dsdgp_model_desc* d) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
     DS_CHECK_ARG(y.kern_kind == DSDGP_KERN_RBF || y.kern_kind == DSDGP_KERN_MATERN52);
-    if (pad_M(y.M) > 256) {
-      dsdgp_set_error("layer %d: M=%d > 256 inducing points needs the streamed large-M path (not built yet)", l, y.M);
+    if (pad_M(y.M) > (sm_chain_enabled() ? 1024 : 256)) {
+      dsdgp_set_error("layer %d: M=%d inducing points exceeds the built chain kernels (<= 1024)", l, y.M);
       return DSDGP_ERR_UNSUPPORTED;
     }
     if (l > 0) DS_CHECK_ARG(y.D_in == d->layers[l - 1].D_out);
@@ -997,7 +997,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
     red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0});
     red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld) : (int)nch, 0, 1, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp) : (int)nch, 0, 1, 0});
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }

@@ -448,3 +448,52 @@ def test_full_cov_propagation(white):
     mf, vf = model.layers[0].conditional_ND(Xs, full_cov=True)
     assert_allclose(np.einsum("iid->id", vf), vd, rtol=1e-9, atol=1e-11)
     assert_allclose(mf, md, rtol=1e-10, atol=1e-12)
+
+
+# ---------------------------------------------------------------- large M / wide inputs (config-4/5-shaped slices)
+def test_cfg4_shape_mnist_like_multiclass():
+    # BASELINE.json configs[3] shape: widths 784 -> 30 (fixed PCA Linear mean) -> 30 (Identity) -> 10, M = 512,
+    # MultiClass(10) (demo_mnist.ipynb:99-104).  Slice: N = 32 of 300 rows, S = 2.
+    rng = np.random.RandomState(40)
+    Ndata, N, S, M, K = 300, 32, 2, 512, 10
+    Xall = rng.uniform(size=(Ndata, 784)) * (rng.uniform(size=(Ndata, 784)) < 0.19)
+    Yall = rng.choice(np.arange(K, dtype=np.float64), Ndata).reshape(Ndata, 1)
+    Z = Xall[rng.permutation(Ndata)[:M % Ndata or Ndata]]
+    Z = np.concatenate([Z, Xall[:M - Z.shape[0]] + 0.05 * rng.randn(M - Z.shape[0], 784)]) if Z.shape[0] < M else Z
+    specs = [kern_spec("rbf", 784, 2.0, 2.0), kern_spec("rbf", 30, 2.0, 2.0), kern_spec("rbf", 30, 2.0, 2.0)]
+    spec, state, model = make_case(Xall, Yall, Z, specs, S=S, num_data=60000, num_classes=K)
+    X, Y = Xall[:N], Yall[:N]
+    zs = [rng.randn(S, N, 30), rng.randn(S, N, 30), rng.randn(S, N, K)]
+    _, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    _, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    for l in range(3):
+        assert_allclose(Fm[l], Fm_o[l], rtol=1e-8, atol=1e-9)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-8, atol=1e-9)
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=60000, tol=1e-6)
+
+
+def test_cfg5_shape_M1024():
+    # BASELINE.json configs[4] shape: 3 layers 8 -> 8 -> 8 -> 1, M = 1024 (slice N = 32, S = 2) + one natural-gradient step
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(41)
+    N, D, M, S = 32, 8, 1024, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = rng.randn(M, D) * 1.5
+    specs = [kern_spec("rbf", D, 1.0, 1.0)] * 3
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=7372)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 1)]
+    _, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    _, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    assert_allclose(Fm[-1], Fm_o[-1], rtol=1e-8, atol=1e-9)
+    assert_allclose(Fv[-1], Fv_o[-1], rtol=1e-8, atol=1e-9)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=7372)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-8)
+    grads = model.engine().gradient_dict()
+    for k in ("l2.q_mu", "l1.Z", "l0.kern_lengthscales_raw", "l2.q_sqrt"):
+        assert np.max(np.abs(-g[k] - grads[k])) <= 1e-6 * (np.max(np.abs(g[k])) + 1e-12), k
+    mu, sq = O.natgrad_step(state["l2.q_mu"], state["l2.q_sqrt"], -g["l2.q_mu"], -g["l2.q_sqrt"], 0.1)
+    last = model.layers[-1]
+    NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
+    assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
