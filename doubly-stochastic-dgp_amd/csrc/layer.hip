@@ -496,10 +496,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
   while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
   const WgradJob J = jobs[jb];
   int local = w - J.task_start;
-  const int tiles = J.ti * J.tj;
+  const int tiles = J.sym ? J.ti * (J.ti + 1) / 2 : J.ti * J.tj;
   const int split = local / tiles;
   local = local % tiles;
-  const int tile_i = local / J.tj, tile_j = local % J.tj;
+  int tile_i, tile_j;
+  if (J.sym) {
+    tile_i = 0;
+    while ((tile_i + 1) * (tile_i + 2) / 2 <= local) ++tile_i;
+    tile_j = local - tile_i * (tile_i + 1) / 2;
+  } else {
+    tile_i = local / J.tj;
+    tile_j = local % J.tj;
+  }
   const int64_t nch = Rp / 16;
   const int64_t c_lo = split * nch / nsplit, c_hi = (split + 1) * nch / nsplit;
   d4 acc[NI][NJ];

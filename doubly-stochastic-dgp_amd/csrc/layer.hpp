@@ -61,6 +61,7 @@ struct WgradJob {
   int32_t ti, tj;       // tiles in i / j (tile = 16*NI x 16*NJ)
   int32_t ldo;
   int32_t task_start;
+  int32_t sym, pad;     // sym: P == Q (symmetric result): only tiles with tile_j <= tile_i are computed
 };
 
 int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);

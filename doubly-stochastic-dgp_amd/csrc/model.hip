@@ -35,7 +35,9 @@ struct RedJob {
   double* out;
   int64_t count;
   int32_t nsplit, blk_start;
-  int32_t wide, pad;   // wide: few outputs, many splits -> one workgroup per output element (fixed-order tree)
+  int32_t wide;        // wide: few outputs, many splits -> one workgroup per output element (fixed-order tree)
+  int32_t sym_n;       // > 0: (sym_n x sym_n) symmetric result whose 64x64 tiles above the diagonal were not computed
+  int32_t sym_tile;
 };
 
 struct LayerState {
@@ -183,7 +185,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int tj_big = v.Mp / (16 * NI);
-    S.nsplit_big_max = choose_nsplit((1 + d.D_out) * ti * tj_big, S.ld_max / 16, 1024);
+    S.nsplit_big_max = choose_nsplit(ti * tj_big + d.D_out * (ti * (ti + 1) / 2), S.ld_max / 16, 1024);
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
@@ -483,8 +485,13 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     if (threadIdx.x == 0) J.out[i] = s;
     return;
   }
-  const int64_t i = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
-  if (i >= J.count) return;
+  const int64_t i0 = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
+  if (i0 >= J.count) return;
+  int64_t i = i0;
+  if (J.sym_n > 0) {   // mirror the tiles above the diagonal from their transposes
+    const int64_t r = i0 / J.sym_n, cc = i0 % J.sym_n;
+    if (cc / J.sym_tile > r / J.sym_tile) i = cc * J.sym_n + r;
+  }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
   for (; sp + 8 <= J.nsplit; sp += 8) {     // eight independent loads in flight; fixed order -> deterministic
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.count + i];
   }
   for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.count + i];
-  J.out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  J.out[i0] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu
@@ -973,7 +980,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     wgrad_shapes(v.Mp, NI, ti);
     const int64_t MM = (int64_t)v.Mp * v.Mp;
     std::vector<WgradJob> jobs(v.D_out + 3);
-    int ns = choose_nsplit((1 + v.D_out) * ti * ti, nch, 1024);
+    int ns = choose_nsplit(ti * ti + v.D_out * (ti * (ti + 1) / 2), nch, 1024);   // G is full, the D_out P_d are symmetric
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
     St.ns_big = ns;
     int start = 0;
@@ -984,20 +991,21 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
       J.out = St.part_big + (int64_t)j * ns * MM;
       J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
-      start += ns * ti * ti;
-      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, 0});
+      J.sym = (j >= 1) ? 1 : 0; J.pad = 0;                 // P_d = sum_r v a a^T is symmetric; G = E A^T is not
+      start += ns * (J.sym ? ti * (ti + 1) / 2 : ti * ti);
+      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16 * NI});
     }
     St.tot_big = start;
     int nt = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), nch, 512);
     if (nt > St.nsplit_thin_max) nt = St.nsplit_thin_max;
     St.ns_thin = nt;
-    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, v.DP16 / 16, v.DP16, 0};
+    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, v.DP16 / 16, v.DP16, 0, 0, 0};
     jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, v.DinP16 / 16,
-                                 v.DinP16, nt * ti * (v.DP16 / 16)};
+                                 v.DinP16, nt * ti * (v.DP16 / 16), 0, 0};
     St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
-    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0});
-    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp) : (int)nch, 0, 1, 0});
+    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
+    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp) : (int)nch, 0, 1, 0, 0});
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -1113,7 +1121,6 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   }
   DS_HIP(hipGetLastError());
   if (with_grad) {
-    DS_HIP(hipMemsetAsync(m->grad, 0, m->desc.n_theta * sizeof(double), ctx->stream));
     DS_TRY(backward_layers(m, n, S, kl_weight));
   }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, L, m->lik_part, nblocks, w, kl_weight,

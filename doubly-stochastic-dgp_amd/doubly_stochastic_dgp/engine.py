@@ -55,8 +55,9 @@ class Context:
         return self.torch.empty(*shape, dtype=self.torch.float64, device=f"cuda:{self.device}")
 
     def to_device(self, arr):
-        t = self.torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64))
-        return t.to(f"cuda:{self.device}")
+        a = np.array(arr, dtype=np.float64, order="C", copy=True) if not getattr(arr, "flags", None) or not arr.flags.writeable \
+            else np.ascontiguousarray(arr, dtype=np.float64)
+        return self.torch.as_tensor(a).to(f"cuda:{self.device}")
 
     def prof_enable(self, on=True):
         _lib.check(self.lib.dsdgp_prof_enable(self.handle, int(on)))

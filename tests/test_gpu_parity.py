@@ -497,3 +497,61 @@ def test_cfg5_shape_M1024():
     NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
     assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
     assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------- full BASELINE.json sizes
+def test_full_size_cfg2_against_oracle():
+    # configs[1] at full size: N = 1000, S = 20, M = 128, 3 layers, inner q_sqrt * 1e-5 (the benchmark workload itself)
+    rng = np.random.RandomState(50)
+    N, D, M, S = 1000, 8, 128, 20
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[rng.permutation(N)[:M]] + 0.05 * rng.randn(M, D)
+    spec, state, model = make_case(X, Y, Z, [kern_spec("rbf", D)] * 3, S=S, num_data=7372, q_sqrt_scale=1e-5, lik_var=1.0)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), np.zeros((1, 1, 1))]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=7372)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-8)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-5, (k, err)        # q_sqrt*1e-5 => cancellation-dominated variances
+
+
+def test_full_size_cfg3_properties():
+    # configs[2] at full size (5 layers, D = 9, M = 256, S = 20, minibatch 2000): the oracle would need minutes, so check
+    # size-independent properties of the device path instead
+    rng = np.random.RandomState(51)
+    N, D, M, S = 2000, 9, 256, 20
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[rng.permutation(N)[:M]] + 0.05 * rng.randn(M, D)
+    spec, state, model = make_case(X, Y, Z, [kern_spec("rbf", D, 1.0, 1.5)] * 5, S=S, num_data=41157)
+    zs = [rng.randn(S, N, D) for _ in range(4)] + [np.zeros((1, 1, 1))]
+    e1 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    g1 = model.engine().grad.cpu().numpy().copy()
+    e2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    g2 = model.engine().grad.cpu().numpy().copy()
+    assert e1 == e2 and np.array_equal(g1, g2)                          # bitwise deterministic (no atomics)
+    # (i) permuting the minibatch rows (with their noise) leaves the ELBO unchanged
+    perm = rng.permutation(N)
+    zp = [z[:, perm, :] for z in zs[:4]] + [zs[4]]
+    e3 = model._build_likelihood(X[perm], Y[perm], zs=zp)
+    assert_allclose(e3, e1, rtol=1e-11)
+    # (ii) the S-sample estimator is the mean of the S single-sample estimators (same KL): rows are independent
+    eng = model.engine()
+    out_all = eng.elbo(X, Y, S, zs=zs, data_scale=1.0, kl_weight=0.0)
+    acc = 0.0
+    for s_ in (0, 7, 19):
+        out_s = eng.elbo(X, Y, 1, zs=[z[s_:s_ + 1] for z in zs[:4]] + [zs[4]], data_scale=1.0, kl_weight=0.0)
+        acc += out_s[1]
+    _, Fm, Fv = eng.propagate(X, S, zs=zs, want=("mean", "var"))
+    from doubly_stochastic_dgp.utils import BroadcastingLikelihood
+    ve = model.likelihood.variational_expectations_mean(Fm[-1].cpu().numpy(), Fv[-1].cpu().numpy(), Y)
+    assert_allclose(ve.sum(), out_all[1], rtol=1e-11)
+    ve3 = np.mean([model.likelihood.variational_expectations_mean(Fm[-1].cpu().numpy()[s_:s_ + 1], Fv[-1].cpu().numpy()[s_:s_ + 1], Y).sum()
+                   for s_ in (0, 7, 19)])
+    assert_allclose(acc / 3.0, ve3, rtol=1e-10)
+    # (iii) num_data enters only through the linear data scale (dgp.py:96-98)
+    o1 = eng.elbo(X, Y, S, zs=zs, data_scale=1.0, kl_weight=1.0)
+    o2 = eng.elbo(X, Y, S, zs=zs, data_scale=3.0, kl_weight=1.0)
+    assert_allclose(o2[1], 3.0 * o1[1], rtol=1e-13)
+    assert_allclose(o2[0], 3.0 * o1[1] - o1[2], rtol=1e-12)
