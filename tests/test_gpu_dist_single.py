@@ -1,0 +1,50 @@
+"""Exercises the data-parallel code path (distributed.attach -> flat all-reduce over RCCL on the shared stream) on the single
+GPU of the test box with a 1-rank NCCL process group: same numbers as the non-distributed step, no hang, fp64 all-reduce OK.
+(The world_size-2 arithmetic of the sharding is covered on CPU by tests/test_distributed_cpu.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from tests.helpers import kern_spec, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_attach_allreduce_single_rank_nccl():
+    import torch
+    import torch.distributed as dist
+    from doubly_stochastic_dgp.distributed import attach
+    from doubly_stochastic_dgp.engine import Context
+    Context.get()                                   # installs the shared stream before the process group is created
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        rng = np.random.RandomState(0)
+        N, D, M, S = 200, 4, 32, 3
+        X, Y = rng.randn(N, D), rng.randn(N, 1)
+        Z = X[:M].copy()
+        zs = [rng.randn(S, N, D), rng.randn(S, N, 1)]
+        _, _, ref = make_case(X, Y, Z, [kern_spec("rbf", D)] * 2, S=S, num_data=1000)
+        _, _, dp = make_case(X, Y, Z, [kern_spec("rbf", D)] * 2, S=S, num_data=1000)
+        attach(dp, 0, 1)
+        e_ref = ref._build_likelihood(X, Y, zs=zs, with_grad=True)
+        e_dp = dp._build_likelihood(X, Y, zs=zs, with_grad=True)
+        assert_allclose(e_dp, e_ref, rtol=1e-13)
+        assert np.array_equal(dp.engine().grad.cpu().numpy(), ref.engine().grad.cpu().numpy())
+        for _ in range(3):
+            ref.train_step(0.01, X=X, Y=Y, zs=zs)
+            dp.train_step(0.01, X=X, Y=Y, zs=zs)
+        assert_allclose(dp.layers[0].q_mu.value, ref.layers[0].q_mu.value, rtol=1e-12, atol=1e-14)
+        t = torch.ones(4, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        dist.barrier()
+        assert float(t.sum().item()) == 4.0
+    finally:
+        dist.destroy_process_group()

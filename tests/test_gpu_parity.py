@@ -555,3 +555,34 @@ def test_full_size_cfg3_properties():
     o2 = eng.elbo(X, Y, S, zs=zs, data_scale=3.0, kl_weight=1.0)
     assert_allclose(o2[1], 3.0 * o1[1], rtol=1e-13)
     assert_allclose(o2[0], 3.0 * o1[1] - o1[2], rtol=1e-12)
+
+
+# ---------------------------------------------------------------- reference edge cases
+def test_step_up_single_point():
+    # tests/test_dgp.py:176-183 TestStepUp: 1 x 1 data, kernels RBF(1) -> RBF(2): [I | 0] Linear mean, M = 1
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian
+    X = np.zeros((1, 1))
+    model = DGP(X, X, X, [RBF(1), RBF(2)], Gaussian())
+    assert model.layers[0].mean_function.kind == "linear" and model.layers[0].num_outputs == 2
+    zs = [np.array([[[0.3, -0.2]]]), np.zeros((1, 1, 1))]
+    got = model.compute_log_likelihood(X, X, zs=zs)
+    specs = [kern_spec("rbf", 1), kern_spec("rbf", 2)]
+    lds = O.init_layers_linear(X, X, X, specs)
+    sl, state = OM.state_from_layers(lds, lik_variance=1.0)
+    spec = dict(jitter=1e-6, white=False, likelihood="gaussian", layers=sl)
+    assert_allclose(got, OM.elbo(spec, state, X, X, zs, 1), rtol=1e-9)
+    assert np.isfinite(model.compute_log_likelihood())          # stochastic path with device-generated z
+
+
+def test_generation2_chain_kernels_still_agree():
+    # the LDS-panel chain kernels (DSDGP_CHAIN_SM=0, layer.hip) are kept as an alternative path: run a parity subset on them
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DSDGP_CHAIN_SM="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "layer_conditional or propagate_three or gradients_three or gradients_white or elbo_value"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
