@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
     t = t % tiles;
   }
   const int m0 = (t / P.tiles_n) * GT, n0 = (t % P.tiles_n) * GT;
+  if (P.lower_only && n0 > m0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int wr = wave >> 1, wc = wave & 1;
@@ -323,8 +324,14 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     if (lane == 0) s_red[wave] = s;
     __syncthreads();
     if (tid == 0) {
-      it.scal[0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      it.scal[1] = (double)s_info;
+      const double ldv = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      if (it.pad & 16) {          // block of a larger matrix: accumulate (launches of one matrix are sequential)
+        it.scal[0] += ldv;
+        if (s_info && it.scal[1] == 0.0) it.scal[1] = (double)(s_info + it.info_offset);
+      } else {
+        it.scal[0] = ldv;
+        it.scal[1] = (double)s_info;
+      }
     }
   }
   // write the factor back (LDS variant) with a zeroed strict upper triangle — unless the caller never reads it
@@ -464,7 +471,7 @@ __global__ void k_unpad(const double* __restrict__ P, int np, double* __restrict
 
 extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t lda, int64_t stride, int* info) {
   DS_CHECK_ARG(ctx && A && batch > 0 && n > 0 && lda >= n);
-  const int np = (int)round_up(n, 16);
+  const int np = n > 496 ? (int)round_up(n, 64) : (int)round_up(n, 16);
   const size_t mat_bytes = (size_t)batch * np * np * sizeof(double);
   const size_t item_bytes = round_up(batch * sizeof(PotrfItem), 256);
   const size_t scal_bytes = round_up((size_t)batch * 2 * sizeof(double), 256);
@@ -475,12 +482,22 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   double* scal_d = (double*)((char*)scr + mat_bytes + item_bytes);
   std::vector<PotrfItem> items(batch);
   for (int b = 0; b < batch; ++b) {
-    items[b] = PotrfItem{P + (size_t)b * np * np, nullptr, nullptr, scal_d + 2 * b, np, np, n, 0};
+    items[b] = PotrfItem{P + (size_t)b * np * np, nullptr, nullptr, scal_d + 2 * b, np, np, n, 0, 0, 0};
   }
   DS_HIP(hipMemcpyAsync(items_d, items.data(), batch * sizeof(PotrfItem), hipMemcpyHostToDevice, ctx->stream));
   DS_HIP(hipStreamSynchronize(ctx->stream));  // items vector is stack-lifetime
   hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
-  DS_TRY(potrf_launch(ctx, items_d, batch, np));
+  if (np >= 512 && np % 64 == 0) {
+    // large matrices: multi-workgroup blocked path (temporary plan; the model path pre-builds its plans)
+    BigChol plan;
+    int rc = bigchol_build(ctx, plan, P, nullptr, nullptr, scal_d, batch, (int64_t)np * np, 2, np, n, nullptr, false);
+    if (rc == DSDGP_OK) rc = bigchol_run(ctx, plan);
+    hipStreamSynchronize(ctx->stream);
+    bigchol_free(plan);
+    DS_TRY(rc);
+  } else {
+    DS_TRY(potrf_launch(ctx, items_d, batch, np));
+  }
   hipLaunchKernelGGL(k_unpad, dim3(ceil_div(n * n, 256), batch), dim3(256), 0, ctx->stream, P, np, A, lda, stride, n);
   DS_HIP(hipGetLastError());
   if (info) {
@@ -617,6 +634,172 @@ extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const 
 
 int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch) {
   hipLaunchKernelGGL(k_trtri_only, dim3(batch), dim3(256), 0, ctx->stream, W, Linv, n, stride);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// multi-workgroup blocked Cholesky / triangular inverse (see linalg.hpp)
+// ------------------------------------------------------------------------------------------------------
+// zero the 64x64 blocks strictly above the block diagonal (the blocked factorisation only maintains the lower blocks)
+__global__ void k_zero_upper_blocks(double* __restrict__ W, int n, int64_t stride) {
+  double* Wb = W + (int64_t)blockIdx.y * stride;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    if ((j >> 6) > (i >> 6)) Wb[idx] = 0.0;
+  }
+}
+__global__ void k_transpose_lower(const double* __restrict__ X, double* __restrict__ XT, int n, int64_t stride) {
+  const double* Xb = X + (int64_t)blockIdx.y * stride;
+  double* Tb = XT + (int64_t)blockIdx.y * stride;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    Tb[idx] = (j >= i) ? Xb[(int64_t)j * n + i] : 0.0;      // XT[i][j] = X[j][i], zero below the diagonal
+  }
+}
+// inverse of the 64x64 lower-triangular diagonal blocks of already-triangular matrices (from_tri mode), one WG per block
+__global__ __launch_bounds__(256) void k_trtri_diag64(const PotrfItem* __restrict__ items) {
+  __shared__ double Lb[64 * 65];
+  __shared__ double Xb[64 * 65];
+  const PotrfItem it = items[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    Lb[i * 65 + j] = (j <= i) ? it.W[(int64_t)i * it.ld + j] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 64) {   // column tid of X by forward substitution
+    const int col = tid;
+    for (int i = 0; i < 64; ++i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = col; k < i; ++k) s -= Lb[i * 65 + k] * Xb[k * 65 + col];
+      Xb[i * 65 + col] = (i >= col) ? s / Lb[i * 65 + i] : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    it.Linv[(int64_t)i * it.ld + j] = Xb[i * 65 + j];
+  }
+}
+
+int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* LinvT, double* scal, int batch, int64_t stride,
+                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri) {
+  DS_CHECK_ARG(n % 64 == 0 && n >= 128 && batch >= 1);
+  P.n = n; P.batch = batch; P.nb = n / 64;
+  P.W = W; P.Linv = Linv; P.LinvT = LinvT; P.scal = scal; P.Tbuf = Tbuf;
+  P.stride = stride; P.scal_stride = scal_stride;
+  P.want_inverse = Linv != nullptr;
+  P.from_tri = from_tri;
+  const int nb = P.nb;
+  // plan-owned scratch (64 x n per matrix) unless the caller supplies one
+  const size_t tb = Tbuf ? 0 : (size_t)batch * 64 * n * sizeof(double);
+  void* tblock = nullptr;
+  if (tb) {
+    DS_HIP(hipMalloc(&tblock, tb));
+    DS_HIP(hipMemset(tblock, 0, tb));
+    Tbuf = (double*)tblock;
+    P.Tbuf = Tbuf;
+  }
+  P.tbuf_block = tblock;
+  std::vector<PotrfItem> items((size_t)nb * batch);
+  for (int p = 0; p < nb; ++p)
+    for (int b = 0; b < batch; ++b) {
+      const int64_t off = (int64_t)b * stride + (int64_t)p * 64 * n + p * 64;
+      int nr = nreal - p * 64;
+      nr = nr < 0 ? 0 : (nr > 64 ? 64 : nr);
+      // without a requested inverse the 64x64 diagonal inverses (needed by the panel solve) live in Tbuf
+      double* dinv = Linv ? Linv + off : Tbuf + (int64_t)b * 64 * n + p * 64;
+      items[(size_t)p * batch + b] = PotrfItem{W + off, dinv, nullptr, scal ? scal + b * scal_stride : nullptr,
+                                               64, n, nr, 16, p * 64, 0};
+    }
+  std::vector<GemmProblem> gp;
+  P.tiles.clear();
+  auto add = [&](GemmProblem& g) {
+    P.tiles.push_back(gemm_plan(&g, 1));
+    g.tile_start = 0;
+    gp.push_back(g);
+  };
+  auto mk = [&](const double* A, const double* B, double* C, int m, int nn, int k, int tA, int tB, double alpha, double beta, int lower) {
+    GemmProblem g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.m = m; g.n = nn; g.k = k;
+    g.lda = n; g.ldb = n; g.ldc = n;
+    g.transA = tA; g.transB = tB; g.batch = batch; g.sA = stride; g.sB = stride; g.sC = stride; g.batch_reduce = 0;
+    g.alpha = alpha; g.beta = beta; g.lower_only = lower;
+    return g;
+  };
+  if (!from_tri) {
+    for (int p = 0; p + 1 < nb; ++p) {
+      const int rem = n - (p + 1) * 64;
+      double* panel = W + (int64_t)(p + 1) * 64 * n + p * 64;
+      // L_ip = A_ip * L_pp^{-T}   (in place: one 64-wide output tile per row block)
+      GemmProblem g1 = mk(panel, Linv ? Linv + (int64_t)p * 64 * n + p * 64 : Tbuf + p * 64, panel, rem, 64, 64, 0, 1, 1.0, 0.0, 0);
+      if (!Linv) g1.sB = (int64_t)64 * n;
+      add(g1);
+      // A_ij -= L_ip L_jp^T  (lower tiles only)
+      GemmProblem g2 = mk(panel, panel, W + (int64_t)(p + 1) * 64 * n + (p + 1) * 64, rem, rem, 64, 0, 1, -1.0, 1.0, 1);
+      add(g2);
+    }
+  }
+  if (P.want_inverse) {
+    for (int i = 1; i < nb; ++i) {
+      // T = L[i, 0:i] * X[0:i, 0:i]  ;  X[i, 0:i] = -X_ii * T
+      GemmProblem g1 = mk(W + (int64_t)i * 64 * n, Linv, Tbuf, 64, i * 64, i * 64, 0, 0, 1.0, 0.0, 0);
+      g1.ldc = n; g1.sC = (int64_t)64 * n;
+      add(g1);
+      GemmProblem g2 = mk(Linv + (int64_t)i * 64 * n + i * 64, Tbuf, Linv + (int64_t)i * 64 * n, 64, i * 64, 64, 0, 0, -1.0, 0.0, 0);
+      g2.ldb = n; g2.sB = (int64_t)64 * n;
+      add(g2);
+    }
+  }
+  const size_t ib = round_up(items.size() * sizeof(PotrfItem), 256), gb = round_up(gp.size() * sizeof(GemmProblem) + 256, 256);
+  DS_HIP(hipMalloc(&P.dev_block, ib + gb));
+  P.diag_items = (PotrfItem*)P.dev_block;
+  P.gp = (GemmProblem*)((char*)P.dev_block + ib);
+  DS_HIP(hipMemcpy(P.diag_items, items.data(), items.size() * sizeof(PotrfItem), hipMemcpyHostToDevice));
+  if (!gp.empty()) DS_HIP(hipMemcpy(P.gp, gp.data(), gp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+  return DSDGP_OK;
+}
+
+void bigchol_free(BigChol& P) {
+  if (P.dev_block) hipFree(P.dev_block);
+  if (P.tbuf_block) hipFree(P.tbuf_block);
+  P.dev_block = nullptr;
+  P.tbuf_block = nullptr;
+}
+
+int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
+  ProfScope ps(ctx, "potrf");
+  const int nb = P.nb, batch = P.batch;
+  int gi = 0;
+  if (!P.from_tri) {
+    if (P.scal)
+      for (int b = 0; b < batch; ++b) DS_HIP(hipMemsetAsync(P.scal + b * P.scal_stride, 0, 2 * sizeof(double), ctx->stream));
+    const size_t lds = (16 * 17 + 8 + (size_t)4 * 16 * 17 + (size_t)64 * 68) * sizeof(double);
+    for (int p = 0; p < nb; ++p) {
+      hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(batch), dim3(256), lds, ctx->stream, P.diag_items + (size_t)p * batch, 4);
+      if (p + 1 < nb) {
+        hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
+        ++gi;
+        hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
+        ++gi;
+      }
+    }
+    hipLaunchKernelGGL(k_zero_upper_blocks, dim3(256, batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride);
+  } else if (P.want_inverse) {
+    hipLaunchKernelGGL(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
+  }
+  if (P.want_inverse) {
+    for (int i = 1; i < nb; ++i) {
+      hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
+      ++gi;
+      hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
+      ++gi;
+    }
+    if (P.LinvT)
+      hipLaunchKernelGGL(k_transpose_lower, dim3(256, batch), dim3(256), 0, ctx->stream, P.Linv, P.LinvT, P.n, P.stride);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

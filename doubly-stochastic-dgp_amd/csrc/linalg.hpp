@@ -14,6 +14,7 @@ struct GemmProblem {
   int32_t batch, batch_reduce;
   int32_t tiles_m, tiles_n, tile_start;
   double alpha, beta;
+  int32_t lower_only, pad;   // lower_only: skip 64x64 tiles strictly above the diagonal (syrk-style updates)
 };
 
 // One matrix of a batched factorisation launch (n multiple of 16; rows/cols >= nreal carry an identity pad).
@@ -22,7 +23,8 @@ struct PotrfItem {
   double* Linv;   // out: W^-1 (lower), may alias nothing else; may be NULL (skip inverse)
   double* LinvT;  // out: transpose of Linv (may be NULL)
   double* scal;   // out: [0] = sum_i<nreal 2 log L_ii (= logdet), [1] = info (0 ok, else 1-based bad pivot)
-  int32_t n, ld, nreal, pad;
+  int32_t n, ld, nreal, pad;   // pad bits: 8 = skip factor write-back, 16 = accumulate into scal (blocked driver), 7 = timing
+  int32_t info_offset, pad2;   // added to a failing pivot index (position of this block inside a larger matrix)
 };
 
 // Fills tile_start/tiles_* of `host` problems, returns the total number of 64x64 tiles.
@@ -33,3 +35,25 @@ int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_til
 int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max);
 // batched inverse of padded lower-triangular matrices (n multiple of 16, identity pad), one workgroup each
 int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch);
+
+// ---- multi-workgroup blocked Cholesky + triangular inverse for large matrices (n >= 512, multiple of 64) ----
+// Right-looking with NB = 64: diagonal blocks by k_potrf_trtri (LDS variant), panel solve and trailing syrk as grouped
+// MFMA GEMM launches over all 64x64 tiles, inverse by the blocked recurrence X_i,: = -X_ii (L_i,: X) (two GEMMs per block
+// row).  All descriptors are built once (static pointers) so a run is a fixed, fully asynchronous launch sequence.
+struct BigChol {
+  int n = 0, batch = 0, nb = 0;
+  bool want_inverse = false, from_tri = false;   // from_tri: input is already a lower-triangular factor (inverse only)
+  double* W = nullptr; double* Linv = nullptr; double* LinvT = nullptr; double* scal = nullptr; double* Tbuf = nullptr;
+  int64_t stride = 0, scal_stride = 0;
+  PotrfItem* diag_items = nullptr;     // device: nb * batch
+  GemmProblem* gp = nullptr;           // device: per panel {solve, trailing}, then per block row {T, X}
+  std::vector<int> tiles;              // tile counts, same order as gp
+  void* dev_block = nullptr;
+  void* tbuf_block = nullptr;         // plan-owned Tbuf (when the caller passed none)
+};
+// W/Linv/LinvT: `batch` matrices of order n (leading dimension n) `stride` doubles apart; scal: 2 doubles per matrix
+// (`scal_stride` apart); Tbuf: batch * 64 * n doubles of scratch (needed when want_inverse).
+int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* LinvT, double* scal, int batch, int64_t stride,
+                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri);
+int bigchol_run(dsdgp_ctx* ctx, const BigChol& P);
+void bigchol_free(BigChol& P);

@@ -49,6 +49,8 @@ struct LayerState {
   double *A, *E, *GW, *VB, *MB, *XT1;
   double *F, *mean, *var, *zbuf, *dF;
   double *part_big, *part_thin, *hyp_part;
+  bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
+  BigChol big_k, big_ngA, big_ngS, big_ngT;
   GemmProblem* ng_gp;  // device: 5 natural-gradient GEMM problems (H, Sinv | Y | X | Splus)
   PotrfItem* ng_items; // device: 2 * D_out factorisation items (A_d, then Splus_d)
   int ng_t1, ng_t2, ng_t3, ng_t4;
@@ -745,7 +747,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     const LayerDev& v = m->L[l].dev;
     ld[l] = v;
     items[l] = PotrfItem{v.Kp, v.Linv, v.LinvT, v.scal, v.Mp, v.Mp, v.M,
-                         getenv("DSDGP_POTRF_TIMING") ? 7 : (desc->white ? 0 : 8) /* Lu itself is only read by the white adjoint */};
+                         getenv("DSDGP_POTRF_TIMING") ? 7 : (desc->white ? 0 : 8) /* Lu itself is only read by the white adjoint */, 0, 0};
     const int Mp = v.Mp;
     const int64_t MM = (int64_t)Mp * Mp;
     GemmProblem P;
@@ -789,11 +791,18 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       DS_HIP(hipMemcpyAsync(St.ng_gp, ng, sizeof(ng), hipMemcpyHostToDevice, st));
       std::vector<PotrfItem> it(2 * v.D_out);
       for (int d = 0; d < v.D_out; ++d) {
-        it[d] = PotrfItem{v.ngA + d * MM, v.ngLAinv + d * MM, v.ngLAinvT + d * MM, v.ngScal + 2 * d, Mp, Mp, v.M, 0};
-        it[v.D_out + d] = PotrfItem{v.ngSplus + d * MM, nullptr, nullptr, v.ngScal + 2 * v.D_out + 2 * d, Mp, Mp, v.M, 0};
+        it[d] = PotrfItem{v.ngA + d * MM, v.ngLAinv + d * MM, v.ngLAinvT + d * MM, v.ngScal + 2 * d, Mp, Mp, v.M, 0, 0, 0};
+        it[v.D_out + d] = PotrfItem{v.ngSplus + d * MM, nullptr, nullptr, v.ngScal + 2 * v.D_out + 2 * d, Mp, Mp, v.M, 0, 0, 0};
       }
       DS_HIP(hipMemcpyAsync(St.ng_items, it.data(), it.size() * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
       DS_HIP(hipStreamSynchronize(st));
+      St.big = Mp >= 512;
+      if (St.big) {
+        DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
+        DS_TRY(bigchol_build(ctx, St.big_ngA, v.ngA, v.ngLAinv, v.ngLAinvT, v.ngScal, v.D_out, MM, 2, Mp, v.M, nullptr, false));
+        DS_TRY(bigchol_build(ctx, St.big_ngS, v.ngSplus, nullptr, nullptr, v.ngScal + 2 * v.D_out, v.D_out, MM, 2, Mp, v.M, nullptr, false));
+        DS_TRY(bigchol_build(ctx, St.big_ngT, v.ngTI, v.ngTinv, nullptr, nullptr, v.D_out, MM, 0, Mp, v.M, nullptr, true));
+      }
     }
   }
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
@@ -844,6 +853,9 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     for (int l = 0; l < m->desc.L; ++l) hipEventDestroy(m->ev_bwd[l]);
     hipEventDestroy(m->ev_side);
     hipStreamDestroy(m->side);
+    for (int l = 0; l < m->desc.L; ++l) {
+      bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngS); bigchol_free(m->L[l].big_ngT);
+    }
     delete m;
   }
   return DSDGP_OK;
@@ -858,7 +870,14 @@ static int prepare_async(dsdgp_model* m) {
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
-  DS_TRY(potrf_launch(ctx, m->potrf_items, L, mp_max));
+  if (mp_max >= 512) {
+    for (int l = 0; l < L; ++l) {
+      if (m->L[l].big) DS_TRY(bigchol_run(ctx, m->L[l].big_k));
+      else DS_TRY(potrf_launch(ctx, m->potrf_items + l, 1, m->L[l].dev.Mp));
+    }
+  } else {
+    DS_TRY(potrf_launch(ctx, m->potrf_items, L, mp_max));
+  }
   DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd));
   hipLaunchKernelGGL(k_kl_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
   hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, ctx->stream, m->layers_dev, L);
@@ -1274,7 +1293,8 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   if (!m->prepared) DS_TRY(prepare_async(m));
   hipLaunchKernelGGL(k_ng_prep, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad);
   DS_HIP(hipGetLastError());
-  DS_TRY(trtri_launch(ctx, v.ngTI, v.ngTinv, v.Mp, MM, v.D_out));
+  if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngT));
+  else DS_TRY(trtri_launch(ctx, v.ngTI, v.ngTinv, v.Mp, MM, v.D_out));
   DS_TRY(gemm_launch(ctx, St.ng_gp, 2, St.ng_t1));
   hipLaunchKernelGGL(k_ng_phi, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l);
   DS_TRY(gemm_launch(ctx, St.ng_gp + 2, 1, St.ng_t2));
@@ -1283,11 +1303,13 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   hipLaunchKernelGGL(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
                      gamma);
   DS_HIP(hipGetLastError());
-  DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
+  if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngA));
+  else DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
   DS_TRY(gemm_launch(ctx, St.ng_gp + 4, 1, St.ng_t4));
   hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
-  DS_TRY(potrf_launch(ctx, St.ng_items + v.D_out, v.D_out, v.Mp));
+  if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngS));
+  else DS_TRY(potrf_launch(ctx, St.ng_items + v.D_out, v.D_out, v.Mp));
   hipLaunchKernelGGL(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
   m->prepared = false;

@@ -48,7 +48,7 @@ def test_gemm(ctx, tA, tB, m, n, k):
     assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
 
 
-@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256])
+@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256, 300, 512, 600, 1024])
 def test_potrf(ctx, n):
     from doubly_stochastic_dgp import _lib
     rng = np.random.RandomState(n)
@@ -497,6 +497,43 @@ def test_cfg5_shape_M1024():
     NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
     assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
     assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+
+
+def test_large_M_white_multiworkgroup_cholesky():
+    # M = 520 (padded 1024) with white=True: the multi-workgroup blocked Cholesky/inverse path, the white-adjoint GEMMs that
+    # read Lu densely (its upper blocks must be exact zeros), and a batched (D_out = 3) natural-gradient step on top
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(43)
+    N, D, M, S = 24, 3, 520, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 3)
+    Z = rng.randn(M, D) * 2.0
+    specs = [kern_spec("rbf", D, 1.0, 1.0), kern_spec("matern52", D, 1.3, 0.9)]
+    spec, state, model = make_case(X, Y, Z, specs, white=True, S=S, num_data=500)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 3)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=500)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-8)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-6, (k, err)
+    mu, sq = O.natgrad_step(state["l1.q_mu"], state["l1.q_sqrt"], -g["l1.q_mu"], -g["l1.q_sqrt"], 0.1)
+    last = model.layers[-1]
+    NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
+    assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+
+
+def test_potrf_large_not_spd(ctx):
+    from doubly_stochastic_dgp import _lib
+    n = 640
+    A = np.eye(n)
+    A[300, 300] = -1.0
+    dA = _dev(ctx, A)
+    info = C.c_int(0)
+    ctx.torch.cuda.current_stream().synchronize()
+    rc = ctx.lib.dsdgp_potrf(ctx.handle, 1, n, _p(dA), n, n * n, C.byref(info))
+    assert rc == _lib.ERR_NOT_SPD and info.value == 301
 
 
 # ---------------------------------------------------------------- full BASELINE.json sizes
