@@ -23,12 +23,14 @@ struct LayerDev {
   double *V, *nL, *Sd, *klv;
   double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
   double *bigred, *thinq, *thinz, *hyp_red;
+  double *R2, *Zp1, *WZ;       // scaled squared distances of Z (Mp x Mp); [Z | 1] and wm [Z | 1] (Mp x DinP16, D_in > 32 only)
   double *klpart, *hyp2part;   // [NPART] KL partial sums ; [NPART][D_in + 2] Ku-side hyper-parameter partials
   double *wLbar, *wH, *wY, *wX;  // white=True: Cholesky-adjoint temporaries (Mp x Mp each)
   // natural-gradient temporaries, (D_out x Mp x Mp) each unless noted
   double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngSplus, *ngTheta1 /* D_out x Mp */, *ngScal /* 4 x D_out */;
 };
 #define NPART 32
+#define WIDE_DIN 32   // layers with D_in above this take the GEMM form of the Ku-side Z / lengthscale adjoints
 
 struct RedJob {
   const double* part;
@@ -82,6 +84,8 @@ struct dsdgp_model {
   PotrfItem* potrf_items;
   GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2, *gp_w1, *gp_w2, *gp_w3;
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
+  GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
+  int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
   RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
   int rjobs_cap, n_red, red_blocks;
   int64_t plan_n;
@@ -136,6 +140,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->gp_fwd = b.take<GemmProblem>(4 * D.L);
   m->gp_bwd1 = b.take<GemmProblem>(3 * D.L);
   m->gp_bwd2 = b.take<GemmProblem>(D.L);
+  m->gp_wz = b.take<GemmProblem>(D.L);
   m->gp_w1 = b.take<GemmProblem>(2 * D.L); m->gp_w2 = b.take<GemmProblem>(D.L); m->gp_w3 = b.take<GemmProblem>(D.L);
   m->rjobs_cap = 0;
   for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 4;
@@ -175,6 +180,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(64 * (d.D_in + 2));
+    v.R2 = b.take<double>(MM);
+    v.Zp1 = b.take<double>(Mp * v.DinP16); v.WZ = b.take<double>(Mp * v.DinP16);
     S.R_max = (int64_t)m->s_max * m->n_max;
     const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
     S.ld_max = round_up(Rin_max, 16);
@@ -221,18 +228,23 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
     }
     v.hyp[HYP_VAR] = var; v.hyp[HYP_WVAR] = wv; v.hyp[HYP_KDIAG] = var + wv;
     v.hyp[HYP_DVAR] = sigmoid_d(rv); v.hyp[HYP_DWVAR] = dwv;
-    for (int j = 0; j < v.D_in; ++j) {
-      const double rl = theta[v.off_kls + (v.ard ? j : 0)];
-      v.hyp[HYP_ILS + j] = 1.0 / (softplus_d(rl) + SOFTPLUS_LOWER);
-      v.hyp[HYP_ILS + v.D_in + j] = sigmoid_d(rl);
-    }
     if (blockIdx.y == 0 && lik_gauss) {
       const double rl = theta[off_lik];
       lik_const[0] = softplus_d(rl) + SOFTPLUS_LOWER;
       lik_const[1] = sigmoid_d(rl);
     }
   }
+  for (int j = tid0; j < v.D_in; j += nth) {
+    const double rl = theta[v.off_kls + (v.ard ? j : 0)];
+    v.hyp[HYP_ILS + j] = 1.0 / (softplus_d(rl) + SOFTPLUS_LOWER);
+    v.hyp[HYP_ILS + v.D_in + j] = sigmoid_d(rl);
+  }
   const int Mp = v.Mp, M = v.M;
+  if (v.D_in > WIDE_DIN)
+    for (int idx = tid0; idx < Mp * v.DinP16; idx += nth) {
+      const int i = idx / v.DinP16, q = idx % v.DinP16;
+      v.Zp1[idx] = (i < M) ? (q < v.D_in ? theta[v.off_Z + (int64_t)i * v.D_in + q] : (q == v.D_in ? 1.0 : 0.0)) : 0.0;
+    }
   for (int idx = tid0; idx < Mp * v.D_in; idx += nth) {
     const double z = (idx / v.D_in < M) ? theta[v.off_Z + idx] : 0.0;
     const double rl = theta[v.off_kls + (v.ard ? idx % v.D_in : 0)];
@@ -252,23 +264,40 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
 }
 
 // Ku = K(Z,Z) + (white + jitter) I   (layers.py:171), identity on the padding
-__global__ void k_kuu_pad(const LayerDev* __restrict__ layers, double jitter) {
+__global__ __launch_bounds__(256) void k_kuu_pad(const LayerDev* __restrict__ layers, double jitter) {
+  // 16 x 16 output tile per workgroup pass; the two 16-row panels of Z are staged through LDS in 32-column chunks so that
+  // wide inputs (784-d MNIST layer) read Z coalesced.  Also stores the scaled squared distances for the adjoint (k_asm_kbar).
+  __shared__ double Zi[16][33], Zj[16][33];
   const LayerDev v = layers[blockIdx.y];
-  const int Mp = v.Mp;
+  const int Mp = v.Mp, nt = Mp / 16, Din = v.D_in;
   const double* ils = v.hyp + HYP_ILS;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
-    const int i = idx / Mp, j = idx % Mp;
-    double k = (i == j) ? 1.0 : 0.0;
-    if (i < v.M && j < v.M) {
-      double r2 = 0.0;
-      for (int q = 0; q < v.D_in; ++q) {
-        const double df = (v.Zp[i * v.D_in + q] - v.Zp[j * v.D_in + q]) * ils[q];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  for (int tile = blockIdx.x; tile < nt * nt; tile += gridDim.x) {
+    const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
+    double r2 = 0.0;
+    for (int q0 = 0; q0 < Din; q0 += 32) {
+      __syncthreads();
+      for (int e = tid; e < 512; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const bool ok = q0 + c < Din;
+        Zi[r][c] = ok ? v.Zp[(int64_t)(i0 + r) * Din + q0 + c] : 0.0;
+        Zj[r][c] = ok ? v.Zp[(int64_t)(j0 + r) * Din + q0 + c] : 0.0;
+      }
+      __syncthreads();
+      const int qn = min(32, Din - q0);
+      for (int c = 0; c < qn; ++c) {
+        const double df = (Zi[ti][c] - Zj[tj][c]) * ils[q0 + c];
         r2 = fma(df, df, r2);
       }
+    }
+    const int i = i0 + ti, j = j0 + tj;
+    double k = (i == j) ? 1.0 : 0.0;
+    if (i < v.M && j < v.M) {
       k = kern_val_rt(v.kern_kind, r2, v.hyp[HYP_VAR]);
       if (i == j) k += v.hyp[HYP_WVAR] + jitter;
     }
-    v.Kp[idx] = k;
+    v.Kp[(int64_t)i * Mp + j] = k;
+    v.R2[(int64_t)i * Mp + j] = r2;
   }
 }
 
@@ -527,11 +556,7 @@ __global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
         kb = -0.5 * (G[i * Mp + j] + G[j * Mp + i]) +
              kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
       }
-      double r2 = 0.0;
-      for (int q = 0; q < v.D_in; ++q) {
-        const double df = (v.Zp[i * v.D_in + q] - v.Zp[j * v.D_in + q]) * ils[q];
-        r2 = fma(df, df, r2);
-      }
+      const double r2 = v.R2[idx];
       double k, dk;
       if (v.kern_kind == DSDGP_KERN_RBF)
         kern_val_grad<DSDGP_KERN_RBF>(r2, v.hyp[HYP_VAR], k, dk);
@@ -586,8 +611,17 @@ __global__ void k_asm_params(const LayerDev* __restrict__ layers, double* __rest
     const int i = (int)(idx / Dout), d = (int)(idx % Dout);
     grad[v.off_q_mu + idx] = v.thinq[i * v.DP16 + d] + kl_w * (v.white ? v.qmu4[i * v.DP4 + d] : v.n4[i * v.DP4 + d]);
   }
-  // Z: through Kuf (GW [X|1]) and through Ku (wm): one wavefront per (i, q), lanes stride over j
-  {
+  // Z: through Kuf (GW [X|1]) and through Ku (wm).  Wide inputs: sum_j wm_ij (z_iq - z_jq) = rowsum_i z_iq - (wm Z)_iq with
+  // WZ = wm [Z | 1] from the MFMA GEMM; otherwise one wavefront per (i, q), lanes stride over j
+  if (Din > WIDE_DIN) {
+    for (int64_t idx = t0; idx < (int64_t)M * Din; idx += nth) {
+      const int i = (int)(idx / Din), q = (int)(idx % Din);
+      const double zi = v.Zp[idx];
+      const double s = v.WZ[(int64_t)i * v.DinP16 + Din] * zi - v.WZ[(int64_t)i * v.DinP16 + q];
+      const double il2 = ils[q] * ils[q];
+      grad[v.off_Z + idx] = 4.0 * il2 * s - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
+    }
+  } else {
     const int lane = threadIdx.x & 63;
     const int64_t w0 = t0 >> 6, nw = nth >> 6;
     for (int64_t idx = w0; idx < (int64_t)M * Din; idx += nw) {
@@ -623,6 +657,18 @@ __global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict
     out[0] = a;
     out[1] = tr;
   }
+  if (Din > WIDE_DIN) {
+    // sum_ij wm_ij (z_iq - z_jq)^2 = 2 sum_i z_iq (rowsum_i z_iq - (wm Z)_iq)   (wm symmetric); rows i = b mod NPART
+    for (int q = threadIdx.x; q < Din; q += 256) {
+      double s = 0.0;
+      for (int i = blockIdx.x; i < M; i += NPART) {
+        const double zi = v.Zp[(int64_t)i * Din + q];
+        s = fma(2.0 * zi, v.WZ[(int64_t)i * v.DinP16 + Din] * zi - v.WZ[(int64_t)i * v.DinP16 + q], s);
+      }
+      out[2 + q] = s;
+    }
+    return;
+  }
   for (int q = 0; q < Din; ++q) {
     double s = 0.0;
     for (int idx = t0; idx < M * M; idx += nth) {
@@ -634,20 +680,22 @@ __global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict
     if (threadIdx.x == 0) out[2 + q] = s;
   }
 }
-__global__ void k_asm_hyp_final(const LayerDev* __restrict__ layers, double* __restrict__ grad) {
+__global__ __launch_bounds__(256) void k_asm_hyp_final(const LayerDev* __restrict__ layers, double* __restrict__ grad) {
+  __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.x];
   const int Din = v.D_in;
   const double* ils = v.hyp + HYP_ILS;
-  if (threadIdx.x != 0) return;
-  double a = 0.0, tr = 0.0;
-  for (int b = 0; b < NPART; ++b) {
-    a += v.hyp2part[b * (Din + 2)];
-    tr += v.hyp2part[b * (Din + 2) + 1];
+  if (threadIdx.x == 0) {
+    double a = 0.0, tr = 0.0;
+    for (int b = 0; b < NPART; ++b) {
+      a += v.hyp2part[b * (Din + 2)];
+      tr += v.hyp2part[b * (Din + 2) + 1];
+    }
+    grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
+    if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
   }
-  grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
-  if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
   double iso = 0.0;
-  for (int q = 0; q < Din; ++q) {
+  for (int q = threadIdx.x; q < Din; q += 256) {
     double s = 0.0;
     for (int b = 0; b < NPART; ++b) s += v.hyp2part[b * (Din + 2) + 2 + q];
     const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
@@ -656,9 +704,9 @@ __global__ void k_asm_hyp_final(const LayerDev* __restrict__ layers, double* __r
     else
       iso += gl;
   }
-  if (!v.ard) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
+  iso = block_sum_256(iso, sh);
+  if (!v.ard && threadIdx.x == 0) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
 }
-
 __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
                        double* __restrict__ v, const double* __restrict__ mask, int64_t n, double lr_t, double b1,
                        double b2, double eps) {
@@ -742,7 +790,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   const int L = desc->L;
   std::vector<LayerDev> ld(L);
   std::vector<PotrfItem> items(L);
-  std::vector<GemmProblem> gf, g1, g2, w1, w2, w3;
+  std::vector<GemmProblem> gf, g1, g2, w1, w2, w3, wz;
+  int64_t asm_elems = 0;
   for (int l = 0; l < L; ++l) {
     const LayerDev& v = m->L[l].dev;
     ld[l] = v;
@@ -767,6 +816,12 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     g1.push_back(P);
     fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);              // U_d U_d^T
     g2.push_back(P);
+    if (v.D_in > WIDE_DIN) {
+      fill_gemm(P, v.wm, v.Zp1, v.WZ, Mp, v.DinP16, Mp, Mp, v.DinP16, v.DinP16, 0, 0, 1, 0, 0, 0, 0);  // wm [Z | 1]
+      wz.push_back(P);
+    }
+    m->kuu_blocks = std::max(m->kuu_blocks, std::min(1024, (Mp / 16) * (Mp / 16)));
+    asm_elems = std::max<int64_t>(asm_elems, (int64_t)v.D_out * v.M * v.M);
     // white=True: d l/d Ku from d l/d Lu = -tril(G) through the Cholesky adjoint  Ku_bar = sym(Lu^-T Phi(Lu^T Lu_bar) Lu^-1)
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
     w1.push_back(P);
@@ -808,6 +863,12 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
   m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
   m->n_bwd2 = (int)g2.size(); m->t_bwd2 = gemm_plan(g2.data(), m->n_bwd2);
+  m->n_wz = (int)wz.size();
+  if (m->n_wz) {
+    m->t_wz = gemm_plan(wz.data(), m->n_wz);
+    DS_HIP(hipMemcpyAsync(m->gp_wz, wz.data(), wz.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+  }
+  m->asm_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, asm_elems / 1024));
   m->n_w = L;
   m->t_w1 = gemm_plan(w1.data(), 2 * L); m->t_w2 = gemm_plan(w2.data(), L); m->t_w3 = gemm_plan(w3.data(), L);
   DS_HIP(hipMemcpyAsync(m->gp_w1, w1.data(), w1.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
@@ -866,7 +927,7 @@ static int prepare_async(dsdgp_model* m) {
   const int L = m->desc.L;
   hipLaunchKernelGGL(k_prep, dim3(64, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev, m->lik_const,
                      m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0);
-  hipLaunchKernelGGL(k_kuu_pad, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
+  hipLaunchKernelGGL(k_kuu_pad, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
@@ -1101,10 +1162,11 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1));
     DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2));
   }
-  hipLaunchKernelGGL(k_asm_kbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
-  hipLaunchKernelGGL(k_asm_params, dim3(64, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
+  hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
+  if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
+  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
   hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
-  hipLaunchKernelGGL(k_asm_hyp_final, dim3(L), dim3(64), 0, ctx->stream, m->layers_dev, m->grad);
+  hipLaunchKernelGGL(k_asm_hyp_final, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
