@@ -38,5 +38,6 @@ void run(int waves_per_simd) {
 }
 int main() {
   run<1>(1); run<2>(1); run<4>(1); run<8>(1); run<4>(2); run<8>(2);
+  run<4>(3); run<4>(4); run<2>(4); run<8>(4); run<1>(8); run<2>(8); run<4>(8);
   return 0;
 }
