@@ -22,7 +22,7 @@ extern "C" int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols
 // mode 0: mean_s variational expectation ; mode 1: logsumexp_s predictive log density - log S
 __global__ void k_gauss_over_samples(const double* __restrict__ mean, const double* __restrict__ var,
                                      const double* __restrict__ Y, int64_t n, int S, int DY, double s2, int mode,
-                                     double* __restrict__ out) {
+                                     const double* __restrict__ sw, double* __restrict__ out) {
   const int64_t total = n * DY;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const double y = Y[i];
@@ -30,9 +30,10 @@ __global__ void k_gauss_over_samples(const double* __restrict__ mean, const doub
       double acc = 0.0;
       for (int s = 0; s < S; ++s) {
         const double mu = mean[(int64_t)s * total + i], v = var[(int64_t)s * total + i];
-        acc += -0.91893853320467274178 - 0.5 * log(s2) - 0.5 * ((y - mu) * (y - mu) + v) / s2;
+        const double ve = -0.91893853320467274178 - 0.5 * log(s2) - 0.5 * ((y - mu) * (y - mu) + v) / s2;
+        acc += sw ? sw[s] * ve : ve;
       }
-      out[i] = acc / S;
+      out[i] = sw ? acc : acc / S;      // quadrature weights (DGP_Quad.E_log_p_Y, dgp.py:160-166) or the MC mean (dgp.py:90)
     } else {
       double mx = -1.0 / 0.0;
       for (int s = 0; s < S; ++s) {
@@ -52,21 +53,21 @@ __global__ void k_gauss_over_samples(const double* __restrict__ mean, const doub
 }
 
 static int gauss_over_samples(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int S,
-                              int DY, double s2, int mode, double* out) {
+                              int DY, double s2, int mode, const double* sw, double* out) {
   DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && s2 > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
-  hipLaunchKernelGGL(k_gauss_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, s2, mode, out);
+  hipLaunchKernelGGL(k_gauss_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, s2, mode, sw, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
 
 extern "C" int dsdgp_gauss_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
-                                   int32_t S, int32_t DY, double lik_var, double* out) {
-  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 0, out);
+                                   int32_t S, int32_t DY, double lik_var, const double* sample_w, double* out) {
+  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 0, sample_w, out);
 }
 extern "C" int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y,
                                            int64_t n, int32_t S, int32_t DY, double lik_var, double* out) {
-  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 1, out);
+  return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 1, nullptr, out);
 }
 
 __global__ void k_add_scalar(const double* __restrict__ in, double v, int64_t count, double* __restrict__ out) {

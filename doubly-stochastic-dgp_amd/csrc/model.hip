@@ -84,6 +84,8 @@ struct dsdgp_model {
   PotrfItem* potrf_items;
   GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2, *gp_w1, *gp_w2, *gp_w3;
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
+  const double* sample_w = nullptr;   // DGP_Quad quadrature weights (borrowed), NULL = Monte-Carlo mean
+  int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
   RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
@@ -347,8 +349,8 @@ __global__ void k_kl_final(const LayerDev* __restrict__ layers, int L) {
 __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ mean, const double* __restrict__ var,
                                                    const double* __restrict__ Y, int64_t n, int S, int DY,
                                                    const double* __restrict__ lik_const, double w,
-                                                   double* __restrict__ part, double* __restrict__ dmean,
-                                                   double* __restrict__ dvar) {
+                                                   const double* __restrict__ sw, double* __restrict__ part,
+                                                   double* __restrict__ dmean, double* __restrict__ dvar) {
   __shared__ double sh[4];
   const double s2 = lik_const[0];
   const int64_t total = (int64_t)S * n * DY;
@@ -360,11 +362,12 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
     const double y = Y[(row % n) * DY + dd];
     const double mu = mean[idx], v = var[idx];
     const double q = (y - mu) * (y - mu) + v;
-    ve = -0.91893853320467274178 - 0.5 * log(s2) - 0.5 * q / s2;
-    dl = -0.5 / s2 + 0.5 * q / (s2 * s2);
+    const double f = sw ? sw[row / n] * S : 1.0;     // quadrature weight relative to the MC mean's 1/S (dgp.py:166)
+    ve = f * (-0.91893853320467274178 - 0.5 * log(s2) - 0.5 * q / s2);
+    dl = f * (-0.5 / s2 + 0.5 * q / (s2 * s2));
     if (dmean) {
-      dmean[idx] = -w * (y - mu) / s2;
-      dvar[idx] = 0.5 * w / s2;
+      dmean[idx] = -w * f * (y - mu) / s2;
+      dvar[idx] = 0.5 * w * f / s2;
     }
   }
   const double a = block_sum_256(ve, sh);
@@ -372,6 +375,20 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
   if (threadIdx.x == 0) {
     part[2 * blockIdx.x] = a;
     part[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// per-sample quadrature weights applied to per-row values (R = S*n rows) and the (R x K) adjoints (MultiClass + DGP_Quad)
+__global__ void k_scale_by_sample(const double* __restrict__ sw, int64_t n, int S, int K, int64_t R, double* __restrict__ ve,
+                                  double* __restrict__ dmean, double* __restrict__ dvar) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R * K; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / K;
+    const double f = sw[row / n] * S;
+    if (i % K == 0) ve[row] *= f;
+    if (dmean) {
+      dmean[i] *= f;
+      dvar[i] *= f;
+    }
   }
 }
 
@@ -1176,6 +1193,7 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
                                 double kl_weight, int with_grad, double* out) {
   DS_CHECK_ARG(m && X && Y && out);
   DS_CHECK_ARG(!zs || zstride);
+  DS_CHECK_ARG(!m->sample_w || S == m->sample_w_S);
   if (with_grad) {
     DS_CHECK_ARG(m->grad != nullptr);
   }
@@ -1190,13 +1208,18 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   const double w = data_scale / (double)S;
   if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN) {
     hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
-                       w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+                       w, m->sample_w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
   } else {
     // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
     DS_CHECK_ARG(DY == m->desc.num_classes);
     const int64_t R = (int64_t)S * n;
     DS_TRY(multiclass_launch(ctx, last.mean, last.var, Y, n, R, DY, 0, w, last.F, with_grad ? m->lik_dmean : nullptr,
                              with_grad ? m->lik_dvar : nullptr, -1));
+    if (m->sample_w) {
+      const int64_t cnt = R * DY;
+      hipLaunchKernelGGL(k_scale_by_sample, dim3((int)std::min<int64_t>(2048, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream,
+                         m->sample_w, n, S, DY, R, last.F, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+    }
     nblocks = ceil_div(R, 256);
     hipLaunchKernelGGL(k_partial_sum, dim3(nblocks), dim3(256), 0, ctx->stream, last.F, R, m->lik_part);
   }
@@ -1208,6 +1231,13 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
                      m->lik_const, m->grad, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, with_grad, out);
   DS_HIP(hipGetLastError());
   m->prepared = true;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_set_sample_weights(dsdgp_model* m, const double* w, int32_t S) {
+  DS_CHECK_ARG(m && (!w || (S > 0 && S <= m->s_max)));
+  m->sample_w = w;
+  m->sample_w_S = w ? S : 0;
   return DSDGP_OK;
 }
 

@@ -109,12 +109,13 @@ int multiclass_launch(dsdgp_ctx* ctx, const double* mean, const double* var, con
 }
 
 // out[i] (n x 1) = mean_s var_exp (mode 0) or logsumexp_s density - log S (mode 1), from per-(s,i) values tmp (S*n)
-__global__ void k_over_samples(const double* __restrict__ tmp, int64_t n, int S, int mode, double* __restrict__ out) {
+__global__ void k_over_samples(const double* __restrict__ tmp, int64_t n, int S, int mode, const double* __restrict__ sw,
+                               double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     if (mode == 0) {
       double a = 0.0;
-      for (int s = 0; s < S; ++s) a += tmp[(int64_t)s * n + i];
-      out[i] = a / S;
+      for (int s = 0; s < S; ++s) a += (sw ? sw[s] : 1.0) * tmp[(int64_t)s * n + i];
+      out[i] = sw ? a : a / S;
     } else {
       double mx = -1.0 / 0.0;
       for (int s = 0; s < S; ++s) mx = fmax(mx, tmp[(int64_t)s * n + i]);
@@ -126,12 +127,13 @@ __global__ void k_over_samples(const double* __restrict__ tmp, int64_t n, int S,
 }
 
 extern "C" int dsdgp_multiclass_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
-                                        int32_t S, int32_t K, int mode, double* out) {
+                                        int32_t S, int32_t K, int mode, const double* sample_w, double* out) {
   DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && (mode == 0 || mode == 1));
   void* scr;
   DS_TRY(ctx_scratch(ctx, (size_t)S * n * sizeof(double), &scr));
   DS_TRY(multiclass_launch(ctx, mean, var, Y, n, (int64_t)S * n, K, mode, 0.0, (double*)scr, nullptr, nullptr, -1));
-  hipLaunchKernelGGL(k_over_samples, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const double*)scr, n, S, mode, out);
+  hipLaunchKernelGGL(k_over_samples, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const double*)scr, n, S, mode,
+                     mode == 0 ? sample_w : nullptr, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

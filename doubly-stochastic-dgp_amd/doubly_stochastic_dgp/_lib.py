@@ -73,6 +73,7 @@ _PROTOS = {
     "dsdgp_model_elbo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_int64), C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "dsdgp_model_adam_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]),
+    "dsdgp_model_set_sample_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "dsdgp_model_natgrad_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int)]),
     "dsdgp_model_layer_kl": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dsdgp_model_layer_conditional": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -83,12 +84,12 @@ _PROTOS = {
     "dsdgp_randn": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "dsdgp_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "dsdgp_gauss_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                      C.c_double, C.c_void_p]),
+                                      C.c_double, C.c_void_p, C.c_void_p]),
     "dsdgp_gauss_predict_density": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                               C.c_int32, C.c_double, C.c_void_p]),
     "dsdgp_add_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p]),
     "dsdgp_multiclass_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                           C.c_int, C.c_void_p]),
+                                           C.c_int, C.c_void_p, C.c_void_p]),
     "dsdgp_multiclass_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 

@@ -209,6 +209,46 @@ class DGP_Base(Parameterized):
         return self.likelihood.predict_density_logmeanexp(Fmean, Fvar, np.asarray(Ynew, dtype=np.float64))
 
 
+class DGP_Quad(DGP_Base):
+    """A DGP evaluated with Gauss-Hermite quadrature over the inner layers instead of Monte-Carlo samples (dgp.py:129-166):
+    H**D_quad deterministic whitened points, D_quad = the summed inner-layer widths, injected through `zs` with shape
+    (S,1,D) and combined with the quadrature weights in place of the mean over S.  Exponential in D_quad — a test oracle for
+    the sampler (tests/test_dgp.py:120-174), evaluated (and differentiated) by the same device path as DGP."""
+
+    def __init__(self, *args, H=100, **kwargs):
+        DGP_Base.__init__(self, *args, **kwargs)
+        from .utils import mvhermgauss
+        self.H = int(H)
+        self.D_quad = sum(layer.q_mu.shape[1] for layer in self.layers[:-1])        # dgp.py:142
+        gh_x, gh_w = mvhermgauss(self.H, self.D_quad)
+        gh_x = gh_x * 2.0 ** 0.5                                                     # dgp.py:144
+        self.gh_w = gh_w * np.pi ** (-0.5 * self.D_quad)                             # dgp.py:145
+        self.gh_x, s = [], 0
+        for layer in self.layers[:-1]:                                               # dgp.py:149-154: (S,1,D) slices
+            e = s + layer.q_mu.shape[1]
+            self.gh_x.append(np.ascontiguousarray(gh_x[:, None, s:e]))
+            s = e
+        self.gh_x.append(np.zeros((1, 1, 1)))                                        # dgp.py:157 (never used)
+        self.num_samples = self.H ** self.D_quad                                     # dgp.py:164
+
+    def engine(self):
+        eng = DGP_Base.engine(self)
+        if getattr(eng, "_sample_w", None) is None:
+            eng.set_sample_weights(eng.ctx.to_device(self.gh_w))
+        return eng
+
+    def E_log_p_Y(self, X, Y, zs=None):                                              # dgp.py:160-166
+        Fmean, Fvar = self._build_predict(X, full_cov=False, S=self.num_samples, zs=self.gh_x)
+        return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64), weights=self.gh_w)
+
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False):
+        return DGP_Base._build_likelihood(self, X, Y, zs=self.gh_x, with_grad=with_grad)
+
+    def train_step(self, *args, **kwargs):
+        kwargs["zs"] = self.gh_x
+        return DGP_Base.train_step(self, *args, **kwargs)
+
+
 class DGP(DGP_Base):
     """The doubly-stochastic DGP with linear/identity mean functions (dgp.py:169-192)."""
 

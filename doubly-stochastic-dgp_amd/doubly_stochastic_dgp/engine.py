@@ -84,6 +84,7 @@ class Engine:
         self._dev_dirty = False        # device theta newer than host Parameter values
         self._structure_dirty = False
         self._needs_prepare = True
+        self._sample_w = None
         self._build_layout()
         self._ensure(n_max, s_max)
 
@@ -248,6 +249,8 @@ class Engine:
                                                C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
         self.model = h
         self.n_max, self.s_max = n_max, s_max
+        if getattr(self, "_sample_w", None) is not None:       # DGP_Quad weights survive a model re-creation
+            self.set_sample_weights(self._sample_w)
         self._host_dirty = True
         self._needs_prepare = True
         self.adam_t = 0
@@ -339,6 +342,13 @@ class Engine:
         _lib.check(self.lib.dsdgp_model_natgrad_step(self.model, l, float(gamma), C.byref(info) if check else None))
         self._dev_dirty = True
         self._needs_prepare = True
+
+    def set_sample_weights(self, w_dev):
+        """DGP_Quad (dgp.py:160-166): weight the S propagated samples by w (device tensor, kept alive here) instead of 1/S;
+        None restores the Monte-Carlo mean."""
+        self._sample_w = w_dev
+        _lib.check(self.lib.dsdgp_model_set_sample_weights(self.model, ptr(w_dev) if w_dev is not None else None,
+                                                           int(w_dev.numel()) if w_dev is not None else 0))
 
     def layer_kl(self, l):
         self._prepare_checked()

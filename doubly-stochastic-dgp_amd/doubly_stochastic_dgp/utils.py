@@ -31,6 +31,16 @@ def reparameterize(mean, var, z, full_cov=False):
     return out.cpu().numpy()
 
 
+def mvhermgauss(H, D):
+    """[UPSTREAM] gpflow.quadrature.mvhermgauss: the H**D tensor-product Gauss-Hermite nodes (H**D, D) and weights (H**D,)
+    for the weight function exp(-|x|^2) (consumed by DGP_Quad, dgp.py:143-145)."""
+    import itertools
+    gh_x, gh_w = np.polynomial.hermite.hermgauss(int(H))
+    x = np.array(list(itertools.product(*(gh_x,) * int(D))))
+    w = np.prod(np.array(list(itertools.product(*(gh_w,) * int(D)))), axis=1)
+    return x.reshape(int(H) ** int(D), int(D)), w
+
+
 class BroadcastingLikelihood:
     """Wrapper giving every likelihood method (S,N,D) semantics with Y of shape (N,D) (utils.py:54-121): the Gaussian
     broadcasts Y[None]; every other likelihood is evaluated on the flattened (S*N, D) arrays with Y tiled S times
@@ -45,26 +55,36 @@ class BroadcastingLikelihood:
             raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
                                       "(Gaussian, MultiClass are)")
 
-    def _run(self, mode, Fmu, Fvar, Y):
+    def _run(self, mode, Fmu, Fvar, Y, weights=None):
         from . import _lib
         from .engine import Context, ptr
         ctx = Context.get()
         Fmu = np.asarray(Fmu, dtype=np.float64)
         S, N, D = Fmu.shape
         m, v, y = ctx.to_device(Fmu), ctx.to_device(np.broadcast_to(Fvar, Fmu.shape)), ctx.to_device(Y)
+        w = None
+        if weights is not None:
+            if mode != 0 or np.shape(weights) != (S,):
+                raise ValueError("sample weights apply to the variational expectations and must have shape (S,)")
+            w = ctx.to_device(np.asarray(weights, dtype=np.float64))
+        wp = ptr(w) if w is not None else None
         if not self.needs_broadcasting:
             out = ctx.empty(N, D)
-            fn = ctx.lib.dsdgp_gauss_var_exp if mode == 0 else ctx.lib.dsdgp_gauss_predict_density
-            _lib.check(fn(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, float(self.likelihood.variance.value), ptr(out)))
+            lv = float(self.likelihood.variance.value)
+            if mode == 0:
+                _lib.check(ctx.lib.dsdgp_gauss_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, lv, wp, ptr(out)))
+            else:
+                _lib.check(ctx.lib.dsdgp_gauss_predict_density(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, lv, ptr(out)))
         else:
             out = ctx.empty(N, 1)
-            _lib.check(ctx.lib.dsdgp_multiclass_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, ptr(out)))
+            _lib.check(ctx.lib.dsdgp_multiclass_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
         ctx.sync()
         return out.cpu().numpy()
 
-    def variational_expectations_mean(self, Fmu, Fvar, Y):
-        """reduce_mean over S of variational_expectations (dgp.py:89-90)."""
-        return self._run(0, Fmu, Fvar, Y)
+    def variational_expectations_mean(self, Fmu, Fvar, Y, weights=None):
+        """reduce_mean over S of variational_expectations (dgp.py:89-90); with `weights` (S,) the weighted sum over S of
+        DGP_Quad.E_log_p_Y (dgp.py:165-166)."""
+        return self._run(0, Fmu, Fvar, Y, weights)
 
     def predict_density_logmeanexp(self, Fmu, Fvar, Y):
         """logsumexp_S(predict_density) - log S (dgp.py:124-126)."""

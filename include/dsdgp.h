@@ -148,6 +148,11 @@ int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n
                      const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
                      double kl_weight, int with_grad, double* out);
 
+/* DGP_Quad (dgp.py:129-166): replace the Monte-Carlo mean over the S propagated samples of dsdgp_model_elbo by the
+ * weighted sum  sum_s w[s] (.)  (Gauss-Hermite weights, summing to one).  w: device, S doubles, borrowed until cleared;
+ * NULL restores the mean.  dsdgp_model_elbo then requires its S argument to equal this S. */
+int dsdgp_model_set_sample_weights(dsdgp_model* m, const double* w, int32_t S);
+
 /* [UPSTREAM] tf.train.AdamOptimizer step on theta using grad (t counts from 1). Non-trainable entries are skipped. */
 int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t);
 
@@ -184,9 +189,11 @@ int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols, const int
                       double* dst);
 
 /* DGP_Base.E_log_p_Y with the Gaussian likelihood (dgp.py:83-90): out[i,d] = mean_s varexp(mean[s,i,d], var[s,i,d], Y[i,d]).
- * mean/var: (S*n x DY); Y, out: (n x DY); lik_var: host scalar. */
+ * mean/var: (S*n x DY); Y, out: (n x DY); lik_var: host scalar.
+ * sample_w (device, S doubles, may be NULL): DGP_Quad.E_log_p_Y (dgp.py:160-166) — out = sum_s sample_w[s] varexp_s
+ * instead of the mean over s. */
 int dsdgp_gauss_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int32_t S,
-                        int32_t DY, double lik_var, double* out);
+                        int32_t DY, double lik_var, const double* sample_w, double* out);
 /* DGP_Base.predict_density, Gaussian (dgp.py:121-126): out[i,d] = logsumexp_s log N(Y | mean, var + lik_var) - log S. */
 int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
                                 int32_t S, int32_t DY, double lik_var, double* out);
@@ -194,7 +201,7 @@ int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, const double
  * mode 0: out[i] = mean_s variational expectation ; mode 1: out[i] = logsumexp_s log density - log S.
  * mean/var: (S*n x K); Y: (n x 1) class labels stored as doubles; out: (n x 1). */
 int dsdgp_multiclass_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int32_t S,
-                             int32_t K, int mode, double* out);
+                             int32_t K, int mode, const double* sample_w, double* out);
 /* MultiClass.predict_mean_and_var: out_mean[r,k] = predictive class probability, out_var = p - p^2; R rows. */
 int dsdgp_multiclass_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t R, int32_t K, double* out_mean,
                              double* out_var);

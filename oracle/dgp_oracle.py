@@ -357,9 +357,10 @@ class MultiClass:
 # dgp.py:42-126  DGP_Base
 # --------------------------------------------------------------------------------------------------
 class DGPOracle:
-    def __init__(self, layers, likelihood, num_samples=1, num_data=None):
+    def __init__(self, layers, likelihood, num_samples=1, num_data=None, sample_weights=None):
         self.layers, self.likelihood = layers, likelihood
         self.num_samples, self.num_data = num_samples, num_data
+        self.sample_weights = sample_weights          # DGP_Quad (dgp.py:145): gh_w, replaces the mean over S by a weighted sum
 
     # dgp.py:61-76 propagate
     def propagate(self, xp, X, zs, full_cov=False, S=1):
@@ -375,6 +376,9 @@ class DGPOracle:
     def E_log_p_Y(self, xp, X, Y, zs):
         _, Fmeans, Fvars = self.propagate(xp, X, zs, full_cov=False, S=self.num_samples)
         var_exp = self.likelihood.variational_expectations(xp, Fmeans[-1], Fvars[-1], Y)   # dgp.py:89
+        if self.sample_weights is not None:                             # DGP_Quad.E_log_p_Y, dgp.py:165-166
+            w = xp.asarray(self.sample_weights)
+            return xp.sum(var_exp * w[:, None, None], 0)
         return xp.mean(var_exp, 0)                                      # dgp.py:90
 
     # dgp.py:92-98 _build_likelihood
@@ -389,6 +393,23 @@ class DGPOracle:
         _, Fmeans, Fvars = self.propagate(xp, Xnew, zs, S=S)
         l = self.likelihood.predict_density(xp, Fmeans[-1], Fvars[-1], Ynew)
         return xp.logsumexp(l - math.log(S), 0)
+
+
+def quad_points(H, layer_widths):
+    """DGP_Quad.__init__ (dgp.py:141-157): tensor-product Gauss-Hermite points split per inner layer as (S,1,D) whitened
+    z's plus a dummy for the last layer, and the weights gh_w (summing to one).  [UPSTREAM] gpflow.quadrature.mvhermgauss
+    restated through numpy's hermgauss."""
+    import itertools
+    D = int(sum(layer_widths))
+    gx, gw = np.polynomial.hermite.hermgauss(H)
+    x = np.array(list(itertools.product(*(gx,) * D))).reshape(H ** D, D) * 2.0 ** 0.5
+    w = np.prod(np.array(list(itertools.product(*(gw,) * D))).reshape(H ** D, D), axis=1) * np.pi ** (-0.5 * D)
+    zs, s = [], 0
+    for d in layer_widths:
+        zs.append(x[:, None, s:s + d])
+        s += d
+    zs.append(np.zeros((1, 1, 1)))
+    return zs, w
 
 
 # --------------------------------------------------------------------------------------------------

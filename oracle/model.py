@@ -43,7 +43,7 @@ def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
     return spec_layers, state
 
 
-def build(xp, spec, state, num_samples=1, num_data=None):
+def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
     """Instantiate the oracle model under backend ``xp`` from (spec, state)."""
     layers = []
     for i, ls in enumerate(spec["layers"]):
@@ -61,20 +61,21 @@ def build(xp, spec, state, num_samples=1, num_data=None):
         lik = O.Gaussian(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
     else:
         lik = O.MultiClass(spec["num_classes"])
-    return O.DGPOracle(layers, lik, num_samples=num_samples, num_data=num_data)
+    return O.DGPOracle(layers, lik, num_samples=num_samples, num_data=num_data, sample_weights=sample_weights)
 
 
-def elbo(spec, state, X, Y, zs, num_samples, num_data=None):
-    m = build(O.NP, spec, state, num_samples, num_data)
+def elbo(spec, state, X, Y, zs, num_samples, num_data=None, sample_weights=None):
+    m = build(O.NP, spec, state, num_samples, num_data, sample_weights)
     return float(m.build_likelihood(O.NP, np.asarray(X, float), np.asarray(Y, float), zs))
 
 
-def elbo_and_grad(spec, state, X, Y, zs, num_samples, num_data=None):
+def elbo_and_grad(spec, state, X, Y, zs, num_samples, num_data=None, sample_weights=None):
     """ELBO and d(ELBO)/d(state) via torch CPU float64 autograd on the identical op sequence
     (stands in for tf.gradients [UPSTREAM]).  q_sqrt gradients are lower-triangular by construction."""
     import torch
     leaves = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in state.items()}
-    m = build(O.TH, spec, leaves, num_samples, num_data)
+    m = build(O.TH, spec, leaves, num_samples, num_data,
+              None if sample_weights is None else torch.as_tensor(np.asarray(sample_weights, dtype=np.float64)))
     zs_t = [None if z is None else torch.as_tensor(np.asarray(z, dtype=np.float64)) for z in zs]
     val = m.build_likelihood(O.TH, torch.as_tensor(np.asarray(X, float)), torch.as_tensor(np.asarray(Y, float)), zs_t)
     val.backward()

@@ -499,6 +499,55 @@ def test_cfg5_shape_M1024():
     assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
 
 
+# ---------------------------------------------------------------- DGP_Quad (dgp.py:129-166)
+@pytest.mark.parametrize("num_classes", [None, 3])
+def test_dgp_quad_matches_oracle(num_classes):
+    # quadrature over the inner layers: (S,1,D) Gauss-Hermite z's and weights in place of the MC mean — value, E_log_p_Y
+    # and every gradient against the oracle's weighted restatement
+    from doubly_stochastic_dgp.dgp import DGP_Quad
+    rng = np.random.RandomState(21)
+    N, D, M, H = 30, 2, 12, 7
+    X = rng.randn(N, D)
+    Y = rng.randint(0, 3, size=(N, 1)).astype(float) if num_classes else rng.randn(N, 1)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 0.8), kern_spec("matern52", D, 1.2, 1.1)]
+    spec, state, model = make_case(X, Y, Z, specs, S=1, num_data=90, num_classes=num_classes)
+    quad = DGP_Quad(X, Y, model.likelihood.likelihood, model.layers, H=H, num_data=90)
+    assert quad.D_quad == 2 and quad.num_samples == H ** 2
+    zs, w = O.quad_points(H, [2])
+    assert_allclose(w.sum(), 1.0, rtol=1e-12)
+    for a, b in zip(quad.gh_x, zs):
+        assert_allclose(a, b, rtol=0, atol=0)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, H ** 2, num_data=90, sample_weights=w)
+    got = quad._build_likelihood(X, Y, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = quad.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-7, (k, err)
+    om = OM.build(O.NP, spec, state, H ** 2, 90, sample_weights=w)
+    assert_allclose(quad.E_log_p_Y(X, Y), om.E_log_p_Y(O.NP, X, Y, zs), rtol=1e-9, atol=1e-11)
+
+
+def test_dgp_quad_vs_monte_carlo():
+    # tests/test_dgp.py:120-174: the sampled bound agrees with quadrature within 3 standard errors (1-D inner layer,
+    # z shared across the N points exactly as the reference's (S,1,D) quadrature nodes are)
+    from doubly_stochastic_dgp.dgp import DGP_Quad
+    rng = np.random.RandomState(22)
+    N, M = 2, 2
+    X, Y = rng.randn(N, 1), rng.randn(N, 1)
+    specs = [kern_spec("rbf", 1, 1.0, 0.3)] * 2
+    spec, state, model = make_case(X, Y, X.copy(), specs, S=300, lik_var=0.01)
+    quad = DGP_Quad(X, Y, model.likelihood.likelihood, model.layers, H=100)
+    q = quad.compute_log_likelihood(X, Y)
+    vals = []
+    for r in range(60):
+        z0 = np.random.RandomState(500 + r).randn(300, 1, 1)
+        vals.append(model.compute_log_likelihood(X, Y, zs=[z0, np.zeros((1, 1, 1))]))
+    mean, se = np.mean(vals), np.std(vals) / np.sqrt(len(vals))
+    assert abs(q - mean) < 3 * se + 1e-9, (q, mean, se)
+
+
 def test_large_M_white_multiworkgroup_cholesky():
     # M = 520 (padded 1024) with white=True: the multi-workgroup blocked Cholesky/inverse path, the white-adjoint GEMMs that
     # read Lu densely (its upper blocks must be exact zeros), and a batched (D_out = 3) natural-gradient step on top

@@ -117,3 +117,17 @@ def test_positive_transform_roundtrip():
     y = np.array([1e-5, 0.01, 1.0, 50.0])
     assert_allclose(positive_forward(positive_backward(y)), y, rtol=1e-12)
     assert_allclose(positive_forward(positive_backward(y)), O.positive_forward(O.NP, O.positive_backward_np(y)), rtol=1e-14)
+
+
+def test_mvhermgauss_matches_oracle_quad_points():
+    # [UPSTREAM] gpflow.quadrature.mvhermgauss as consumed by DGP_Quad (dgp.py:143-157)
+    from doubly_stochastic_dgp.utils import mvhermgauss
+    from oracle import dgp_oracle as O
+    x, w = mvhermgauss(5, 3)
+    assert x.shape == (125, 3) and w.shape == (125,)
+    zs, wq = O.quad_points(5, [1, 2])
+    np.testing.assert_allclose(np.concatenate([zs[0][:, 0, :], zs[1][:, 0, :]], 1), x * 2 ** 0.5, rtol=0, atol=0)
+    np.testing.assert_allclose(wq, w * np.pi ** -1.5, rtol=1e-15)
+    # exact for polynomials: E[z1^2 z2^4] under N(0, I) = 1 * 3
+    z = x * 2 ** 0.5
+    np.testing.assert_allclose(np.sum(wq * z[:, 0] ** 2 * z[:, 1] ** 4), 3.0, rtol=1e-12)
