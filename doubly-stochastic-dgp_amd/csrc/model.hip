@@ -50,6 +50,8 @@ struct LayerState {
   int nsplit_big_max, nsplit_thin_max;
   double *A, *E, *GW, *VB, *MB, *XT1;
   double *F, *mean, *var, *zbuf, *dF;
+  double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
+  int prop;
   double *part_big, *part_thin, *hyp_part;
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
   BigChol big_k, big_ngA, big_ngS, big_ngT;
@@ -192,7 +194,9 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.XT1 = b.take<double>(v.DinP16 * S.ld_max);
     S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
     S.var = b.take<double>(S.R_max * d.D_out); S.zbuf = b.take<double>(S.R_max * d.D_out + 2);
-    S.dF = b.take<double>(S.R_max * d.D_out);
+    S.prop = (l + 1 < D.L) ? d.input_prop_dim : 0;     // the last layer's concatenation is host glue (nothing consumes it)
+    S.dF = b.take<double>(S.R_max * (d.D_out + S.prop));
+    S.Xcat = S.prop ? b.take<double>(S.R_max * (d.D_out + S.prop)) : nullptr;
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int tj_big = v.Mp / (16 * NI);
@@ -466,11 +470,24 @@ __global__ void k_reparam(const double* __restrict__ mean, const double* __restr
 //   MB[d][r] = sum_s (dF + dmean)[s,r,d]
 //   VB[d][r] = sum_s (dF * z / (2 sqrt(var + jitter)) + dvar)[s,r,d]       (utils.py:41 reverse)
 //   XT1      = [X^T ; 1]  (for dl/dZ = GW [X | 1])
+// input propagation (layers.py:105-110): next-layer input = [ X[:, :prop] | samples ]; the `rep` output rows of one input
+// row (layer 0 is evaluated once per data row) read the same X row
+__global__ void k_concat_prop(const double* __restrict__ Xin, int64_t Rin, int D_in, int prop, const double* __restrict__ F,
+                              int D_out, int64_t R, double* __restrict__ out) {
+  const int W = prop + D_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R * W; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t orow = i / W;
+    const int j = (int)(i % W);
+    out[i] = (j < prop) ? Xin[(orow % Rin) * D_in + j] : F[orow * D_out + (j - prop)];
+  }
+}
+
 __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restrict__ dmean, const double* __restrict__ dvar,
                            const double* __restrict__ z, int64_t zs_s, int64_t zs_n, int64_t zs_d, int64_t n_inner,
                            const double* __restrict__ var, const double* __restrict__ X, int64_t Rin, int rep, int D_in,
                            int D_out, int DP16, int DinP16, double jitter, int64_t ld, double* __restrict__ MB,
-                           double* __restrict__ VB, double* __restrict__ XT1) {
+                           double* __restrict__ VB, double* __restrict__ XT1, int ldf, int offf) {
+  // dF: adjoint of the next layer's input, (rows x ldf) with this layer's samples at column offset offf (input propagation)
   // grid: x over rows, y over the d / j index (max(DP16, DinP16) slices)
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ld) return;
@@ -488,14 +505,14 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int64_t orow = (int64_t)(s + u) * Rin + r;
-            const double f = dF[orow * D_out + d];
+            const double f = dF[orow * ldf + offf + d];
             m4[u] += f;
             v4[u] = fma(f, z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d], v4[u]);
           }
         }
         for (; s < rep; ++s) {
           const int64_t orow = (int64_t)s * Rin + r;
-          const double f = dF[orow * D_out + d];
+          const double f = dF[orow * ldf + offf + d];
           m4[0] += f;
           v4[0] = fma(f, z[(orow / n_inner) * zs_s + (orow % n_inner) * zs_n + d * zs_d], v4[0]);
         }
@@ -752,7 +769,8 @@ static int validate_desc(const dsdgp_model_desc* d) {
       dsdgp_set_error("layer %d: M=%d inducing points exceeds the built chain kernels (<= 1024)", l, y.M);
       return DSDGP_ERR_UNSUPPORTED;
     }
-    if (l > 0) DS_CHECK_ARG(y.D_in == d->layers[l - 1].D_out);
+    DS_CHECK_ARG(y.input_prop_dim >= 0 && y.input_prop_dim <= y.D_in);
+    if (l > 0) DS_CHECK_ARG(y.D_in == d->layers[l - 1].D_out + d->layers[l - 1].input_prop_dim);   // layers.py:105-110
     if (y.mean_kind == DSDGP_MEAN_IDENTITY) DS_CHECK_ARG(y.D_in == y.D_out);
     if (y.mean_kind == DSDGP_MEAN_LINEAR) DS_CHECK_ARG(y.mean_A != nullptr);
   }
@@ -1048,7 +1066,15 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
       DS_TRY(layer_fwd_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
-    Xin = a.F;
+    if (St.prop && !last) {
+      const int64_t R = (int64_t)S * n, cnt = R * (v.D_out + St.prop);
+      hipLaunchKernelGGL(k_concat_prop, dim3((int)std::min<int64_t>(4096, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream, Xin, Rin,
+                         v.D_in, St.prop, a.F, v.D_out, R, St.Xcat);
+      DS_HIP(hipGetLastError());
+      Xin = St.Xcat;
+    } else {
+      Xin = a.F;
+    }
   }
   return DSDGP_OK;
 }
@@ -1139,7 +1165,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                        last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
                        St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
-                       St.MB, St.VB, St.XT1);
+                       St.MB, St.VB, St.XT1, v.D_out + St.prop, St.prop);
     DS_HIP(hipGetLastError());
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;

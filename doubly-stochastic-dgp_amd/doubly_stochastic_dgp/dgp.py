@@ -133,7 +133,18 @@ class DGP_Base(Parameterized):
             return Fs, Fmeans, Fvars
         Fs, Fmeans, Fvars = eng.propagate(X, int(S), zs=zs, seed=self._next_seed())
         eng.ctx.sync()
-        return self._np(Fs), self._np(Fmeans), self._np(Fvars)
+        Fs, Fmeans, Fvars = self._np(Fs), self._np(Fmeans), self._np(Fvars)
+        if any(layer.input_prop_dim for layer in self.layers):
+            # the device hands the concatenated [X_prop | F] to the next layer itself; the returned lists get the same
+            # copies prepended here (layers.py:105-117)
+            from .layers import concat_input_prop
+            Xh = X.cpu().numpy() if hasattr(X, "data_ptr") else np.asarray(X, dtype=np.float64)
+            Fin = np.tile(Xh[None], [int(S), 1, 1])
+            for l, layer in enumerate(self.layers):
+                if layer.input_prop_dim:
+                    Fs[l], Fmeans[l], Fvars[l] = concat_input_prop(Fin, layer.input_prop_dim, Fs[l], Fmeans[l], Fvars[l])
+                Fin = Fs[l]
+        return Fs, Fmeans, Fvars
 
     # dgp.py:78-81
     def _build_predict(self, X, full_cov=False, S=1, zs=None):

@@ -132,6 +132,10 @@ class Engine:
                 off += cnt
                 return p.trainable
 
+            ld.input_prop_dim = int(getattr(layer, "input_prop_dim", None) or 0)
+            if ld.input_prop_dim and l == len(self.layers) - 1 and len(self.layers) > 1:
+                raise NotImplementedError("the last layer of a DGP does not propagate inputs "
+                                          "(layer_initializations.py:75-78)")
             ld.trainable_Z = int(add(layer.feature.Z, "id", "Z"))
             ld.trainable_q_mu = int(add(layer.q_mu, "id", "q_mu"))
             ld.trainable_q_sqrt = int(add(layer.q_sqrt, "qsqrt", "q_sqrt"))

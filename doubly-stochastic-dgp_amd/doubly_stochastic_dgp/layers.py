@@ -27,10 +27,23 @@ def _host_K_symm(kern, Z):
     return K
 
 
+def concat_input_prop(X, p, samples, mean, var, full_cov=False):
+    """layers.py:105-117: prepend the propagated inputs X[..., :p] to the samples and means, and zeros to the variances
+    (pure copies — no arithmetic)."""
+    X_prop = X[:, :, :p]
+    samples = np.concatenate([X_prop, samples], 2)
+    mean = np.concatenate([X_prop, mean], 2)
+    if full_cov:
+        zeros = np.zeros(var.shape[:3] + (p,))
+        var = np.concatenate([zeros, var], 3)
+    else:
+        var = np.concatenate([np.zeros_like(X_prop), var], 2)
+    return samples, mean, var
+
+
 class Layer(Parameterized):
     def __init__(self, input_prop_dim=None, **kwargs):
-        if input_prop_dim:
-            raise NotImplementedError("input propagation (init_layers_input_prop) is outside the DGP hot path")
+        """input_prop_dim: the first dimensions of X to propagate (layers.py:36-50); None = no input propagation."""
         self.input_prop_dim = input_prop_dim
 
     def conditional_ND(self, X, full_cov=False):
@@ -56,6 +69,9 @@ class Layer(Parameterized):
             z = self._engine().randn(mean.shape)
         z = np.broadcast_to(np.asarray(z, dtype=np.float64), mean.shape)
         samples = reparameterize(mean, var, z, full_cov=full_cov)
+        if self.input_prop_dim:                                   # layers.py:105-117
+            samples, mean, var = concat_input_prop(np.asarray(X, dtype=np.float64), self.input_prop_dim, samples, mean, var,
+                                                   full_cov)
         return samples, mean, var
 
 

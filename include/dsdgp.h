@@ -94,6 +94,7 @@ typedef struct {
   int32_t kern_kind, ard, has_white;
   int32_t mean_kind;               /* DSDGP_MEAN_* */
   int32_t trainable_Z, trainable_q_mu, trainable_q_sqrt, trainable_kvar, trainable_kls, trainable_wvar;
+  int32_t input_prop_dim;          /* Layer(input_prop_dim) layers.py:36-50,105-117: the next layer sees [X[:, :p] | samples] */
   const double* mean_A;            /* device, (D_in x D_out) for DSDGP_MEAN_LINEAR (fixed: layer_initializations.py:42) */
   /* offsets (in doubles) into the flat unconstrained parameter vector theta: */
   int64_t off_Z;                   /* (M, D_in)                       feature.Z           layers.py:153 */

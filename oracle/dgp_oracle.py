@@ -58,6 +58,7 @@ class NP:
     tile = staticmethod(lambda a, reps: np.tile(a, reps))
     reshape = staticmethod(lambda a, s: np.reshape(a, s))
     stack = staticmethod(lambda xs: np.stack(xs))
+    concat = staticmethod(lambda xs, axis: np.concatenate(xs, axis))
     tril = staticmethod(np.tril)
     softplus = staticmethod(lambda x: np.logaddexp(0.0, x))
     erf = staticmethod(lambda x: __import__("scipy.special", fromlist=["erf"]).erf(x))
@@ -100,6 +101,7 @@ class TH:
     tile = staticmethod(lambda a, reps: a.repeat(*reps))
     reshape = staticmethod(lambda a, s: a.reshape(*s))
     stack = staticmethod(lambda xs: TH._t.stack(list(xs)))
+    concat = staticmethod(lambda xs, axis: TH._t.cat(list(xs), dim=axis))
     tril = staticmethod(lambda a: TH._t.tril(a))
     softplus = staticmethod(lambda x: TH._t.nn.functional.softplus(x, threshold=1e9))
     erf = staticmethod(lambda x: TH._t.erf(x))
@@ -191,7 +193,8 @@ class MeanFn:
 # layers.py:122-246  SVGP_Layer
 # --------------------------------------------------------------------------------------------------
 class SVGPLayer:
-    def __init__(self, kern, Z, q_mu, q_sqrt, mean_function, white=False, jitter=DEFAULT_JITTER):
+    def __init__(self, kern, Z, q_mu, q_sqrt, mean_function, white=False, jitter=DEFAULT_JITTER, input_prop_dim=None):
+        self.input_prop_dim = input_prop_dim                             # layers.py:36-50
         self.kern, self.Z, self.q_mu, self.q_sqrt = kern, Z, q_mu, q_sqrt
         self.mean_function, self.white, self.jitter = mean_function, white, jitter
         self.num_inducing = Z.shape[0]
@@ -259,10 +262,19 @@ class SVGPLayer:
         mean, var = self.conditional_ND(xp, xp.reshape(X, (S * N, Din)))           # layers.py:71-73
         return xp.reshape(mean, (S, N, self.num_outputs)), xp.reshape(var, (S, N, self.num_outputs))
 
-    # layers.py:76-119 sample_from_conditional (input_prop_dim unused by DGP: omitted)
+    # layers.py:76-119 sample_from_conditional
     def sample_from_conditional(self, xp, X, z, full_cov=False):
         mean, var = self.conditional_SND(xp, X, full_cov=full_cov)
         samples = reparameterize(xp, mean, var, z, full_cov=full_cov, jitter=self.jitter)  # layers.py:103
+        if self.input_prop_dim:                                          # layers.py:105-117
+            X_prop = X[:, :, :self.input_prop_dim]
+            samples = xp.concat([X_prop, samples], 2)
+            mean = xp.concat([X_prop, mean], 2)
+            if full_cov:
+                S, N = X.shape[0], X.shape[1]
+                var = xp.concat([xp.zeros(S, N, N, self.input_prop_dim), var], 3)
+            else:
+                var = xp.concat([X_prop * 0.0, var], 2)
         return samples, mean, var
 
 
@@ -451,6 +463,36 @@ def init_layers_linear(X, Y, Z, kern_specs, num_outputs=None, final_mean="zero",
             Z_run = Z_run.dot(W)
             X_run = X_run.dot(W)
     out.append(make(kern_specs[-1], Z_run, num_outputs, MeanFn(final_mean)))   # :51
+    return out
+
+
+# layer_initializations.py:55-79 init_layers_input_prop; `pads` replaces the reference's np.random.randn draws (one (M, dim_in - D)
+# standard-normal array per layer) so that both sides of a parity test see the same inducing inputs
+def init_layers_input_prop(X, Y, Z, kern_specs, pads, num_outputs=None, final_mean="zero", white=False,
+                           jitter=DEFAULT_JITTER):
+    num_outputs = num_outputs or Y.shape[1]
+    D = X.shape[1]
+    out = []
+
+    def make(spec, Zl, dim_out, mf, prop):
+        kern = Kern(**spec)
+        M = Zl.shape[0]
+        q_mu = np.zeros((M, dim_out))
+        q_sqrt = np.tile(np.eye(M)[None], [dim_out, 1, 1])
+        if not white:
+            Lu = np.linalg.cholesky(kern.K(NP, Zl) + np.eye(M) * jitter)
+            q_sqrt = np.tile(Lu[None], [dim_out, 1, 1])
+        return dict(kern=kern, Z=Zl.copy(), q_mu=q_mu, q_sqrt=q_sqrt, mean=mf, white=white, input_prop_dim=prop)
+
+    for i, (s_in, s_out) in enumerate(zip(kern_specs[:-1], kern_specs[1:])):
+        dim_in, dim_out = s_in["input_dim"], s_out["input_dim"] - D                    # :65-66
+        std_in = float(s_in["variance"]) ** 0.5                                          # :67
+        Zp = np.concatenate([Z, pads[i] * 2.0 * std_in], 1)                              # :68-69
+        out.append(make(s_in, Zp, dim_out, MeanFn("zero"), D))                           # :70
+    dim_in = kern_specs[-1]["input_dim"]
+    std_in = float(kern_specs[-2]["variance"]) ** 0.5 if dim_in > D else 1.0             # :73
+    Zp = np.concatenate([Z, pads[-1] * 2.0 * std_in], 1)
+    out.append(make(kern_specs[-1], Zp, num_outputs, MeanFn(final_mean), None))          # :77
     return out
 
 

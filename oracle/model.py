@@ -27,7 +27,8 @@ def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
         k = ld["kern"]
         spec_layers.append(dict(kind=k.kind, input_dim=k.input_dim, ARD=k.ARD,
                                 has_white=k.white_variance is not None,
-                                mean=ld["mean"].kind, mean_A=ld["mean"].A))
+                                mean=ld["mean"].kind, mean_A=ld["mean"].A,
+                                input_prop_dim=ld.get("input_prop_dim")))
         state[f"l{i}.Z"] = np.array(ld["Z"], dtype=np.float64)
         state[f"l{i}.q_mu"] = np.array(ld["q_mu"], dtype=np.float64)
         state[f"l{i}.q_sqrt"] = np.array(ld["q_sqrt"], dtype=np.float64)
@@ -56,7 +57,8 @@ def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
                                       if ls.get("has_white") else None))
         mf = O.MeanFn(ls["mean"], A=ls.get("mean_A"))
         layers.append(O.SVGPLayer(kern, g("Z"), g("q_mu"), g("q_sqrt"), mf,
-                                  white=spec["white"], jitter=spec["jitter"]))
+                                  white=spec["white"], jitter=spec["jitter"],
+                                  input_prop_dim=ls.get("input_prop_dim")))
     if spec["likelihood"] == "gaussian":
         lik = O.Gaussian(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
     else:

@@ -12,7 +12,7 @@ from numpy.testing import assert_allclose
 
 from oracle import dgp_oracle as O
 from oracle import model as OM
-from tests.helpers import kern_spec, make_case, rel_err
+from tests.helpers import kern_spec, make_case, product_kernel, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -497,6 +497,70 @@ def test_cfg5_shape_M1024():
     NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
     assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
     assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------- input propagation (layer_initializations.py:55-79)
+def _input_prop_case(white=False):
+    from doubly_stochastic_dgp import settings
+    from doubly_stochastic_dgp.dgp import DGP_Base
+    from doubly_stochastic_dgp.gpflow_compat import Gaussian
+    from doubly_stochastic_dgp.layer_initializations import init_layers_input_prop
+    rng = np.random.RandomState(31)
+    N, D, M, S = 40, 2, 14, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", 2, 1.3, 0.9), kern_spec("matern52", 5, 0.8, 1.4), kern_spec("rbf", 4, 1.1, 1.2, ARD=True)]
+    np.random.seed(5)
+    pads = [np.random.randn(M, k["input_dim"] - D) for k in specs]
+    lds = O.init_layers_input_prop(X, Y, Z, specs, pads, white=white)
+    for l in lds:
+        l["q_mu"] = 0.3 * rng.randn(*l["q_mu"].shape)
+        l["q_sqrt"] = l["q_sqrt"] * 0.7 + 0.05 * np.tril(rng.randn(*l["q_sqrt"].shape))
+    sl, state = OM.state_from_layers(lds, lik_variance=0.2)
+    spec = dict(jitter=1e-6, white=white, likelihood="gaussian", layers=sl, num_classes=None)
+    np.random.seed(5)
+    with settings.temp_jitter(1e-6):
+        layers = init_layers_input_prop(X, Y, Z, [product_kernel(k) for k in specs], white=white)
+        model = DGP_Base(X, Y, Gaussian(variance=0.2), layers, num_samples=S, num_data=123)
+    for l, layer in zip(lds, model.layers):
+        assert_allclose(layer.feature.Z.value, l["Z"], rtol=0, atol=0)
+        layer.q_mu = l["q_mu"]
+        layer.q_sqrt = l["q_sqrt"]
+    zs = [rng.randn(S, N, 3), rng.randn(S, N, 2), rng.randn(S, N, 1)]
+    return X, Y, spec, state, model, zs, S
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_input_propagation_matches_oracle(white):
+    X, Y, spec, state, model, zs, S = _input_prop_case(white)
+    assert [l.input_prop_dim for l in model.layers] == [2, 2, None]
+    Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    Fs, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    assert Fs[0].shape == (S, 40, 5) and Fs[1].shape == (S, 40, 4) and Fs[2].shape == (S, 40, 1)
+    for l in range(3):
+        assert_allclose(Fs[l], Fs_o[l], rtol=1e-9, atol=1e-10)
+        assert_allclose(Fm[l], Fm_o[l], rtol=1e-9, atol=1e-10)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-9, atol=1e-10)
+    assert np.all(Fs[1][:, :, :2] == X[None]) and np.all(Fv[0][:, :, :2] == 0.0)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=123)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-7, (k, err)
+
+
+def test_input_propagation_full_cov():
+    X, Y, spec, state, model, zs, S = _input_prop_case()
+    Xs = X[:9]
+    z9 = [z[:, :9] for z in zs]
+    Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, Xs, z9, S, full_cov=True)
+    Fs, Fm, Fv = model.propagate(Xs, full_cov=True, S=S, zs=z9)
+    for l in range(3):
+        assert Fv[l].shape == Fv_o[l].shape
+        assert_allclose(Fs[l], Fs_o[l], rtol=1e-8, atol=1e-9)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-8, atol=1e-9)
 
 
 # ---------------------------------------------------------------- DGP_Quad (dgp.py:129-166)

@@ -279,3 +279,36 @@ def test_T4_natgrad_gamma1_gives_collapsed_bound(white):
     bound = (-0.5 * Y.T @ np.linalg.solve(C, Y)).item() - 0.5 * ld - 0.5 * N * math.log(2 * math.pi) \
         - 0.5 / s2 * (kern.Kdiag(NP, X).sum() - np.trace(Qff))
     assert_allclose(elbo, bound, rtol=1e-7)
+
+
+def test_input_propagation_restatement():
+    # layers.py:105-117 + layer_initializations.py:55-79: the propagated inputs are copied in front of samples/means with zero
+    # variance, widths chain as kern.input_dim, and the autograd gradient agrees with central differences
+    rng = np.random.RandomState(9)
+    N, D, M, S = 6, 2, 5, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[:M] + 0.01
+    specs = [dict(kind="rbf", input_dim=2, variance=1.3, lengthscales=0.9, ARD=False, white_variance=None),
+             dict(kind="rbf", input_dim=4, variance=0.8, lengthscales=1.1, ARD=False, white_variance=None)]
+    pads = [rng.randn(M, 0), rng.randn(M, 2)]
+    lds = O.init_layers_input_prop(X, Y, Z, specs, pads)
+    assert lds[0]["Z"].shape == (M, 2) and lds[1]["Z"].shape == (M, 4) and lds[0]["q_mu"].shape == (M, 2)
+    assert_allclose(lds[1]["Z"][:, 2:], pads[1] * 2.0 * 1.3 ** 0.5, rtol=1e-15)
+    for l in lds:
+        l["q_mu"] = 0.3 * rng.randn(*l["q_mu"].shape)
+        l["q_sqrt"] = l["q_sqrt"] * 0.7
+    sl, state = OM.state_from_layers(lds, lik_variance=0.2)
+    spec = dict(jitter=1e-6, white=False, likelihood="gaussian", layers=sl, num_classes=None)
+    zs = [rng.randn(S, N, 2), rng.randn(S, N, 1)]
+    Fs, Fm, Fv = OM.propagate(spec, state, X, zs, S)
+    assert Fs[0].shape == (S, N, 4)
+    assert np.all(Fs[0][:, :, :2] == X[None]) and np.all(Fm[0][:, :, :2] == X[None]) and np.all(Fv[0][:, :, :2] == 0)
+    _, _, Fvf = OM.propagate(spec, state, X, zs, S, full_cov=True)
+    assert Fvf[0].shape == (S, N, N, 4) and np.all(Fvf[0][..., :2] == 0)
+    v, g = OM.elbo_and_grad(spec, state, X, Y, zs, S)
+    for k, idx in (("l0.q_mu", (1, 0)), ("l0.Z", (2, 1)), ("l1.Z", (0, 3))):
+        e = np.zeros_like(state[k]); e[idx] = 1e-6
+        sp, sm = dict(state), dict(state)
+        sp[k], sm[k] = state[k] + e, state[k] - e
+        fd = (OM.elbo(spec, sp, X, Y, zs, S) - OM.elbo(spec, sm, X, Y, zs, S)) / 2e-6
+        assert abs(fd - g[k][idx]) <= 1e-6 * max(1.0, abs(fd)), (k, fd, g[k][idx])
