@@ -14,6 +14,7 @@ struct LayerFwdArgs {
   const double* LinvT;  // (Mp x Mp)  Lu^{-T}
   const double* Linv;   // (Mp x Mp)  Lu^{-1}
   const double* Tp;     // (D_out x Mp x Mp) lower-triangular q_sqrt, zero padded
+  const double* TpT;    // (D_out x Mp x Mp) its transpose (split-M kernels read every weight as rows [i][k])
   const double* qmu;    // (Mp x D_out)
   int32_t mean_kind;
   const double* mean_A; // (D_in x D_out) for the fixed Linear mean function
@@ -38,6 +39,7 @@ struct LayerBwdArgs {
   const double* hyp;
   const double* Kinv;   // (Mp x Mp)
   const double* Linv;   // (Mp x Mp)   (white path)
+  const double* LinvT;  // (Mp x Mp)   (white path, split-M kernels)
   const double* Sd;     // (D_out x Mp x Mp)  q_sqrt q_sqrt^T
   const double* qmu4;   // (Mp x DP4)
   const double* Asave;

@@ -16,6 +16,42 @@
 
 #define XCH 64   // columns of x/l staged per chunk
 
+// Operand order of the chain GEMMs — two variants, chosen per instance (measured, tools/ab_kernels.py):
+//  * D4 (NW >= 8, i.e. Mp >= 512): every weight matrix is read as plain rows W[i][k]: lane (g, c) of the wave that owns output
+//    row-block ib fetches W[16 ib + c][16 kb + 4 g .. + 3] with ONE 32-byte load and feeds its four values to the four MFMAs of
+//    the k-block, i.e. MFMA step s contracts k = 16 kb + 4 g + s (any bijection of k inside a 16-block is allowed as long as A
+//    and B agree).  The matching B row is 4 g + s, so the activation rows are stored PERMUTED in LDS (row 4 a + b of a block
+//    lives at slot 4 b + a): the B read of step s is slot 16 kb + 4 s + g, conflict-free with an immediate offset, and the loop
+//    carries one global load and no address arithmetic per four MFMAs (2x on the M = 512 / 1024 chains).
+//  * scalar (NW = 4, Mp <= 256): one 8-byte load per MFMA from the transposed matrix W^T[k][i] (k = 16 kb + 4 s + g, natural
+//    LDS order): each load instruction covers 4 full cache lines, which wins while the whole weight set is L1/L2-hot.
+template <bool D4>
+__device__ __forceinline__ int act_slot(int m) {
+  return D4 ? ((m & ~15) | ((m & 3) << 2) | ((m >> 2) & 3)) : m;
+}
+// slot of row (g + 4 t) of block ib — the MFMA D-layout rows this lane holds
+template <bool D4>
+__device__ __forceinline__ int out_slot(int ib, int g, int t) {
+  return D4 ? 16 * ib + 4 * g + t : 16 * ib + g + 4 * t;
+}
+
+// acc += W[16 ib + c][16 kb .. 16 kb + 15] . act[16 kb .. 16 kb + 15][c]
+//   WR = W as rows [i][k], WT = the same matrix transposed ([k][i]); Mp = leading dimension of both
+template <int Mp, bool D4>
+__device__ __forceinline__ d4 chain_block(const double* __restrict__ WR, const double* __restrict__ WT,
+                                          const double* __restrict__ actb, int ib, int kb, int g, int c, d4 acc) {
+  if constexpr (D4) {
+    const d4 w4 = *reinterpret_cast<const d4*>(WR + (int64_t)(16 * ib + c) * Mp + 16 * kb + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma_f64(w4[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
+  } else {
+    const double* __restrict__ w = WT + (int64_t)(16 * kb + g) * Mp + 16 * ib + c;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma_f64(w[(int64_t)(4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
+  }
+  return acc;
+}
+
 template <int MPB, int NW>
 struct Own {
   static constexpr int NQ = (MPB >= NW) ? MPB / NW : 1;
@@ -86,6 +122,7 @@ template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
+  constexpr bool D4 = (NW >= 8);
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -123,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
             const double df = zr[j] - xs[c * (Din + 1) + j];
             r2 = fma(df, df, r2);
           }
-          actb[m * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
+          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
         }
       }
     }
@@ -137,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = 16 * ib + g + 4 * t;
-          actb[m * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
+          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
         }
       }
     }
@@ -152,13 +189,8 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB, NW>::ib(wave, q);
-      const double* __restrict__ W = a.LinvT + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
-      for (int kb = 0; kb <= ib; ++kb) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc[q]);
-      }
+      for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(a.Linv, a.LinvT, actb, ib, kb, g, c, acc[q]);
     }
   }
   {
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
+      for (int t = 0; t < 4; ++t) actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
     }
   }
   __syncthreads();
@@ -188,13 +220,8 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
-        const double* __restrict__ W = a.Linv + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
-        for (int kb = ib; kb < MPB; ++kb) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc[q]);
-        }
+        for (int kb = ib; kb < MPB; ++kb) acc[q] = chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, acc[q]);
       }
     }
     __syncthreads();   // a1 fully consumed -> overwrite with a
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
+        for (int t = 0; t < 4; ++t) actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
       }
     }
   }
@@ -246,17 +273,13 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
     if (act) {
+      const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
       const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
-        const double* __restrict__ W = Td + 16 * ib + c + (int64_t)g * Mp;
 #pragma unroll 2
-        for (int kb = ib; kb < MPB; ++kb) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            cacc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], cacc[q]);
-        }
+        for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
       }
     }
     double* rs2 = red_s2 + (d & 1) * NW * 16;
@@ -323,6 +346,7 @@ template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
+  constexpr bool D4 = (NW >= 8);
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     for (int t = 0; t < 4; ++t) {
       const double v = (act && rin) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] : 0.0;
       av[q][t] = v;
-      if (act) actb[(16 * ib + g + 4 * t) * 16 + c] = v;
+      if (act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
     }
   }
   __syncthreads();
@@ -356,15 +380,31 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     const double vd2 = 2.0 * vd;
     if (act) {
       const double* __restrict__ Sd = a.Sd + (int64_t)d * Mp * Mp;
+      if constexpr (D4) {
+        // y_d = S_d a for this wave's row blocks (the NQ chains interleaved), then abar += 2 vbar_d(column) * y_d
+        d4 y[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-        const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
+        for (int q = 0; q < NQ; ++q) y[q] = (d4){0, 0, 0, 0};
 #pragma unroll 2
         for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c] * vd2, acc[q]);
+          for (int q = 0; q < NQ; ++q) y[q] = chain_block<Mp, D4>(Sd, Sd, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, y[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[q][t] = fma(vd2, y[q][t], acc[q][t]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int ib = Own<MPB, NW>::ib(wave, q);
+          const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
+#pragma unroll 2
+          for (int kb = 0; kb < MPB; ++kb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c] * vd2, acc[q]);
+          }
         }
       }
     }
@@ -387,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (WHITE) acc[q][t] -= 2.0 * gsum * av[q][t];
-        actb[(16 * ib + g + 4 * t) * 16 + c] = acc[q][t];
+        actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
       }
     }
   }
@@ -397,15 +437,20 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
 #pragma unroll
   for (int q = 0; q < NQ; ++q) bb[q] = (d4){0, 0, 0, 0};
   if (act) {
+    if (WHITE || !D4) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-      const double* __restrict__ W = (WHITE ? a.Linv : a.Kinv) + 16 * ib + c + (int64_t)g * Mp;
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll 2
-      for (int kb = (WHITE ? ib : 0); kb < MPB; ++kb) {
+        for (int kb = (WHITE ? ib : 0); kb < MPB; ++kb)
+          bb[q] = WHITE ? chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, bb[q])
+                        : chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, ib, kb, g, c, bb[q]);
+      }
+    } else {
+#pragma unroll 2
+      for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          bb[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], bb[q]);
+        for (int q = 0; q < NQ; ++q) bb[q] = chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, bb[q]);
       }
     }
   }

@@ -18,7 +18,7 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
 struct LayerDev {
   int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, pad0;
   int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
-  double *Zp, *Zs, *hyp, *Tp, *qmu, *qmu4;
+  double *Zp, *Zs, *hyp, *Tp, *TpT, *qmu, *qmu4;
   double *Kp, *Linv, *LinvT, *Kinv, *scal;
   double *V, *nL, *Sd, *klv;
   double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
@@ -164,6 +164,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.Zs = b.take<double>(Mp * d.D_in);
     v.hyp = b.take<double>(HYP_ILS + 2 * d.D_in + 8);
     v.Tp = b.take<double>(d.D_out * MM);
+    v.TpT = b.take<double>(d.D_out * MM);
     v.qmu = b.take<double>(Mp * d.D_out);
     v.qmu4 = b.take<double>(Mp * v.DP4);
     v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.Kinv = b.take<double>(MM);
@@ -260,6 +261,7 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
   for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
     const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
     v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+    v.TpT[idx] = (j < M && i <= j) ? theta[v.off_q_sqrt + ((int64_t)d * M + j) * M + i] : 0.0;
   }
   for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
     v.qmu[idx] = (idx / v.D_out < M) ? theta[v.off_q_mu + idx] : 0.0;
@@ -1036,7 +1038,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     LayerFwdArgs a{};
     a.X = Xin; a.Rin = Rin; a.rep = rep;
     a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
-    a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+    a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.TpT = v.TpT; a.qmu = v.qmu;
     a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
     a.jitter = m->desc.jitter;
     a.n_inner = n;
@@ -1169,7 +1171,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipGetLastError());
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
-    b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.Sd = v.Sd; b.qmu4 = v.qmu4;
+    b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
     b.Asave = St.A; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = St.E; b.GW = St.GW;
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
     b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
@@ -1295,7 +1297,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   LayerFwdArgs a{};
   a.X = X; a.Rin = n; a.rep = 1;
   a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
-  a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.qmu = v.qmu;
+  a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.TpT = v.TpT; a.qmu = v.qmu;
   a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
   a.jitter = m->desc.jitter;
   a.n_inner = n;

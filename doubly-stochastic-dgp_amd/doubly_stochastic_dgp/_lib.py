@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdsdgp.so")
+# DSDGP_LIB_PATH: development override (A/B builds of the kernels); the shipped library is csrc/libdsdgp.so
+_LIB_PATH = os.environ.get("DSDGP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libdsdgp.so")
 
 DSDGP_MAX_LAYERS = 16
 KERN_RBF, KERN_MATERN52 = 0, 1

@@ -118,6 +118,9 @@ class Engine:
                 A = np.asarray(layer.mean_function.A._value, dtype=np.float64)
                 if A.shape != (Din, Dout):
                     raise ValueError("Linear mean function has the wrong shape")
+                if layer.mean_function.A.trainable:
+                    raise NotImplementedError("a trainable Linear mean function is not on the built path: "
+                                              "init_layers_linear fixes it (layer_initializations.py:41-42)")
                 tA = self.ctx.to_device(A)
                 self._mean_A.append(tA)
                 ld.mean_A = tA.data_ptr()

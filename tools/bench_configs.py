@@ -29,7 +29,12 @@ CONFIGS = [
 ]
 
 
-def run(cfg):
+def build(cfg_id):
+    """(model, step) of config `cfg_id` (1-based) without timing — used by tools/ab_kernels.py."""
+    return _build(CONFIGS[cfg_id - 1])
+
+
+def _build(cfg):
     rng = np.random.default_rng(0)
     n, D = cfg["n"], cfg["D"]
     if cfg.get("classes"):
@@ -54,6 +59,11 @@ def run(cfg):
             model.engine().natgrad_step(len(model.layers) - 1, ng.gamma, check=False)
         model.train_step(0.01)
 
+    return model, step
+
+
+def run(cfg):
+    model, step = _build(cfg)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
