@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   constexpr bool D4 = (NW >= 8);
+  constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   constexpr bool D4 = (NW >= 8);
+  constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     const double vd2 = 2.0 * vd;
     if (act) {
       const double* __restrict__ Sd = a.Sd + (int64_t)d * Mp * Mp;
-      if constexpr (D4) {
+      if constexpr (ILV) {
         // y_d = S_d a for this wave's row blocks (the NQ chains interleaved), then abar += 2 vbar_d(column) * y_d
         d4 y[NQ];
 #pragma unroll
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
 #pragma unroll
   for (int q = 0; q < NQ; ++q) bb[q] = (d4){0, 0, 0, 0};
   if (act) {
-    if (WHITE || !D4) {
+    if (WHITE || !ILV) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
