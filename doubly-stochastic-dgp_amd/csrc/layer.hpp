@@ -76,4 +76,4 @@ size_t layer_fwd_lds_bytes(int Mp, int D_in);
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
 int sm_chain_enabled();
-int64_t sm_hyp_parts(int64_t ld, int Mp);   // number of hyp_part rows the split-M backward writes for ld padded rows
+int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in);   // number of hyp_part rows the split-M backward writes for ld padded rows

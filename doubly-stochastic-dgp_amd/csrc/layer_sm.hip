@@ -122,7 +122,7 @@ template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
-  constexpr bool D4 = (NW >= 8);
+  constexpr bool D4 = (MPB >= 32);
   constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -347,7 +347,7 @@ template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
-  constexpr bool D4 = (NW >= 8);
+  constexpr bool D4 = (MPB >= 32);
   constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -574,8 +574,17 @@ int sm_chain_enabled() {
   static const int on = getenv("DSDGP_CHAIN_SM") ? atoi(getenv("DSDGP_CHAIN_SM")) : 1;
   return on;
 }
-static inline int sm_nw(int Mp) { return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : 4); }
-int64_t sm_hyp_parts(int64_t ld, int Mp) { return (int64_t)sm_nw(Mp) * ceil_div(ld, 16); }
+// waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
+// one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
+#define SM_SMALL_BLOCKS 160
+static inline bool sm_small(int Mp, int64_t nblk, int D_in) {
+  static const int on = getenv("DSDGP_SM_SMALL") ? atoi(getenv("DSDGP_SM_SMALL")) : 1;
+  return on && (Mp == 128 || Mp == 256) && nblk <= SM_SMALL_BLOCKS && D_in <= XCH;
+}
+static inline int sm_nw(int Mp, int64_t nblk, int D_in) {
+  return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : (sm_small(Mp, nblk, D_in) ? 8 : 4));
+}
+int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in) * ceil_div(ld, 16); }
 
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
@@ -627,11 +636,26 @@ static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
       return DSDGP_ERR_UNSUPPORTED;                                                    \
   }
 
+#define SM_SMALL_CASE(FN, MPB, ARGS)                                                                       \
+  if (Mp == MPB * 16) {                                                                                    \
+    if (kern_kind == DSDGP_KERN_RBF)                                                                       \
+      return white ? FN<MPB, 8, DSDGP_KERN_RBF, true, false> ARGS : FN<MPB, 8, DSDGP_KERN_RBF, false, false> ARGS; \
+    return white ? FN<MPB, 8, DSDGP_KERN_MATERN52, true, false> ARGS : FN<MPB, 8, DSDGP_KERN_MATERN52, false, false> ARGS; \
+  }
+
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white) {
   const bool wide = a.D_in > XCH;
+  if (sm_small(Mp, ceil_div(a.Rin, 16), a.D_in)) {
+    SM_SMALL_CASE(fwd_sm_go, 8, (ctx, a))
+    SM_SMALL_CASE(fwd_sm_go, 16, (ctx, a))
+  }
   SM_DISPATCH(fwd_sm_go, (ctx, a))
 }
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
   const bool wide = a.D_in > XCH;
+  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in)) {
+    SM_SMALL_CASE(bwd_sm_go, 8, (ctx, a))
+    SM_SMALL_CASE(bwd_sm_go, 16, (ctx, a))
+  }
   SM_DISPATCH(bwd_sm_go, (ctx, a))
 }

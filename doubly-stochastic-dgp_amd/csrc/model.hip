@@ -205,7 +205,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
-    S.hyp_part = b.take<double>((size_t)(sm_hyp_parts(S.ld_max, v.Mp) + 16) * (d.D_in + 2));
+    S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 3);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -1130,7 +1130,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
     red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp) : (int)nch, 0, 1, 0, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0});
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
