@@ -120,10 +120,11 @@ int gemm_plan(GemmProblem* host, int nprob) {
   return total;
 }
 
-int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles) {
+int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream) {
   if (total_tiles <= 0) return DSDGP_OK;
-  ProfScope ps(ctx, "gemm");
-  hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, ctx->stream, dev, nprob);
+  hipStream_t st = stream ? stream : ctx->stream;
+  ProfScope ps(ctx, "gemm", st);
+  hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

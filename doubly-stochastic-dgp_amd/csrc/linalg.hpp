@@ -30,7 +30,7 @@ struct PotrfItem {
 // Fills tile_start/tiles_* of `host` problems, returns the total number of 64x64 tiles.
 int gemm_plan(GemmProblem* host, int nprob);
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
-int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles);
+int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream = nullptr);
 // n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant
 int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max);
 // batched inverse of padded lower-triangular matrices (n multiple of 16, identity pad), one workgroup each

@@ -85,6 +85,11 @@ struct dsdgp_model {
   double* scal4;       // internal copy of out
   PotrfItem* potrf_items;
   GemmProblem *gp_fwd, *gp_bwd1, *gp_bwd2, *gp_w1, *gp_w2, *gp_w3;
+  GemmProblem* gp_pt;   // P_d T_d (the only KL/q_sqrt GEMM that depends on the backward pass)
+  int n_pt = 0, t_pt = 0;
+  hipEvent_t ev_fork, ev_prep_side, ev_z;
+  bool prepared_grad = false;  // the last prepare also produced U_d, n, U_d U_d^T
+  bool side_pending = false;   // parameter-only work (Ku^-1, S_d, KL, U, UU) still running on the side stream
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
   const double* sample_w = nullptr;   // DGP_Quad quadrature weights (borrowed), NULL = Monte-Carlo mean
   int sample_w_S = 0;
@@ -143,6 +148,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->potrf_items = b.take<PotrfItem>(D.L);
   m->gp_fwd = b.take<GemmProblem>(4 * D.L);
   m->gp_bwd1 = b.take<GemmProblem>(3 * D.L);
+  m->gp_pt = b.take<GemmProblem>(D.L);
   m->gp_bwd2 = b.take<GemmProblem>(D.L);
   m->gp_wz = b.take<GemmProblem>(D.L);
   m->gp_w1 = b.take<GemmProblem>(2 * D.L); m->gp_w2 = b.take<GemmProblem>(D.L); m->gp_w3 = b.take<GemmProblem>(D.L);
@@ -827,7 +833,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   const int L = desc->L;
   std::vector<LayerDev> ld(L);
   std::vector<PotrfItem> items(L);
-  std::vector<GemmProblem> gf, g1, g2, w1, w2, w3, wz;
+  std::vector<GemmProblem> gf, g1, g2, w1, w2, w3, wz, gpt;
   int64_t asm_elems = 0;
   for (int l = 0; l < L; ++l) {
     const LayerDev& v = m->L[l].dev;
@@ -850,7 +856,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     fill_gemm(P, v.Kinv, v.qmu4, v.n4, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // n
     g1.push_back(P);
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
-    g1.push_back(P);
+    gpt.push_back(P);
     fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);              // U_d U_d^T
     g2.push_back(P);
     if (v.D_in > WIDE_DIN) {
@@ -899,6 +905,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   }
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
   m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
+  m->n_pt = (int)gpt.size(); m->t_pt = gemm_plan(gpt.data(), m->n_pt);
+  DS_HIP(hipMemcpyAsync(m->gp_pt, gpt.data(), gpt.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
   m->n_bwd2 = (int)g2.size(); m->t_bwd2 = gemm_plan(g2.data(), m->n_bwd2);
   m->n_wz = (int)wz.size();
   if (m->n_wz) {
@@ -937,6 +945,9 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   for (int l = 0; l < L; ++l) DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_prep_side, hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_z, hipEventDisableTiming));
   m->prepared = false;
   m->plan_n = -1;
   m->plan_S = -1;
@@ -950,6 +961,7 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     hipStreamSynchronize(m->side);
     for (int l = 0; l < m->desc.L; ++l) hipEventDestroy(m->ev_bwd[l]);
     hipEventDestroy(m->ev_side);
+    hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
     hipStreamDestroy(m->side);
     for (int l = 0; l < m->desc.L; ++l) {
       bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngS); bigchol_free(m->L[l].big_ngT);
@@ -959,9 +971,34 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
   return DSDGP_OK;
 }
 
-static int prepare_async(dsdgp_model* m) {
+// Side-stream overlap pays for its cross-stream events (a few microseconds each) only when the kernels are long enough:
+// tiny models (cfg 1: 100 rows, M = 50) are launch-latency-bound and run 40 % faster on a single stream.
+static bool overlap_on(const dsdgp_model* m, int64_t n, int S) {
+  const char* no = getenv("DSDGP_NO_OVERLAP");   // read per call so that a profiler can serialise the kernels
+  if (!m->overlap || (no && atoi(no))) return false;
+  int mp_max = 0;
+  for (int l = 0; l < m->desc.L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
+  return n * S * (int64_t)mp_max >= (int64_t)1 << 20;
+}
+
+// main stream waits for the parameter-only side work of the last prepare (no-op when nothing is pending)
+static int join_prep(dsdgp_model* m) {
+  if (m->side_pending) {
+    DS_HIP(hipStreamWaitEvent(m->ctx->stream, m->ev_prep_side, 0));
+    m->side_pending = false;
+  }
+  return DSDGP_OK;
+}
+
+// Parameter transforms, Ku, its Cholesky / inverse factor (main stream: the forward chain needs exactly these), then the
+// parameter-only rest — Ku^-1, S_d, Lu^-1 q_sqrt, KL and, for a gradient step, U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu and
+// U_d U_d^T — which nothing needs before the backward pass / the final reduction: with `side` it runs on the side stream
+// concurrently with the forward layers and the caller joins (join_prep) where it is first consumed.
+// (`side` = run that part on the side stream.)
+static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = false) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
+  DS_TRY(join_prep(m));
   hipLaunchKernelGGL(k_prep, dim3(64, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev, m->lik_const,
                      m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0);
   hipLaunchKernelGGL(k_kuu_pad, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
@@ -976,11 +1013,26 @@ static int prepare_async(dsdgp_model* m) {
   } else {
     DS_TRY(potrf_launch(ctx, m->potrf_items, L, mp_max));
   }
-  DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd));
-  hipLaunchKernelGGL(k_kl_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
-  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, ctx->stream, m->layers_dev, L);
+  hipStream_t st = ctx->stream;
+  if (side) {
+    DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));
+    DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    st = m->side;
+  }
+  DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
+  hipLaunchKernelGGL(k_kl_part, dim3(NPART, L), dim3(256), 0, st, m->layers_dev);
+  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, st, m->layers_dev, L);
   DS_HIP(hipGetLastError());
+  if (with_grad && !m->desc.white) {
+    DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1, st));
+    DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2, st));
+  }
+  if (side) {
+    DS_HIP(hipEventRecord(m->ev_prep_side, m->side));
+    m->side_pending = true;
+  }
   m->prepared = true;
+  m->prepared_grad = with_grad;
   return DSDGP_OK;
 }
 
@@ -1013,9 +1065,9 @@ extern "C" int dsdgp_model_prepare(dsdgp_model* m, int* info) {
   return read_info(m, info);
 }
 
-static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out) {
+static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out, hipStream_t st = nullptr) {
   const int nb = (int)std::min<int64_t>(2048, ceil_div((count + 1) / 2, 256));
-  hipLaunchKernelGGL(k_randn, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, seed, stream, count, out);
+  hipLaunchKernelGGL(k_randn, dim3(nb > 0 ? nb : 1), dim3(256), 0, st ? st : ctx->stream, seed, stream, count, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -1023,7 +1075,7 @@ static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t c
 // dgp.py:61-76 propagate
 static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, const double* const* zs,
                           const int64_t* zstride, uint64_t seed, bool save, bool need_last_F, double* const* Fs,
-                          double* const* Fmeans, double* const* Fvars) {
+                          double* const* Fmeans, double* const* Fvars, bool z_ready = false) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_CHECK_ARG(n > 0 && n <= m->n_max && S > 0 && S <= m->s_max);
@@ -1048,7 +1100,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
         a.z = zs[l];
         a.zs_s = zstride[3 * l]; a.zs_n = zstride[3 * l + 1]; a.zs_d = zstride[3 * l + 2];
       } else {
-        DS_TRY(randn_async(ctx, seed, (uint64_t)l, (int64_t)S * n * v.D_out, St.zbuf));
+        if (!(z_ready && !last)) DS_TRY(randn_async(ctx, seed, (uint64_t)l, (int64_t)S * n * v.D_out, St.zbuf));
         a.z = St.zbuf;
         a.zs_s = n * v.D_out; a.zs_n = v.D_out; a.zs_d = 1;
       }
@@ -1156,8 +1208,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(ensure_plan(m, n, S));
-  const char* no = getenv("DSDGP_NO_OVERLAP");   // read per call so that a profiler can serialise the kernels
-  const bool overlap = m->overlap && !(no && atoi(no));
+  const bool overlap = overlap_on(m, n, S);
+  DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
   for (int l = L - 1; l >= 0; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1204,8 +1256,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
     DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
   } else {
-    DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1));
-    DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2));
+    DS_TRY(gemm_launch(ctx, m->gp_pt, m->n_pt, m->t_pt));
   }
   hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
   if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
@@ -1227,8 +1278,22 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   }
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
-  DS_TRY(prepare_async(m));
-  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr));
+  // fresh N(0,1) draws do not depend on the parameters: generate them on the side stream while Ku is factorised
+  bool z_side = false;
+  const bool ovl = overlap_on(m, n, S);
+  if (ovl) {
+    DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));     // after the previous step's readers of zbuf
+    DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    for (int l = 0; l + 1 < L; ++l)
+      if (!(zs && zs[l])) {
+        DS_TRY(randn_async(ctx, seed, (uint64_t)l, (int64_t)S * n * m->L[l].dev.D_out, m->L[l].zbuf, m->side));
+        z_side = true;
+      }
+    if (z_side) DS_HIP(hipEventRecord(m->ev_z, m->side));
+  }
+  DS_TRY(prepare_async(m, with_grad != 0, ovl));
+  if (z_side) DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_z, 0));
+  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side));
   LayerState& last = m->L[L - 1];
   const int DY = last.dev.D_out;
   const int64_t total = (int64_t)S * n * DY;
@@ -1255,6 +1320,7 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   if (with_grad) {
     DS_TRY(backward_layers(m, n, S, kl_weight));
   }
+  DS_TRY(join_prep(m));   // KL values
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, L, m->lik_part, nblocks, w, kl_weight,
                      m->lik_const, m->grad, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, with_grad, out);
   DS_HIP(hipGetLastError());
