@@ -560,10 +560,17 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
   }
   const int64_t i0 = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
   if (i0 >= J.count) return;
-  int64_t i = i0;
-  if (J.sym_n > 0) {   // mirror the tiles above the diagonal from their transposes
+  int64_t i = i0, o = i0;
+  if (J.sym_n > 0) {
+    // tiles above the diagonal were not computed: the thread that would own element (lr, lc) of upper tile (ti, tj) sums the
+    // SAME local element of the lower tile (tj, ti) — coalesced partial reads — and stores it at the transposed position
     const int64_t r = i0 / J.sym_n, cc = i0 % J.sym_n;
-    if (cc / J.sym_tile > r / J.sym_tile) i = cc * J.sym_n + r;
+    const int64_t ti = r / J.sym_tile, tj = cc / J.sym_tile;
+    if (tj > ti) {
+      const int64_t lr = r % J.sym_tile, lc = cc % J.sym_tile;
+      i = (tj * J.sym_tile + lr) * J.sym_n + ti * J.sym_tile + lc;
+      o = (ti * J.sym_tile + lc) * J.sym_n + tj * J.sym_tile + lr;
+    }
   }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.count + i];
   }
   for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.count + i];
-  J.out[i0] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  J.out[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu

@@ -1,0 +1,9 @@
+#!/bin/bash
+for v in base w5; do
+  if [ $v = base ]; then unset DSDGP_LIB_PATH; else export DSDGP_LIB_PATH=$PWD/tools/bin/libdsdgp_$v.so; fi
+  echo "== variant $v"
+  timeout 600 python tools/ab_kernels.py 2 2>&1 | grep "^{"
+  timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-130
+done
+unset DSDGP_LIB_PATH
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gradient or white or full_size or natgrad" 2>&1 | tail -1
