@@ -120,6 +120,8 @@ struct Bump {
 };
 
 static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
+  static const int scale = getenv("DSDGP_WGRAD_TARGET") ? atoi(getenv("DSDGP_WGRAD_TARGET")) : 1024;   // tuning knob (tasks for the big jobs)
+  target_tasks = (int)((int64_t)target_tasks * scale / 1024);
   int ns = target_tasks / (tiles_per_split > 0 ? tiles_per_split : 1);
   if (ns < 1) ns = 1;
   int64_t cap = nchunks / 4;
@@ -267,7 +269,8 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
   for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
     const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
     v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
-    v.TpT[idx] = (j < M && i <= j) ? theta[v.off_q_sqrt + ((int64_t)d * M + j) * M + i] : 0.0;
+    if (Mp >= 512)   // only the row-oriented (32-byte load) chain kernels of the large-M path read q_sqrt^T
+      v.TpT[idx] = (j < M && i <= j) ? theta[v.off_q_sqrt + ((int64_t)d * M + j) * M + i] : 0.0;
   }
   for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
     v.qmu[idx] = (idx / v.D_out < M) ? theta[v.off_q_mu + idx] : 0.0;
