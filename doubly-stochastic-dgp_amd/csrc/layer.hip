@@ -485,6 +485,36 @@ int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kin
 // loads 4 consecutive r (32 B) of one row, and the t-th of them is the k-operand of the t-th MFMA, so a 16-row x
 // 16-r fragment costs two 16-B loads per lane and no LDS.
 // ------------------------------------------------------------------------------------------------------
+// K loop of one (split, tile) task; GUARD: only the first njv of the NJ column blocks of Q exist (thin products A MB^T,
+// GW [X|1]^T ride in the same launch as the M x M products, their Q has 16..DinP16 rows)
+template <int NI, int NJ, bool GUARD>
+__device__ __forceinline__ void wgrad_loop(const double* __restrict__ Pp, const double* __restrict__ Qp,
+                                           const double* __restrict__ scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
+                                           int njv, d4 (&acc)[NI][NJ]) {
+  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
+    const int64_t rb = ch * 16;
+    d4 pa[NI], qb[NJ];
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4*>(Pp + (int64_t)16 * ii * ld + rb);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4*>(Qp + (int64_t)16 * jj * ld + rb);
+    if (scale) {
+      const d4 sc = *reinterpret_cast<const d4*>(scale + rb + 4 * g);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (!GUARD || jj < njv) qb[jj] *= sc;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+          if (!GUARD || jj < njv) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
+  }
+}
+
 template <int NI, int NJ>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
                                                int64_t Rp, int total_tasks) {
@@ -510,6 +540,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
   }
   const int64_t nch = Rp / 16;
   const int64_t c_lo = split * nch / nsplit, c_hi = (split + 1) * nch / nsplit;
+  const int njv = (J.qrows16 - NJ * tile_j < NJ) ? J.qrows16 - NJ * tile_j : NJ;    // column blocks of this tile that exist
   d4 acc[NI][NJ];
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii)
@@ -517,34 +548,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
     for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
   const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
   const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
-  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
-    const int64_t rb = ch * 16;
-    d4 pa[NI], qb[NJ];
-#pragma unroll
-    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4*>(Pp + (int64_t)16 * ii * ld + rb);
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) qb[jj] = *reinterpret_cast<const d4*>(Qp + (int64_t)16 * jj * ld + rb);
-    if (J.scale) {
-      const d4 sc = *reinterpret_cast<const d4*>(J.scale + rb + 4 * g);
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) qb[jj] *= sc;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int ii = 0; ii < NI; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
-  }
+  if (njv == NJ)
+    wgrad_loop<NI, NJ, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else
+    wgrad_loop<NI, NJ, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
   const int rowsP = 16 * NI * J.ti;
   double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
+      if (jj < njv) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] = acc[ii][jj][t];
+        for (int t = 0; t < 4; ++t)
+          o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] = acc[ii][jj][t];
+      }
 }
 
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,

@@ -60,10 +60,11 @@ struct WgradJob {
   const double* Q;
   const double* scale;  // or NULL
   double* out;          // [nsplit][rowsP][ldo]
-  int32_t ti, tj;       // tiles in i / j (tile = 16*NI x 16*NJ)
+  int32_t ti, tj;       // tiles in i / j (tile = 16*NI x 16*NJ; the last j tile may be partial, see qrows16)
   int32_t ldo;
   int32_t task_start;
-  int32_t sym, pad;     // sym: P == Q (symmetric result): only tiles with tile_j <= tile_i are computed
+  int32_t sym;          // P == Q (symmetric result): only tiles with tile_j <= tile_i are computed
+  int32_t qrows16;      // rows of Q / 16 (= columns of the result / 16)
 };
 
 int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);

@@ -212,7 +212,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.nsplit_big_max = choose_nsplit(ti * tj_big + d.D_out * (ti * (ti + 1) / 2), S.ld_max / 16, 1024);
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
-    S.part_thin = b.take<double>((size_t)S.nsplit_thin_max * Mp * (v.DP16 + v.DinP16));
+    S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mp * (v.DP16 + v.DinP16));
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 3);
     S.ng_gp = b.take<GemmProblem>(5);
@@ -1178,18 +1178,20 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
       J.out = St.part_big + (int64_t)j * ns * MM;
       J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
-      J.sym = (j >= 1) ? 1 : 0; J.pad = 0;                 // P_d = sum_r v a a^T is symmetric; G = E A^T is not
+      J.sym = (j >= 1) ? 1 : 0; J.qrows16 = v.Mp / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
       start += ns * (J.sym ? ti * (ti + 1) / 2 : ti * ti);
       red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16 * NI});
     }
-    St.tot_big = start;
-    int nt = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), nch, 512);
-    if (nt > St.nsplit_thin_max) nt = St.nsplit_thin_max;
+    // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
+    const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI), nt = ns;
     St.ns_thin = nt;
-    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, v.DP16 / 16, v.DP16, 0, 0, 0};
-    jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, v.DinP16 / 16,
-                                 v.DinP16, nt * ti * (v.DP16 / 16), 0, 0};
-    St.tot_thin = jobs[v.D_out + 2].task_start + nt * ti * (v.DinP16 / 16);
+    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, tjq, v.DP16, start, 0, v.DP16 / 16};
+    start += nt * ti * tjq;
+    jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, tjz, v.DinP16, start, 0,
+                                 v.DinP16 / 16};
+    start += nt * ti * tjz;
+    St.tot_big = start;
+    St.tot_thin = 0;
     red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0});
@@ -1250,8 +1252,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
     }
-    DS_TRY(wgrad_launch(ctx, St.wj, 1 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
-    DS_TRY(wgrad_launch(ctx, St.wj + 1 + v.D_out, 2, St.tot_thin, St.ns_thin, ld, ld, NI, 1, ws));
+    DS_TRY(wgrad_launch(ctx, St.wj, 3 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
   }
   if (overlap) {
     DS_HIP(hipEventRecord(m->ev_side, m->side));
