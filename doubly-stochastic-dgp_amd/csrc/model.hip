@@ -16,7 +16,7 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
 // device-resident per-layer descriptor shared by all the small per-layer kernels
 // ------------------------------------------------------------------------------------------------------
 struct LayerDev {
-  int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, pad0;
+  int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, hyp_parts;   // rows of hyp2part per backward: > 0 written by k_asm_kbar (folded), < 0: -NPART rows by k_asm_hyp_part
   int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
   double *Zp, *Zs, *hyp, *Tp, *TpT, *qmu, *qmu4;
   double *Kp, *Linv, *LinvT, *Kinv, *scal;
@@ -95,6 +95,10 @@ struct dsdgp_model {
   int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
+  bool need_hyp_part = false;
+  // arguments of the pending k_finalize (value + likelihood-variance gradient): launched on the side stream beside the
+  // backward chain when streams overlap, otherwise on the main stream after it
+  struct { int nblocks; double w, kl_weight; int with_grad; double* out; bool done; } fin;   // some layer does not fold its Ku-side hyper-parameter partials into k_asm_kbar
   RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
   int rjobs_cap, n_red, red_blocks;
   int64_t plan_n;
@@ -164,7 +168,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     LayerDev& v = S.dev;
     v.M = d.M; v.Mp = pad_M(d.M); v.D_in = d.D_in; v.D_out = d.D_out;
     v.DP4 = (int)round_up(d.D_out, 4); v.DP16 = (int)round_up(d.D_out, 16); v.DinP16 = (int)round_up(d.D_in + 1, 16);
-    v.kern_kind = d.kern_kind; v.ard = d.ard; v.has_white = d.has_white; v.white = D.white; v.pad0 = 0;
+    v.kern_kind = d.kern_kind; v.ard = d.ard; v.has_white = d.has_white; v.white = D.white; v.hyp_parts = -NPART;
     v.off_Z = d.off_Z; v.off_q_mu = d.off_q_mu; v.off_q_sqrt = d.off_q_sqrt;
     v.off_kvar = d.off_kvar; v.off_kls = d.off_kls; v.off_wvar = d.off_wvar;
     const size_t Mp = v.Mp, MM = Mp * Mp;
@@ -192,7 +196,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.ngLAinvT = b.take<double>(d.D_out * MM); v.ngSplus = b.take<double>(d.D_out * MM);
     v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
-    v.hyp2part = b.take<double>(64 * (d.D_in + 2));
+    v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
     v.R2 = b.take<double>(MM);
     v.Zp1 = b.take<double>(Mp * v.DinP16); v.WZ = b.take<double>(Mp * v.DinP16);
     S.R_max = (int64_t)m->s_max * m->n_max;
@@ -587,11 +591,16 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
 
 // dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu
 // then wm = Kbar ∘ dk/dr2 and wk = Kbar ∘ k / variance for the Gram adjoint.
-__global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
+// FOLD (D_in <= 32 and one element per thread): the Ku-side hyper-parameter partial sums of k_asm_hyp_part are taken here,
+// one row of hyp2part per workgroup, while kbar / wm / wk are still in registers (one launch less on the step's tail).
+__global__ __launch_bounds__(256) void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
+  __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.y];
-  const int Mp = v.Mp, M = v.M;
+  const int Mp = v.Mp, M = v.M, Din = v.D_in;
   const double* G = v.bigred;
-  const double* ils = v.hyp + HYP_ILS;
+  const bool fold = v.hyp_parts > 0;
+  double a_sum = 0.0, tr_sum = 0.0, wm_keep = 0.0;
+  int i_keep = 0, j_keep = 0;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Mp * Mp; idx += gridDim.x * blockDim.x) {
     const int i = idx / Mp, j = idx % Mp;
     double kb = 0.0, wm = 0.0, wk = 0.0;
@@ -616,10 +625,26 @@ __global__ void k_asm_kbar(const LayerDev* __restrict__ layers, double kl_w) {
         kern_val_grad<DSDGP_KERN_MATERN52>(r2, v.hyp[HYP_VAR], k, dk);
       wm = kb * dk;
       wk = kb * k / v.hyp[HYP_VAR];
+      a_sum += wk;
+      if (i == j) tr_sum += kb;
+      wm_keep = wm; i_keep = i; j_keep = j;
     }
     v.Kbar[idx] = kb;
     v.wm[idx] = wm;
     v.wk[idx] = wk;
+  }
+  if (!fold) return;
+  double* out = v.hyp2part + (int64_t)blockIdx.x * (Din + 2);
+  a_sum = block_sum_256(a_sum, sh);
+  tr_sum = block_sum_256(tr_sum, sh);
+  if (threadIdx.x == 0) {
+    out[0] = a_sum;
+    out[1] = tr_sum;
+  }
+  for (int q = 0; q < Din; ++q) {
+    const double df = v.Zp[i_keep * Din + q] - v.Zp[j_keep * Din + q];
+    const double sq = block_sum_256(wm_keep * df * df, sh);
+    if (threadIdx.x == 0) out[2 + q] = sq;
   }
 }
 
@@ -695,6 +720,7 @@ __global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict
   __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.y];
   const int Mp = v.Mp, M = v.M, Din = v.D_in;
+  if (v.hyp_parts > 0) return;   // folded into k_asm_kbar
   const int t0 = blockIdx.x * 256 + threadIdx.x, nth = NPART * 256;
   double* out = v.hyp2part + (int64_t)blockIdx.x * (Din + 2);
   double a = 0.0, tr = 0.0;
@@ -739,7 +765,7 @@ __global__ __launch_bounds__(256) void k_asm_hyp_final(const LayerDev* __restric
   const double* ils = v.hyp + HYP_ILS;
   if (threadIdx.x == 0) {
     double a = 0.0, tr = 0.0;
-    for (int b = 0; b < NPART; ++b) {
+    for (int b = 0; b < abs(v.hyp_parts); ++b) {
       a += v.hyp2part[b * (Din + 2)];
       tr += v.hyp2part[b * (Din + 2) + 1];
     }
@@ -749,7 +775,7 @@ __global__ __launch_bounds__(256) void k_asm_hyp_final(const LayerDev* __restric
   double iso = 0.0;
   for (int q = threadIdx.x; q < Din; q += 256) {
     double s = 0.0;
-    for (int b = 0; b < NPART; ++b) s += v.hyp2part[b * (Din + 2) + 2 + q];
+    for (int b = 0; b < abs(v.hyp_parts); ++b) s += v.hyp2part[b * (Din + 2) + 2 + q];
     const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
     if (v.ard)
       grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
@@ -912,6 +938,13 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
         DS_TRY(bigchol_build(ctx, St.big_ngT, v.ngTI, v.ngTinv, nullptr, nullptr, v.D_out, MM, 0, Mp, v.M, nullptr, true));
       }
     }
+  }
+  for (int l = 0; l < L; ++l) {
+    LayerDev& v = m->L[l].dev;
+    const bool fold = v.D_in <= WIDE_DIN && (int64_t)m->kuu_blocks * 256 >= (int64_t)v.Mp * v.Mp;
+    v.hyp_parts = fold ? m->kuu_blocks : -NPART;
+    ld[l].hyp_parts = v.hyp_parts;
+    if (!fold) m->need_hyp_part = true;
   }
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
   m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
@@ -1216,6 +1249,15 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
   return DSDGP_OK;
 }
 
+static int launch_finalize(dsdgp_model* m, hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, m->layers_dev, m->desc.L, m->lik_part, m->fin.nblocks, m->fin.w,
+                     m->fin.kl_weight, m->lik_const, m->grad,
+                     m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.with_grad, m->fin.out);
+  DS_HIP(hipGetLastError());
+  m->fin.done = true;
+  return DSDGP_OK;
+}
+
 static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
@@ -1251,6 +1293,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
+      if (!m->fin.done) DS_TRY(launch_finalize(m, m->side));   // needs the likelihood partials (main, before ev_bwd) and KL (side)
     }
     DS_TRY(wgrad_launch(ctx, St.wj, 3 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
   }
@@ -1272,7 +1315,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
   if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
   hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
-  hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
+  if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
   hipLaunchKernelGGL(k_asm_hyp_final, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -1328,13 +1371,15 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
     hipLaunchKernelGGL(k_partial_sum, dim3(nblocks), dim3(256), 0, ctx->stream, last.F, R, m->lik_part);
   }
   DS_HIP(hipGetLastError());
+  m->fin.nblocks = nblocks; m->fin.w = w; m->fin.kl_weight = kl_weight; m->fin.with_grad = with_grad; m->fin.out = out;
+  m->fin.done = false;
   if (with_grad) {
     DS_TRY(backward_layers(m, n, S, kl_weight));
   }
-  DS_TRY(join_prep(m));   // KL values
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, L, m->lik_part, nblocks, w, kl_weight,
-                     m->lik_const, m->grad, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, with_grad, out);
-  DS_HIP(hipGetLastError());
+  if (!m->fin.done) {
+    DS_TRY(join_prep(m));   // KL values
+    DS_TRY(launch_finalize(m, ctx->stream));
+  }
   m->prepared = true;
   return DSDGP_OK;
 }
