@@ -19,6 +19,27 @@ extern "C" int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols
   return DSDGP_OK;
 }
 
+// X and Y rows of one minibatch in one launch (Minibatch(X), Minibatch(Y) share their seed, dgp.py:51-52)
+__global__ void k_gather_rows2(const double* __restrict__ a, int64_t ca, double* __restrict__ da, const double* __restrict__ b,
+                               int64_t cb, double* __restrict__ db, const int64_t* __restrict__ idx, int64_t n) {
+  const int64_t ct = ca + cb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * ct; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ct, j = i % ct;
+    if (j < ca)
+      da[r * ca + j] = a[idx[r] * ca + j];
+    else
+      db[r * cb + (j - ca)] = b[idx[r] * cb + (j - ca)];
+  }
+}
+extern "C" int dsdgp_gather_rows2(dsdgp_ctx* ctx, const double* srcX, int64_t colsX, double* dstX, const double* srcY,
+                                  int64_t colsY, double* dstY, const int64_t* idx, int64_t n, int64_t idx_offset) {
+  DS_CHECK_ARG(ctx && srcX && srcY && dstX && dstY && idx && n > 0 && colsX > 0 && colsY > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(n * (colsX + colsY), 256));
+  hipLaunchKernelGGL(k_gather_rows2, dim3(nb), dim3(256), 0, ctx->stream, srcX, colsX, dstX, srcY, colsY, dstY, idx + idx_offset, n);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
 // mode 0: mean_s variational expectation ; mode 1: logsumexp_s predictive log density - log S
 __global__ void k_gauss_over_samples(const double* __restrict__ mean, const double* __restrict__ var,
                                      const double* __restrict__ Y, int64_t n, int S, int DY, double s2, int mode,

@@ -232,10 +232,10 @@ __device__ __forceinline__ double softplus_d(double x) { return x > 0 ? x + log1
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // parameter transforms + padding (LowerTriangular / positive transforms of layers.py:150 and [UPSTREAM] kernels)
-__global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restrict__ layers, double* __restrict__ lik_const,
-                       int64_t off_lik, int lik_gauss) {
-  const LayerDev v = layers[blockIdx.y];
-  const int tid0 = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+#define PREP_BLOCKS 64
+__device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, double* __restrict__ lik_const, int64_t off_lik,
+                          int lik_gauss, int bx) {
+  const int tid0 = bx * blockDim.x + threadIdx.x, nth = PREP_BLOCKS * blockDim.x;
   if (tid0 == 0) {
     const double rv = theta[v.off_kvar];
     const double var = softplus_d(rv) + SOFTPLUS_LOWER;
@@ -247,7 +247,7 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
     }
     v.hyp[HYP_VAR] = var; v.hyp[HYP_WVAR] = wv; v.hyp[HYP_KDIAG] = var + wv;
     v.hyp[HYP_DVAR] = sigmoid_d(rv); v.hyp[HYP_DWVAR] = dwv;
-    if (blockIdx.y == 0 && lik_gauss) {
+    if (blockIdx.y == 0 && lik_gauss) {   // (grid y = layer)
       const double rl = theta[off_lik];
       lik_const[0] = softplus_d(rl) + SOFTPLUS_LOWER;
       lik_const[1] = sigmoid_d(rl);
@@ -285,41 +285,53 @@ __global__ void k_prep(const double* __restrict__ theta, const LayerDev* __restr
 }
 
 // Ku = K(Z,Z) + (white + jitter) I   (layers.py:171), identity on the padding
-__global__ __launch_bounds__(256) void k_kuu_pad(const LayerDev* __restrict__ layers, double jitter) {
+__device__ void kuu_body(const LayerDev& v, const double* __restrict__ theta, double jitter, int bx, int nbx) {
   // 16 x 16 output tile per workgroup pass; the two 16-row panels of Z are staged through LDS in 32-column chunks so that
   // wide inputs (784-d MNIST layer) read Z coalesced.  Also stores the scaled squared distances for the adjoint (k_asm_kbar).
-  __shared__ double Zi[16][33], Zj[16][33];
-  const LayerDev v = layers[blockIdx.y];
-  const int Mp = v.Mp, nt = Mp / 16, Din = v.D_in;
-  const double* ils = v.hyp + HYP_ILS;
+  // Reads the raw parameters (not k_prep's outputs): both roles run in ONE launch.
+  __shared__ double Zi[16][33], Zj[16][33], ils_s[32];
+  const int Mp = v.Mp, nt = Mp / 16, Din = v.D_in, M = v.M;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  for (int tile = blockIdx.x; tile < nt * nt; tile += gridDim.x) {
+  const double var = softplus_d(theta[v.off_kvar]) + SOFTPLUS_LOWER;
+  const double wvar = v.has_white ? softplus_d(theta[v.off_wvar]) + SOFTPLUS_LOWER : 0.0;
+  for (int tile = bx; tile < nt * nt; tile += nbx) {
     const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
     double r2 = 0.0;
     for (int q0 = 0; q0 < Din; q0 += 32) {
       __syncthreads();
+      if (tid < 32 && q0 + tid < Din) ils_s[tid] = 1.0 / (softplus_d(theta[v.off_kls + (v.ard ? q0 + tid : 0)]) + SOFTPLUS_LOWER);
       for (int e = tid; e < 512; e += 256) {
         const int r = e >> 5, c = e & 31;
         const bool ok = q0 + c < Din;
-        Zi[r][c] = ok ? v.Zp[(int64_t)(i0 + r) * Din + q0 + c] : 0.0;
-        Zj[r][c] = ok ? v.Zp[(int64_t)(j0 + r) * Din + q0 + c] : 0.0;
+        Zi[r][c] = (ok && i0 + r < M) ? theta[v.off_Z + (int64_t)(i0 + r) * Din + q0 + c] : 0.0;
+        Zj[r][c] = (ok && j0 + r < M) ? theta[v.off_Z + (int64_t)(j0 + r) * Din + q0 + c] : 0.0;
       }
       __syncthreads();
       const int qn = min(32, Din - q0);
       for (int c = 0; c < qn; ++c) {
-        const double df = (Zi[ti][c] - Zj[tj][c]) * ils[q0 + c];
+        const double df = (Zi[ti][c] - Zj[tj][c]) * ils_s[c];
         r2 = fma(df, df, r2);
       }
     }
     const int i = i0 + ti, j = j0 + tj;
     double k = (i == j) ? 1.0 : 0.0;
-    if (i < v.M && j < v.M) {
-      k = kern_val_rt(v.kern_kind, r2, v.hyp[HYP_VAR]);
-      if (i == j) k += v.hyp[HYP_WVAR] + jitter;
+    if (i < M && j < M) {
+      k = kern_val_rt(v.kern_kind, r2, var);
+      if (i == j) k += wvar + jitter;
     }
     v.Kp[(int64_t)i * Mp + j] = k;
     v.R2[(int64_t)i * Mp + j] = r2;
   }
+}
+
+// ONE launch for the parameter transforms / padding (first PREP_BLOCKS block columns) and Ku (the rest), grid (x, L)
+__global__ __launch_bounds__(256) void k_prep_kuu(const double* __restrict__ theta, const LayerDev* __restrict__ layers,
+                                                  double* __restrict__ lik_const, int64_t off_lik, int lik_gauss, double jitter) {
+  const LayerDev v = layers[blockIdx.y];
+  if (blockIdx.x < PREP_BLOCKS)
+    prep_body(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x);
+  else
+    kuu_body(v, theta, jitter, blockIdx.x - PREP_BLOCKS, gridDim.x - PREP_BLOCKS);
 }
 
 __device__ double block_sum_256(double x, double* sh) {
@@ -668,10 +680,15 @@ __global__ void k_white_phi(const LayerDev* __restrict__ layers) {
 }
 
 // final assembly of d loss / d theta: elementwise part, grid (blocks, L)
-__global__ void k_asm_params(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w) {
+__device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad);
+__global__ __launch_bounds__(256) void k_asm_params(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w) {
   const LayerDev v = layers[blockIdx.y];
+  if (blockIdx.x == gridDim.x - 1) {   // extra block: hyper-parameter gradients of this layer
+    asm_hyp_final(v, grad);
+    return;
+  }
   const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out;
-  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)(gridDim.x - 1) * blockDim.x;
   const double* ils = v.hyp + HYP_ILS;
   // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
   for (int64_t idx = t0; idx < (int64_t)Dout * M * M; idx += nth) {
@@ -758,9 +775,10 @@ __global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict
     if (threadIdx.x == 0) out[2 + q] = s;
   }
 }
-__global__ __launch_bounds__(256) void k_asm_hyp_final(const LayerDev* __restrict__ layers, double* __restrict__ grad) {
+// kernel hyper-parameter gradients from the partial sums (one workgroup per layer; runs as the LAST block row of
+// k_asm_params — its inputs come from kernels that precede that launch)
+__device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
   __shared__ double sh[4];
-  const LayerDev v = layers[blockIdx.x];
   const int Din = v.D_in;
   const double* ils = v.hyp + HYP_ILS;
   if (threadIdx.x == 0) {
@@ -1042,9 +1060,8 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
-  hipLaunchKernelGGL(k_prep, dim3(64, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev, m->lik_const,
-                     m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0);
-  hipLaunchKernelGGL(k_kuu_pad, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->desc.jitter);
+  hipLaunchKernelGGL(k_prep_kuu, dim3(PREP_BLOCKS + m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
+                     m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter);
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
@@ -1314,9 +1331,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   }
   hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
   if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
-  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
   if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
-  hipLaunchKernelGGL(k_asm_hyp_final, dim3(L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad);
+  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

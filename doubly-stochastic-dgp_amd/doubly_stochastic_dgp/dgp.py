@@ -108,9 +108,9 @@ class DGP_Base(Parameterized):
             idx = ctx.torch.as_tensor(self._minibatch.next_indices()).to(Xd.device)
             off, n = 0, idx.shape[0]
         Xb, Yb = ctx.empty(n, Xd.shape[1]), ctx.empty(n, Yd.shape[1])
-        for src, dst in ((Xd, Xb), (Yd, Yb)):
-            _lib.check(ctx.lib.dsdgp_gather_rows(ctx.handle, C.c_void_p(src.data_ptr()), src.shape[1],
-                                                 C.c_void_p(idx.data_ptr()), n, off, C.c_void_p(dst.data_ptr())))
+        _lib.check(ctx.lib.dsdgp_gather_rows2(ctx.handle, C.c_void_p(Xd.data_ptr()), Xd.shape[1], C.c_void_p(Xb.data_ptr()),
+                                              C.c_void_p(Yd.data_ptr()), Yd.shape[1], C.c_void_p(Yb.data_ptr()),
+                                              C.c_void_p(idx.data_ptr()), n, off))
         self._keep_idx = idx
         return Xb, Yb
 

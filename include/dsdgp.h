@@ -188,6 +188,9 @@ int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, d
  * idx: device int64.  Index generation stays on the host (own RNG; TF's shuffle order is not reproducible). */
 int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols, const int64_t* idx, int64_t n, int64_t idx_offset,
                       double* dst);
+/* The X and Y minibatches of one step in one launch (the two Minibatch iterators of dgp.py:51-52 share their seed). */
+int dsdgp_gather_rows2(dsdgp_ctx* ctx, const double* srcX, int64_t colsX, double* dstX, const double* srcY, int64_t colsY,
+                       double* dstY, const int64_t* idx, int64_t n, int64_t idx_offset);
 
 /* DGP_Base.E_log_p_Y with the Gaussian likelihood (dgp.py:83-90): out[i,d] = mean_s varexp(mean[s,i,d], var[s,i,d], Y[i,d]).
  * mean/var: (S*n x DY); Y, out: (n x DY); lik_var: host scalar.
