@@ -487,7 +487,9 @@ int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kin
 // ------------------------------------------------------------------------------------------------------
 // K loop of one (split, tile) task; GUARD: only the first njv of the NJ column blocks of Q exist (thin products A MB^T,
 // GW [X|1]^T ride in the same launch as the M x M products, their Q has 16..DinP16 rows)
-template <int NI, int NJ, bool GUARD>
+// DIAG: diagonal tile of a symmetric result (P == Q): only the 16x16 blocks on or below the block diagonal are formed
+// (10 of 16 MFMAs per k-step at NI = NJ = 4); the reduction mirrors at 16-block granularity.
+template <int NI, int NJ, bool GUARD, bool DIAG>
 __device__ __forceinline__ void wgrad_loop(const double* __restrict__ Pp, const double* __restrict__ Qp,
                                            const double* __restrict__ scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
                                            int njv, d4 (&acc)[NI][NJ]) {
@@ -511,7 +513,7 @@ __device__ __forceinline__ void wgrad_loop(const double* __restrict__ Pp, const 
       for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
-          if (!GUARD || jj < njv) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
+          if ((!GUARD || jj < njv) && (!DIAG || jj <= ii)) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
   }
 }
 
@@ -526,20 +528,31 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
   while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
   const WgradJob J = jobs[jb];
   int local = w - J.task_start;
-  const int tiles = J.sym ? J.ti * (J.ti + 1) / 2 : J.ti * J.tj;
-  const int split = local / tiles;
-  local = local % tiles;
-  int tile_i, tile_j;
+  int split, tile_i, tile_j, ns_eff = nsplit;
   if (J.sym) {
-    tile_i = 0;
-    while ((tile_i + 1) * (tile_i + 2) / 2 <= local) ++tile_i;
-    tile_j = local - tile_i * (tile_i + 1) / 2;
+    // off-diagonal tiles first (nsplit K ranges each), then the diagonal tiles (ns_diag longer ranges: they skip 6 of 16 blocks)
+    const int n_off = J.ti * (J.ti - 1) / 2;
+    if (local < nsplit * n_off) {
+      split = local / n_off;
+      local = local % n_off;
+      tile_i = 1;
+      while (tile_i * (tile_i + 1) / 2 <= local) ++tile_i;
+      tile_j = local - tile_i * (tile_i - 1) / 2;
+    } else {
+      local -= nsplit * n_off;
+      split = local / J.ti;
+      tile_i = tile_j = local % J.ti;
+      ns_eff = J.ns_diag;
+    }
   } else {
+    const int tiles = J.ti * J.tj;
+    split = local / tiles;
+    local = local % tiles;
     tile_i = local / J.tj;
     tile_j = local % J.tj;
   }
   const int64_t nch = Rp / 16;
-  const int64_t c_lo = split * nch / nsplit, c_hi = (split + 1) * nch / nsplit;
+  const int64_t c_lo = split * nch / ns_eff, c_hi = (split + 1) * nch / ns_eff;
   const int njv = (J.qrows16 - NJ * tile_j < NJ) ? J.qrows16 - NJ * tile_j : NJ;    // column blocks of this tile that exist
   d4 acc[NI][NJ];
 #pragma unroll
@@ -548,17 +561,20 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
     for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
   const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
   const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
-  if (njv == NJ)
-    wgrad_loop<NI, NJ, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  const bool diag = J.sym && tile_i == tile_j && NI == NJ;
+  if (diag)
+    wgrad_loop<NI, NJ, false, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else if (njv == NJ)
+    wgrad_loop<NI, NJ, false, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
   else
-    wgrad_loop<NI, NJ, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, true, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
   const int rowsP = 16 * NI * J.ti;
   double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
-      if (jj < njv) {
+      if (jj < njv && !(diag && jj > ii)) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] = acc[ii][jj][t];

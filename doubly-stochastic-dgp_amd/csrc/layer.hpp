@@ -65,6 +65,8 @@ struct WgradJob {
   int32_t task_start;
   int32_t sym;          // P == Q (symmetric result): only tiles with tile_j <= tile_i are computed
   int32_t qrows16;      // rows of Q / 16 (= columns of the result / 16)
+  int32_t ns_diag;      // sym: K splits of the (cheaper, 10/16) diagonal tiles; their tasks follow the off-diagonal ones
+  int32_t pad;
 };
 
 int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);

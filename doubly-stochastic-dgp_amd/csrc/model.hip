@@ -213,7 +213,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int tj_big = v.Mp / (16 * NI);
-    S.nsplit_big_max = choose_nsplit(ti * tj_big + d.D_out * (ti * (ti + 1) / 2), S.ld_max / 16, 1024);
+    S.nsplit_big_max = choose_nsplit(ti * tj_big + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
+                                     S.ld_max / 16, 1024);
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mp * (v.DP16 + v.DinP16));
@@ -1217,9 +1218,14 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     wgrad_shapes(v.Mp, NI, ti);
     const int64_t MM = (int64_t)v.Mp * v.Mp;
     std::vector<WgradJob> jobs(v.D_out + 3);
-    int ns = choose_nsplit(ti * ti + v.D_out * (ti * (ti + 1) / 2), nch, 1024);   // G is full, the D_out P_d are symmetric
+    // G is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
+    // of the K splits, so every task carries about the same number of MFMAs
+    const int n_off = ti * (ti - 1) / 2;
+    const double dfrac = (NI + 1) / (2.0 * NI);
+    int ns = choose_nsplit(ti * ti + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
     St.ns_big = ns;
+    const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
     int start = 0;
     for (int j = 0; j <= v.D_out; ++j) {
       WgradJob& J = jobs[j];
@@ -1229,22 +1235,25 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.out = St.part_big + (int64_t)j * ns * MM;
       J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
       J.sym = (j >= 1) ? 1 : 0; J.qrows16 = v.Mp / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
-      start += ns * (J.sym ? ti * (ti + 1) / 2 : ti * ti);
-      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16 * NI});
+      J.ns_diag = ns_diag; J.pad = 0;
+      start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
+      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16});   // mirror at 16-block granularity
     }
     // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
     const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI), nt = ns;
     St.ns_thin = nt;
-    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, tjq, v.DP16, start, 0, v.DP16 / 16};
+    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, tjq, v.DP16, start, 0, v.DP16 / 16, 0, 0};
     start += nt * ti * tjq;
     jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, tjz, v.DinP16, start, 0,
-                                 v.DinP16 / 16};
+                                 v.DinP16 / 16, 0, 0};
     start += nt * ti * tjz;
     St.tot_big = start;
     St.tot_thin = 0;
     red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0});
+    // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
+    DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MM * sizeof(double), ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
