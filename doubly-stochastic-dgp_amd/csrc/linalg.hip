@@ -219,11 +219,13 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
   __syncthreads();
   PH(5);
 
-  for (int jb = 0; jb < nb; ++jb) {
+  // Diagonal block jb: Cholesky by wave 0 (lane i < 16 owns row i in registers; pivots/columns broadcast with v_readlane),
+  // then column `lane` of X = L_jj^{-1} by forward substitution, column-oriented so that the 15 updates after each solved
+  // entry are independent (critical path 16 steps instead of 136 chained FMAs); LDS reads are broadcasts.  Wave 0 only.
+  auto factor_diag = [&](int jb) {
     const int j0 = jb * 16;
     double* Xd = Xdall + jb * 16 * 17;
-    // (a) diagonal block: wave 0, lane i (<16) owns row i in registers; pivots/columns broadcast with v_readlane
-    if (wave == 0) {
+    {
       const int i = c;
       double a[16];
 #pragma unroll
@@ -242,11 +244,9 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
         Ld[i * 17 + 16] = myinv;
       }
     }
-    __syncthreads();
-    PH(0);
-    if (wave == 0 && lane < 16) {
-      // column `lane` of X = L_jj^{-1} by forward substitution, column-oriented so that the 15 updates after each
-      // solved entry are independent (critical path 16 steps instead of 136 chained FMAs); LDS reads are broadcasts
+    __builtin_amdgcn_s_waitcnt(0);          // single wave: its own LDS stores are visible to its own later reads once drained
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {
       double x[16], sacc[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[i] = (i == lane) ? 1.0 : 0.0;
@@ -259,8 +259,30 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 #pragma unroll
       for (int i = 0; i < 16; ++i) Xd[i * 17 + lane] = x[i];
     }
-    __syncthreads();
-    PH(1);
+  };
+  // one trailing tile: A_ik -= L_ij L_kj^T
+  auto trail_tile = [&](int ib, int kb, int j0) {
+    d4 acc;
+    double av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      av[s] = W[(int64_t)(ib * 16 + c) * ld + j0 + 4 * s + g];
+      bv[s] = W[(int64_t)(kb * 16 + c) * ld + j0 + 4 * s + g];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma_f64(-av[s], bv[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[(int64_t)(ib * 16 + g + 4 * r) * ld + kb * 16 + c] = acc[r];
+  };
+
+  if (wave == 0) factor_diag(0);
+  __syncthreads();
+  PH(0);
+  for (int jb = 0; jb < nb; ++jb) {
+    const int j0 = jb * 16;
+    double* Xd = Xdall + jb * 16 * 17;
     // (b) panel: L_ij = A_ij * L_jj^{-T}   (16x16 MFMA products)
     for (int ib = jb + 1 + wave; ib < nb; ib += 4) {
       d4 acc = (d4){0, 0, 0, 0};
@@ -274,45 +296,25 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
     }
     __syncthreads();
     PH(2);
-    // (c) trailing update (syrk): A_ik -= L_ij L_kj^T for jb < kb <= ib
+    // (c) trailing update (syrk) with look-ahead: wave 0 updates the next diagonal tile first and factors it (Cholesky +
+    // inverse, a ~7000-cycle dependent chain) while waves 1-3 update the other tiles — the factorisation of block jb+1 is
+    // off the critical path whenever the rest of the trailing update is at least as long
     const int nt = nb - jb - 1;
-    const int cnt = nt * (nt + 1) / 2;
-    for (int idx = wave; idx < cnt; idx += 8) {
-      // two independent (ib, kb) blocks per iteration: their 4-MFMA dependency chains interleave
-      int ibv[2], kbv[2];
-      bool okv[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int id = idx + 4 * u;
-        okv[u] = id < cnt;
-        int ib2 = 0;
-        while ((ib2 + 1) * (ib2 + 2) / 2 <= id) ++ib2;
-        const int kb2 = id - ib2 * (ib2 + 1) / 2;
-        ibv[u] = okv[u] ? jb + 1 + ib2 : jb + 1;
-        kbv[u] = okv[u] ? jb + 1 + kb2 : jb + 1;
-      }
-      d4 acc[2];
-      double av[2][4], bv[2][4];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[u][r] = W[(int64_t)(ibv[u] * 16 + g + 4 * r) * ld + kbv[u] * 16 + c];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          av[u][s] = W[(int64_t)(ibv[u] * 16 + c) * ld + j0 + 4 * s + g];
-          bv[u][s] = W[(int64_t)(kbv[u] * 16 + c) * ld + j0 + 4 * s + g];
+    if (nt > 0) {
+      const int cnt = nt * (nt + 1) / 2;      // tile id 0 = (jb+1, jb+1)
+      if (wave == 0) {
+        trail_tile(jb + 1, jb + 1, j0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        factor_diag(jb + 1);
+      } else {
+        for (int id = wave; id < cnt; id += 3) {
+          int ib2 = 0;
+          while ((ib2 + 1) * (ib2 + 2) / 2 <= id) ++ib2;
+          const int kb2 = id - ib2 * (ib2 + 1) / 2;
+          trail_tile(jb + 1 + ib2, jb + 1 + kb2, j0);
         }
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = mfma_f64(-av[u][s], bv[u][s], acc[u]);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (okv[u]) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) W[(int64_t)(ibv[u] * 16 + g + 4 * r) * ld + kbv[u] * 16 + c] = acc[u][r];
-        }
     }
     __syncthreads();
     PH(3);
