@@ -780,26 +780,50 @@ __global__ __launch_bounds__(256) void k_asm_hyp_part(const LayerDev* __restrict
 // k_asm_params — its inputs come from kernels that precede that launch)
 __device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
   __shared__ double sh[4];
-  const int Din = v.D_in;
+  __shared__ double gl_s[64];
+  const int Din = v.D_in, parts = abs(v.hyp_parts), stride = Din + 2;
   const double* ils = v.hyp + HYP_ILS;
-  if (threadIdx.x == 0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
     double a = 0.0, tr = 0.0;
-    for (int b = 0; b < abs(v.hyp_parts); ++b) {
-      a += v.hyp2part[b * (Din + 2)];
-      tr += v.hyp2part[b * (Din + 2) + 1];
+    for (int b = threadIdx.x; b < parts; b += 256) {
+      a += v.hyp2part[b * stride];
+      tr += v.hyp2part[b * stride + 1];
     }
-    grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
-    if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
+    a = block_sum_256(a, sh);
+    tr = block_sum_256(tr, sh);
+    if (threadIdx.x == 0) {
+      grad[v.off_kvar] = (a + v.hyp_red[0] + v.hyp_red[1]) * v.hyp[HYP_DVAR];
+      if (v.has_white) grad[v.off_wvar] = (tr + v.hyp_red[1]) * v.hyp[HYP_DWVAR];
+    }
   }
   double iso = 0.0;
-  for (int q = threadIdx.x; q < Din; q += 256) {
-    double s = 0.0;
-    for (int b = 0; b < abs(v.hyp_parts); ++b) s += v.hyp2part[b * (Din + 2) + 2 + q];
-    const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
-    if (v.ard)
-      grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
-    else
-      iso += gl;
+  if (Din <= 64) {
+    // few lengthscales: one wavefront per q, lanes over the partial rows (a serial walk over the rows is latency-bound)
+    for (int q = wave; q < Din; q += 4) {
+      double s = 0.0;
+      for (int b = lane; b < parts; b += 64) s += v.hyp2part[b * stride + 2 + q];
+      s = sum_wave(s);
+      if (lane == 0) gl_s[q] = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
+    }
+    __syncthreads();
+    if (threadIdx.x < Din) {
+      const double gl = gl_s[threadIdx.x];
+      if (v.ard)
+        grad[v.off_kls + threadIdx.x] = gl * v.hyp[HYP_ILS + Din + threadIdx.x];
+      else
+        iso = gl;
+    }
+  } else {
+    for (int q = threadIdx.x; q < Din; q += 256) {
+      double s = 0.0;
+      for (int b = 0; b < parts; ++b) s += v.hyp2part[b * stride + 2 + q];
+      const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
+      if (v.ard)
+        grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
+      else
+        iso += gl;
+    }
   }
   iso = block_sum_256(iso, sh);
   if (!v.ard && threadIdx.x == 0) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
