@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 2
+#pragma unroll 4
       for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(a.Linv, a.LinvT, actb, ib, kb, g, c, acc[q]);
     }
   }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 2
+#pragma unroll 4
         for (int kb = ib; kb < MPB; ++kb) acc[q] = chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, acc[q]);
       }
     }
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 2
+#pragma unroll 4
         for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
       }
     }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         d4 y[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] = (d4){0, 0, 0, 0};
-#pragma unroll 2
+#pragma unroll 4
         for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
           for (int q = 0; q < NQ; ++q) y[q] = chain_block<Mp, D4>(Sd, Sd, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, y[q]);
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
-#pragma unroll 2
+#pragma unroll 4
           for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -443,13 +443,13 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 2
+#pragma unroll 4
         for (int kb = (WHITE ? ib : 0); kb < MPB; ++kb)
           bb[q] = WHITE ? chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, bb[q])
                         : chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, ib, kb, g, c, bb[q]);
       }
     } else {
-#pragma unroll 2
+#pragma unroll 4
       for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bb[q] = chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, bb[q]);

@@ -1,0 +1,10 @@
+#!/bin/bash
+for v in prev u4; do
+  export DSDGP_LIB_PATH=$PWD/tools/bin/libdsdgp_$v.so
+  echo "== variant $v"
+  timeout 600 python tools/ab_kernels.py 2 2>&1 | grep "^{"
+  timeout 600 python tools/ab_kernels.py 3 2>&1 | grep "^{"
+  timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-130
+done
+unset DSDGP_LIB_PATH
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gradient or trainable or elbo" 2>&1 | tail -1
