@@ -577,14 +577,18 @@ int sm_chain_enabled() {
 // waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
 // one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
 #define SM_SMALL_BLOCKS 160
-static inline bool sm_small(int Mp, int64_t nblk, int D_in) {
+static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
   static const int on = getenv("DSDGP_SM_SMALL") ? atoi(getenv("DSDGP_SM_SMALL")) : 1;
-  return on && (Mp == 128 || Mp == 256) && nblk <= SM_SMALL_BLOCKS && D_in <= XCH;
+  // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
+  // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
+  // (the 4-wave forward instance has the early-mean specialisation)
+  const int64_t lim = (Mp == 256 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
+  return on && (Mp == 128 || Mp == 256) && nblk <= lim && D_in <= XCH;
 }
-static inline int sm_nw(int Mp, int64_t nblk, int D_in) {
-  return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : (sm_small(Mp, nblk, D_in) ? 8 : 4));
+static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {
+  return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
 }
-int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in) * ceil_div(ld, 16); }
+int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in, true) * ceil_div(ld, 16); }
 
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
@@ -645,7 +649,7 @@ static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
 
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white) {
   const bool wide = a.D_in > XCH;
-  if (sm_small(Mp, ceil_div(a.Rin, 16), a.D_in)) {
+  if (sm_small(Mp, ceil_div(a.Rin, 16), a.D_in, false)) {
     SM_SMALL_CASE(fwd_sm_go, 8, (ctx, a))
     SM_SMALL_CASE(fwd_sm_go, 16, (ctx, a))
   }
@@ -653,7 +657,7 @@ int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_
 }
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
   const bool wide = a.D_in > XCH;
-  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in)) {
+  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in, true)) {
     SM_SMALL_CASE(bwd_sm_go, 8, (ctx, a))
     SM_SMALL_CASE(bwd_sm_go, 16, (ctx, a))
   }
