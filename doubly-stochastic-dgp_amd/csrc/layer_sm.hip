@@ -62,6 +62,11 @@ struct Own {
   static __device__ __forceinline__ bool active(int wave) { return MPB >= NW || wave < MPB; }
 };
 
+// outputs per epilogue group of the forward chain: their variance / mean partials are parked in LDS, ONE barrier per group,
+// then all threads write the group's mean / var / F as contiguous runs (the per-output form paid a barrier and 16 scattered
+// 8-byte stores per output).  Double-buffered by group parity.  NW = 16 keeps one output per group (LDS is full at M = 1024).
+static inline constexpr int sm_db(int NW) { return NW == 4 ? 8 : (NW == 8 ? 4 : 1); }
+
 // LDS carve (doubles): xs | act | red
 struct SmLds {
   int xs, act, red, total;
@@ -75,7 +80,8 @@ static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide) {
   L.act = o; o += Mp * 16;
   L.red = o;
   const bool mu_early = (NW == 4) && !wide;
-  const int red_fwd = NW * 16 + 2 * NW * 16 + (mu_early ? NW * 16 * D_out : 2 * NW * 16);   // s1 | 2 x s2 | mean partials
+  const int db = sm_db(NW);
+  const int red_fwd = NW * 16 + 2 * db * NW * 16 + (mu_early ? NW * 16 * D_out : 2 * db * NW * 16);   // s1 | 2 x [db] s2 | mean partials
   const int red_bwd = NW * 16 * xch;                            // dX partials of one chunk
   o += red_fwd > red_bwd ? red_fwd : red_bwd;
   L.total = o;
@@ -130,8 +136,9 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   double* xs = smem + L.xs;
   double* actb = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
   double* red_s1 = smem + L.red;                          // [NW][16]
-  double* red_s2 = red_s1 + NW * 16;                      // [2][NW][16]
-  double* red_mu = red_s2 + 2 * NW * 16;                  // MU_EARLY: [NW][Dout][16] ; else [2][NW][16]
+  constexpr int DB = sm_db(NW);
+  double* red_s2 = red_s1 + NW * 16;                      // [2][DB][NW][16]
+  double* red_mu = red_s2 + 2 * DB * NW * 16;             // MU_EARLY: [NW][Dout][16] ; else [2][DB][NW][16]
   constexpr bool MU_EARLY = (NW == 4) && !WIDE;           // small-M kernels: all mean partials before the q_sqrt loop
   const double* ils = a.hyp + HYP_ILS;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
@@ -268,25 +275,26 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
   const int dchunk = (Dout + (int)gridDim.y - 1) / (int)gridDim.y;
   const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
-  for (int d = d_lo; d < d_hi; ++d) {
-    // --- c_d = q_sqrt_d^T a ; |c_d|^2 (replaces SK/B of layers.py:195-212): out block ib sums kb >= ib
-    d4 cacc[NQ];
+  for (int d0 = d_lo, grp = 0; d0 < d_hi; d0 += DB, ++grp) {
+    const int gs = (d_hi - d0 < DB) ? d_hi - d0 : DB;
+    double* rs2 = red_s2 + (grp & 1) * DB * NW * 16;
+    double* rmu_g = red_mu + (grp & 1) * DB * NW * 16;     // !MU_EARLY only
+    for (int dd = 0; dd < gs; ++dd) {
+      const int d = d0 + dd;
+      // --- c_d = q_sqrt_d^T a ; |c_d|^2 (replaces SK/B of layers.py:195-212): out block ib sums kb >= ib
+      d4 cacc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
-    if (act) {
-      const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
-      const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
+      for (int q = 0; q < NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
+      if (act) {
+        const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
+        const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
+        for (int q = 0; q < NQ; ++q) {
+          const int ib = Own<MPB, NW>::ib(wave, q);
 #pragma unroll 4
-        for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
+          for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
+        }
       }
-    }
-    double* rs2 = red_s2 + (d & 1) * NW * 16;
-    double* rmu = MU_EARLY ? red_mu + d * 16 : red_mu + (d & 1) * NW * 16;
-    const int rmu_stride = MU_EARLY ? Dout * 16 : 16;
-    {
       double p = 0.0, mu = 0.0;
       if (act) {
 #pragma unroll
@@ -302,38 +310,40 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       p = sum_groups(p);
       if constexpr (!MU_EARLY) mu = sum_groups(mu);
       if (g == 0) {
-        rs2[wave * 16 + c] = p;
-        if constexpr (!MU_EARLY) rmu[wave * 16 + c] = mu;
+        rs2[(dd * NW + wave) * 16 + c] = p;
+        if constexpr (!MU_EARLY) rmu_g[(dd * NW + wave) * 16 + c] = mu;
       }
     }
     __syncthreads();
-    if (wave == (d % NW)) {
-      const int64_t r = r0 + c;
-      if (r < a.Rin) {
-        double s1 = 0.0, s2sum = 0.0, mu = 0.0;
+    // epilogue of the group: thread e <-> (row cc, output dd); a row's gs outputs are contiguous in mean / var / F
+    for (int e = tid; e < 16 * gs; e += NW * 64) {
+      const int cc = e / gs, dd = e % gs, d = d0 + dd;
+      const int64_t r = r0 + cc;
+      if (r >= a.Rin) continue;
+      double s1 = 0.0, s2sum = 0.0, mu = 0.0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          s1 += red_s1[w * 16 + c];
-          s2sum += rs2[w * 16 + c];
-          mu += rmu[w * rmu_stride + c];
-        }
-        const double var = kdiag - s1 + s2sum;                               // layers.py:212-217
-        if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
-          mu += a.X[r * Din + d];
-        } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-          double m2 = 0.0;
-          for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
-          mu += m2;
-        }
-        for (int s = g; s < a.rep; s += 4) {
-          const int64_t orow = (int64_t)s * a.Rin + r;
-          const int64_t o = orow * Dout + d;
-          if (a.mean) a.mean[o] = mu;
-          if (a.var) a.var[o] = var;
-          if (a.F && a.z) {
-            const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
-            a.F[o] = mu + zv * sqrt(var + a.jitter);                         // utils.py:41 (no clamp)
-          }
+      for (int w = 0; w < NW; ++w) {
+        s1 += red_s1[w * 16 + cc];
+        s2sum += rs2[(dd * NW + w) * 16 + cc];
+        mu += MU_EARLY ? red_mu[(w * Dout + d) * 16 + cc] : rmu_g[(dd * NW + w) * 16 + cc];
+      }
+      const double var = kdiag - s1 + s2sum;                               // layers.py:212-217
+      if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
+        mu += a.X[r * Din + d];
+      } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+        double m2 = 0.0;
+        for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
+        mu += m2;
+      }
+      const double sd = sqrt(var + a.jitter);
+      for (int s = 0; s < a.rep; ++s) {
+        const int64_t orow = (int64_t)s * a.Rin + r;
+        const int64_t o = orow * Dout + d;
+        if (a.mean) a.mean[o] = mu;
+        if (a.var) a.var[o] = var;
+        if (a.F && a.z) {
+          const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
+          a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
         }
       }
     }
