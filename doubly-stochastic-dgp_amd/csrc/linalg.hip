@@ -39,11 +39,17 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
 
   // software pipeline over (batch, k-tile) steps: the global loads of step t+1 are issued before the MFMAs of step t
-  const int ksteps = (P.k + GK - 1) / GK;
+  int kmin = 0, kmax = P.k;
+  if (P.tri & 1) kmin = max(kmin, n0);
+  if (P.tri & 2) kmax = min(kmax, m0 + GT);
+  if (P.tri & 4) kmax = min(kmax, n0 + GT);
+  if (P.tri & 8) kmin = max(kmin, m0);
+  const int ks_lo = kmin / GK;
+  const int ksteps = max(0, (kmax + GK - 1) / GK - ks_lo);
   const int nsteps = (b1 - b0) * ksteps;
   double ra[4], rb[4];
   auto gload = [&](int step) {
-    const int b = b0 + step / ksteps, k0 = (step % ksteps) * GK;
+    const int b = b0 + step / ksteps, k0 = (ks_lo + step % ksteps) * GK;
     const double* A = P.A + (int64_t)b * P.sA;
     const double* B = P.B + (int64_t)b * P.sB;
 #pragma unroll
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
           double v = P.alpha * acc[ib][jb][r];
           if (P.beta != 0.0) v += P.beta * C[(int64_t)row * P.ldc + col];
           C[(int64_t)row * P.ldc + col] = v;
+          if ((P.tri & 16) && n0 < m0) C[(int64_t)col * P.ldc + row] = v;     // mirror of a symmetric result
         }
       }
 }

@@ -14,7 +14,11 @@ struct GemmProblem {
   int32_t batch, batch_reduce;
   int32_t tiles_m, tiles_n, tile_start;
   double alpha, beta;
-  int32_t lower_only, pad;   // lower_only: skip 64x64 tiles strictly above the diagonal (syrk-style updates)
+  int32_t lower_only;        // skip 64x64 tiles strictly above the diagonal (syrk-style updates, symmetric / triangular results)
+  int32_t tri;               // structure hints that trim the k range of a tile (zeros are never multiplied):
+                             //   1: B[k][n] lower-triangular (k >= n)      2: A[m][k] lower-triangular (k <= m)
+                             //   4: transB with B[n][k] lower-triangular (k <= n)   8: A[m][k] upper-triangular (k >= m)
+                             //  16: with lower_only — also store the transposed tile (symmetric result, full matrix wanted)
 };
 
 // One matrix of a batched factorisation launch (n multiple of 16; rows/cols >= nreal carry an identity pad).

@@ -189,7 +189,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.thinq = b.take<double>(Mp * v.DP16);
     v.thinz = b.take<double>(Mp * v.DinP16);
     v.hyp_red = b.take<double>(d.D_in + 2 + 8);
-    v.klpart = b.take<double>(64);
+    v.klpart = b.take<double>(512);
     v.ngTI = b.take<double>(d.D_out * MM); v.ngTinv = b.take<double>(d.D_out * MM); v.ngTbar = b.take<double>(d.D_out * MM);
     v.ngH = b.take<double>(d.D_out * MM); v.ngY = b.take<double>(d.D_out * MM); v.ngX = b.take<double>(d.D_out * MM);
     v.ngSinv = b.take<double>(d.D_out * MM); v.ngA = b.take<double>(d.D_out * MM); v.ngLAinv = b.take<double>(d.D_out * MM);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_kl_part(const LayerDev* __restrict__ la
   __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.y];
   const int Mp = v.Mp, M = v.M;
-  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)NPART * 256;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   double acc = 0.0;
   for (int64_t idx = t0; idx < (int64_t)v.D_out * M; idx += nth) {
     const int d = (int)(idx / M), i = (int)(idx % M);
@@ -367,12 +367,12 @@ __global__ __launch_bounds__(256) void k_kl_part(const LayerDev* __restrict__ la
   const double tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) v.klpart[blockIdx.x] = tot;
 }
-__global__ void k_kl_final(const LayerDev* __restrict__ layers, int L) {
+__global__ void k_kl_final(const LayerDev* __restrict__ layers, int L, int nparts) {
   const int l = threadIdx.x;
   if (l >= L) return;
   const LayerDev v = layers[l];
   double kl = -0.5 * v.D_out * v.M;                                     // layers.py:234
-  for (int b = 0; b < NPART; ++b) kl += v.klpart[b];
+  for (int b = 0; b < nparts; ++b) kl += v.klpart[b];
   if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                        // layers.py:238 (sum log diag Lu = logdet/2)
   v.klv[0] = kl;
 }
@@ -923,20 +923,27 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     const int64_t MM = (int64_t)Mp * Mp;
     GemmProblem P;
     fill_gemm(P, v.LinvT, v.Linv, v.Kinv, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, 1, 0, 0, 0, 0);              // Ku^-1
+    P.lower_only = 1; P.tri = 8 | 1 | 16;                                                              //   upper x lower, symmetric
     gf.push_back(P);
     fill_gemm(P, v.Linv, v.Tp, v.V, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);            // Lu^-1 q_sqrt
+    P.lower_only = 1; P.tri = 2 | 1;                                                                   //   lower x lower = lower
     gf.push_back(P);
     fill_gemm(P, v.Linv, v.qmu4, v.nL, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // Lu^-1 q_mu
+    P.tri = 2;
     gf.push_back(P);
     fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
+    P.lower_only = 1; P.tri = 2 | 4 | 16;                                                              //   lower x lower^T, symmetric
     gf.push_back(P);
     fill_gemm(P, v.Kinv, v.Tp, v.U, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);            // U_d
+    P.tri = 1;
     g1.push_back(P);
     fill_gemm(P, v.Kinv, v.qmu4, v.n4, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // n
     g1.push_back(P);
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
+    P.lower_only = 1; P.tri = 1;                                                                       //   only tril(P_d T_d) is read
     gpt.push_back(P);
     fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);              // U_d U_d^T
+    P.lower_only = 1; P.tri = 16;
     g2.push_back(P);
     if (v.D_in > WIDE_DIN) {
       fill_gemm(P, v.wm, v.Zp1, v.WZ, Mp, v.DinP16, Mp, Mp, v.DinP16, v.DinP16, 0, 0, 1, 0, 0, 0, 0);  // wm [Z | 1]
@@ -1105,8 +1112,9 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     st = m->side;
   }
   DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
-  hipLaunchKernelGGL(k_kl_part, dim3(NPART, L), dim3(256), 0, st, m->layers_dev);
-  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, st, m->layers_dev, L);
+  const int klb = mp_max >= 512 ? 512 : NPART;    // M = 512 / 1024: V alone is 8..64 MB per layer — 32 workgroups were latency-bound
+  hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
+  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, st, m->layers_dev, L, klb);
   DS_HIP(hipGetLastError());
   if (with_grad && !m->desc.white) {
     DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1, st));
