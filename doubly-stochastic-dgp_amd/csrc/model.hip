@@ -1392,7 +1392,8 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   // fresh N(0,1) draws do not depend on the parameters: generate them on the side stream while Ku is factorised
   bool z_side = false;
   const bool ovl = overlap_on(m, n, S);
-  if (ovl) {
+  static const int z_side_on = getenv("DSDGP_Z_SIDE") ? atoi(getenv("DSDGP_Z_SIDE")) : 1;
+  if (ovl && z_side_on) {
     DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));     // after the previous step's readers of zbuf
     DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     for (int l = 0; l + 1 < L; ++l)

@@ -736,3 +736,33 @@ def test_generation2_chain_kernels_still_agree():
                         "-k", "layer_conditional or propagate_three or gradients_three or gradients_white or elbo_value"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_stream_overlap_is_bitwise_neutral():
+    # Race detector for the side-stream overlap (weight-gradient products, parameter-only algebra, RNG, finalize): every
+    # reduction on the path is fixed-order, so 60 optimiser steps with and without overlap must give IDENTICAL parameters.
+    import os
+    rng = np.random.RandomState(77)
+    N, D, M, S = 3000, 8, 128, 20
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[:M] + 0.05 * rng.randn(M, D)
+    out = []
+    for no_overlap in ("1", "0"):
+        os.environ["DSDGP_NO_OVERLAP"] = no_overlap
+        try:
+            spec, state, model = make_case(X, Y, Z, [kern_spec("rbf", D)] * 3, S=S, num_data=N, q_sqrt_scale=1e-3,
+                                           minibatch_size=1000)
+            for _ in range(60):
+                model.train_step(0.01)
+            elbo = model.train_step(0.01, sync=True)
+            eng = model.engine()
+            eng.sync_to_host()
+            out.append((elbo, np.concatenate([np.ravel(l.q_mu.value) for l in model.layers]),
+                        np.concatenate([np.ravel(l.feature.Z.value) for l in model.layers]),
+                        np.concatenate([np.ravel(l.q_sqrt.value) for l in model.layers])))
+        finally:
+            os.environ["DSDGP_NO_OVERLAP"] = "0"
+    assert np.isfinite(out[0][0])
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
