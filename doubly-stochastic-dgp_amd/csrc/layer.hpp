@@ -28,6 +28,7 @@ struct LayerFwdArgs {
   double* Asave;        // (Mp x ldA): A = Ku^{-1} Kuf (white: Lu^{-1} Kuf), kept for the backward pass, or NULL
   int64_t ldA;
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
+  double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
 };
 
 struct LayerBwdArgs {
@@ -52,6 +53,15 @@ struct LayerBwdArgs {
   int32_t mean_kind;
   const double* mean_A;
   double* hyp_part;     // [nwaves][D_in + 2]: sum kbar*k, sum vbar, lengthscale partials
+  // split-M kernels: when the PREVIOUS layer is an inner layer (one output row per input row) its transposed upstream
+  // adjoints are written here directly (k_adj_prep's job): MBp[d][r] = dX[r][prop+d], VBp[d][r] = dX * z / (2 sqrt(var+jitter))
+  double* MBp;          // (>= Dp x ldA) or NULL (then dX is written instead)
+  double* VBp;
+  const double* zp;     // the previous layer's N(0,1) draws, element (row, d) at zp[(row / n_inner) * zp_s + (row % n_inner) * zp_n + d * zp_d]
+  int64_t zp_s, zp_n, zp_d, n_inner;
+  const double* varp;   // the previous layer's variances (Rin x Dp)
+  int32_t Dp, prop;     // previous layer's D_out, input_prop_dim
+  double jitter;
 };
 
 // out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]

@@ -145,6 +145,14 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   const bool act = Own<MPB, NW>::active(wave);
   const double s2 = a.hyp[HYP_VAR];
 
+  // [X^T ; 1] of this block for the Z-gradient product of the backward pass (coalesced 128-byte runs along the rows)
+  if (a.XT1 && blockIdx.y == 0) {
+    for (int idx = tid; idx < 16 * (Din + 1); idx += NW * 64) {
+      const int j = idx >> 4, rr = idx & 15;
+      const int64_t r = r0 + rr;
+      if (r < a.ldA) a.XT1[(int64_t)j * a.ldA + r] = (r < a.Rin) ? (j < Din ? a.X[r * Din + j] : 1.0) : 0.0;
+    }
+  }
   // --- Kuf tile (layers.py:184): own row-blocks -> act
   if constexpr (!WIDE) {
     // D_in <= XCH: one staging pass, distances accumulated element by element (fewest live registers)
@@ -548,17 +556,18 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
           }
         }
       }
-      if (a.dX) {
+      if (a.dX || a.MBp) {
         sx = sum_groups(sx);
         if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
       }
       sl = sum_wave(sl);
       if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
     }
-    if (a.dX) {
+    if (a.dX || a.MBp) {
       __syncthreads();
       for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
-        const int j = idx % jn, cc = idx / jn;
+        // dX is row-major (j fastest); the fused transposed adjoints are M-major (row fastest): keep the stores coalesced
+        const int j = a.MBp ? idx / 16 : idx % jn, cc = a.MBp ? idx % 16 : idx / jn;
         const int64_t row = r0 + cc;
         if (row < a.Rin) {
           double sx = 0.0;
@@ -570,7 +579,19 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
           } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
             for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[(int64_t)(j0 + j) * Dout + d], a.MB[(int64_t)d * a.ldA + row], dx);
           }
-          a.dX[row * Din + j0 + j] = dx;
+          if (a.MBp) {
+            const int d = j0 + j - a.prop;
+            if (d >= 0) {
+              const double zv = a.zp[(row / a.n_inner) * a.zp_s + (row % a.n_inner) * a.zp_n + d * a.zp_d];
+              a.MBp[(int64_t)d * a.ldA + row] = dx;
+              a.VBp[(int64_t)d * a.ldA + row] = dx * zv * 0.5 * rsqrt(a.varp[row * a.Dp + d] + a.jitter);
+            }
+          } else {
+            a.dX[row * Din + j0 + j] = dx;
+          }
+        } else if (a.MBp && row < a.ldA && j0 + j >= a.prop) {
+          a.MBp[(int64_t)(j0 + j - a.prop) * a.ldA + row] = 0.0;
+          a.VBp[(int64_t)(j0 + j - a.prop) * a.ldA + row] = 0.0;
         }
       }
     }

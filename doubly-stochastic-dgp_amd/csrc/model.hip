@@ -96,6 +96,7 @@ struct dsdgp_model {
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
   bool need_hyp_part = false;
+  bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
   // arguments of the pending k_finalize (value + likelihood-variance gradient): launched on the side stream beside the
   // backward chain when streams overlap, otherwise on the main stream after it
   struct { int nblocks; double w, kl_weight; int with_grad; double* out; bool done; } fin;   // some layer does not fold its Ku-side hyper-parameter partials into k_asm_kbar
@@ -147,7 +148,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->lik_const = b.take<double>(8);
   m->scal4 = b.take<double>(8);
   const int64_t Rlast = (int64_t)m->s_max * m->n_max;
-  m->lik_blocks_max = ceil_div(Rlast * D.layers[D.L - 1].D_out, 256);
+  m->lik_blocks_max = ceil_div((Rlast + 16) * D.layers[D.L - 1].D_out, 256) + 1;   // + the 16-row padding written by the fused adjoint path
   m->lik_part = b.take<double>((size_t)m->lik_blocks_max * 2);
   m->lik_dmean = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
   m->lik_dvar = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
@@ -382,7 +383,10 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
                                                    const double* __restrict__ Y, int64_t n, int S, int DY,
                                                    const double* __restrict__ lik_const, double w,
                                                    const double* __restrict__ sw, double* __restrict__ part,
-                                                   double* __restrict__ dmean, double* __restrict__ dvar) {
+                                                   double* __restrict__ dmean, double* __restrict__ dvar,
+                                                   double* __restrict__ MBt, double* __restrict__ VBt, int64_t ldt) {
+  // MBt / VBt (DY x ldt, or NULL): the adjoints stored transposed and zero-padded, i.e. already in the form the last layer's
+  // backward chain reads (k_adj_prep's job when that layer has one output row per input row)
   __shared__ double sh[4];
   const double s2 = lik_const[0];
   const int64_t total = (int64_t)S * n * DY;
@@ -401,6 +405,13 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
       dmean[idx] = -w * f * (y - mu) / s2;
       dvar[idx] = 0.5 * w * f / s2;
     }
+    if (MBt) {
+      MBt[(int64_t)dd * ldt + row] = -w * f * (y - mu) / s2;
+      VBt[(int64_t)dd * ldt + row] = 0.5 * w * f / s2;
+    }
+  } else if (MBt && idx < ldt * DY) {      // rows of the 16-row padding
+    MBt[(idx % DY) * ldt + idx / DY] = 0.0;
+    VBt[(idx % DY) * ldt + idx / DY] = 0.0;
   }
   const double a = block_sum_256(ve, sh);
   const double b = block_sum_256(dl, sh);
@@ -1203,6 +1214,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
     a.Asave = save ? St.A : nullptr;
+    a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
       a.d_split = (nblk < 256) ? (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk)) : 1;
@@ -1328,6 +1340,12 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     const bool last = (l == L - 1);
     const int64_t Rin = St.Rin_used, ld = St.ld_used;
     const int rep = St.rep_used;
+    // transposed upstream adjoints MB / VB (+ [X^T ; 1]): written by the producer where one exists — the likelihood kernel
+    // for the last layer, the next layer's backward chain for inner layers — else (first layer: S output rows per input
+    // row; generation-2 kernels; MultiClass) by k_adj_prep
+    const bool sm = sm_chain_enabled();
+    const bool fused = sm && ((last && m->fused_last) || (!last && l >= 1));
+    if (!fused)
     hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                        last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
                        St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
@@ -1338,6 +1356,13 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
     b.Asave = St.A; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = St.E; b.GW = St.GW;
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
+    if (sm && l >= 2) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
+      LayerState& Pv = m->L[l - 1];
+      b.dX = nullptr;
+      b.MBp = Pv.MB; b.VBp = Pv.VB;
+      b.zp = Pv.z_used; b.zp_s = Pv.zs_s; b.zp_n = Pv.zs_n; b.zp_d = Pv.zs_d; b.n_inner = n;
+      b.varp = Pv.var; b.Dp = Pv.dev.D_out; b.prop = Pv.prop; b.jitter = m->desc.jitter;
+    }
     b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
     b.hyp_part = St.hyp_part;
     if (sm_chain_enabled())
@@ -1411,9 +1436,16 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   const int64_t total = (int64_t)S * n * DY;
   int nblocks = ceil_div(total, 256);
   const double w = data_scale / (double)S;
+  // the last layer of a deep model has one output row per input row: its transposed adjoints come straight from the
+  // likelihood kernel (no k_adj_prep launch on the critical path)
+  m->fused_last = with_grad && L > 1 && sm_chain_enabled() && m->desc.lik_kind == DSDGP_LIK_GAUSSIAN;
   if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN) {
+    const int64_t ldt = round_up((int64_t)S * n, 16);
+    if (m->fused_last) nblocks = ceil_div(ldt * DY, 256);
     hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
-                       w, m->sample_w, m->lik_part, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
+                       w, m->sample_w, m->lik_part, (with_grad && !m->fused_last) ? m->lik_dmean : nullptr,
+                       (with_grad && !m->fused_last) ? m->lik_dvar : nullptr, m->fused_last ? last.MB : nullptr,
+                       m->fused_last ? last.VB : nullptr, ldt);
   } else {
     // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
     DS_CHECK_ARG(DY == m->desc.num_classes);
