@@ -738,6 +738,31 @@ def test_generation2_chain_kernels_still_agree():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("N,M,S", [(1, 5, 1), (2, 17, 3), (33, 31, 2), (257, 65, 5)])
+def test_ragged_sizes(N, M, S):
+    # single rows, row counts and inducing counts that are not multiples of the 16-row / 16-column MFMA blocks, S = 1:
+    # padding rows, identity-padded Ku and the partial last row block must not leak into values or gradients
+    rng = np.random.RandomState(100 + N)
+    D = 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D)
+    specs = [kern_spec("matern52", D, 1.1, 0.9), kern_spec("rbf", D, 0.7, 1.3, ARD=True)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=5 * N)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    Fs, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    for l in range(2):     # random Z at M = 65: cond(Ku) ~ 1e7, so 1e-8 here (the reference's own bar is 1e-6, tests/test_dgp.py:101-106)
+        assert_allclose(Fs[l], Fs_o[l], rtol=1e-8, atol=1e-9)
+        assert_allclose(Fv[l], Fv_o[l], rtol=1e-8, atol=1e-9)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=5 * N)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-7, (k, err)
+
+
 def test_stream_overlap_is_bitwise_neutral():
     # Race detector for the side-stream overlap (weight-gradient products, parameter-only algebra, RNG, finalize): every
     # reduction on the path is fixed-order, so 60 optimiser steps with and without overlap must give IDENTICAL parameters.
