@@ -12,6 +12,8 @@ gradient: KL is counted once, the data term is scaled by num_data / N_global.
 
 def shard_terms(num_data, n_local, world):
     """(data_scale, kl_weight) of one rank."""
+    if n_local <= 0:
+        raise ValueError("empty minibatch: the ELBO scale num_data / N (dgp.py:96-98) is undefined for N = 0")
     return float(num_data) / float(n_local * world), 1.0 / float(world)
 
 

@@ -763,6 +763,17 @@ def test_ragged_sizes(N, M, S):
         assert err <= 1e-7, (k, err)
 
 
+def test_empty_input_fails_loudly():
+    from doubly_stochastic_dgp import _lib
+    X, Y, spec, state, model, zs = _three_layer(N=20, M=10, S=2)
+    with pytest.raises(_lib.DsdgpError):
+        model.propagate(np.zeros((0, X.shape[1])), S=2)
+    with pytest.raises((ValueError, _lib.DsdgpError)):
+        model.compute_log_likelihood(np.zeros((0, X.shape[1])), np.zeros((0, Y.shape[1])))
+    # the model is still usable afterwards
+    assert np.isfinite(model.compute_log_likelihood(X, Y, zs=zs))
+
+
 def test_stream_overlap_is_bitwise_neutral():
     # Race detector for the side-stream overlap (weight-gradient products, parameter-only algebra, RNG, finalize): every
     # reduction on the path is fixed-order, so 60 optimiser steps with and without overlap must give IDENTICAL parameters.

@@ -131,3 +131,10 @@ def test_mvhermgauss_matches_oracle_quad_points():
     # exact for polynomials: E[z1^2 z2^4] under N(0, I) = 1 * 3
     z = x * 2 ** 0.5
     np.testing.assert_allclose(np.sum(wq * z[:, 0] ** 2 * z[:, 1] ** 4), 3.0, rtol=1e-12)
+
+
+def test_shard_terms_rejects_empty_minibatch():
+    from doubly_stochastic_dgp.distributed import shard_terms
+    assert shard_terms(7372, 1000, 8) == (7372 / 8000.0, 0.125)
+    with pytest.raises(ValueError):
+        shard_terms(100, 0, 1)
