@@ -630,7 +630,13 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     return DSDGP_ERR_UNSUPPORTED;
   }
   if (lds > 64 * 1024)
-    DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
+      if ((int)lds > lds_set) {
+        DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = (int)lds;
+      }
+    }
   ProfScope ps(ctx, "layer_fwd");
   const int nrow = ceil_div(a.Rin, 16);
   int ds = a.d_split > 0 ? a.d_split : 1;
@@ -648,7 +654,13 @@ static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
     return DSDGP_ERR_UNSUPPORTED;
   }
   if (lds > 64 * 1024)
-    DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
+      if ((int)lds > lds_set) {
+        DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = (int)lds;
+      }
+    }
   ProfScope ps(ctx, "layer_bwd");
   hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());

@@ -444,11 +444,23 @@ int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_m
   if (n_max <= 128) {
     const size_t lds = base + (size_t)n_max * (n_max + 4) * sizeof(double);
     if (lds > 64 * 1024)
-      DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      {
+        static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
+        if ((int)lds > lds_set) {
+          DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          lds_set = (int)lds;
+        }
+      }
     hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items, nb_max);
   } else {
     if (base > 64 * 1024)
-      DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)base));
+      {
+        static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
+        if ((int)base > lds_set) {
+          DS_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)base));
+          lds_set = (int)base;
+        }
+      }
     hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items, nb_max);
   }
   DS_HIP(hipGetLastError());
