@@ -1,7 +1,9 @@
 """CPU restatement of the doubly-stochastic DGP hot path (TEST INFRASTRUCTURE — see oracle/__init__.py).
 
 PARITY UNPINNED by numeric vectors (reference needs gpflow==1.1.1 + tensorflow==1.8, neither importable
-here); pinned relationally by tests/test_oracle_identities.py.
+here); pinned relationally by tests/test_oracle_identities.py (the identities the reference's own tests assert,
+T1-T8) and, for the restated [UPSTREAM] formulas, against independent implementations in the image
+(scikit-learn kernels, scipy quadrature, Monte Carlo: T9-T11).
 
 Every function follows the reference *op for op* ("reference form": two triangular solves, SK, B = SK·A,
 sum(A∘B)) and cites the reference file:line (paths under /root/reference/).  [UPSTREAM] marks GPflow 1.1.1 /

@@ -312,3 +312,57 @@ def test_input_propagation_restatement():
         sp[k], sm[k] = state[k] + e, state[k] - e
         fd = (OM.elbo(spec, sp, X, Y, zs, S) - OM.elbo(spec, sm, X, Y, zs, S)) / 2e-6
         assert abs(fd - g[k][idx]) <= 1e-6 * max(1.0, abs(fd)), (k, fd, g[k][idx])
+
+
+# ---- independent pins of the [UPSTREAM] formulas the oracle restates (GPflow itself cannot be imported here) ----------------
+def test_T9_kernels_match_scikit_learn():
+    # RBF / Matern-5/2 Gram matrices against scikit-learn's independent implementation of the same published formulas
+    # (isotropic and ARD lengthscales); White: sigma^2 I on K(X), zero on K(X, X2), sigma^2 on Kdiag
+    from sklearn.gaussian_process import kernels as SK
+    rng = np.random.RandomState(3)
+    X, X2 = rng.randn(17, 4), rng.randn(9, 4)
+    for ls in (0.7, np.array([0.5, 1.0, 1.5, 2.0])):
+        ard = not np.isscalar(ls)
+        for kind, sk in (("rbf", SK.RBF(length_scale=ls)), ("matern52", SK.Matern(length_scale=ls, nu=2.5))):
+            k = O.Kern(kind, 4, variance=1.7, lengthscales=ls, ARD=ard)
+            assert_allclose(k.K(NP, X, X2), 1.7 * sk(X, X2), rtol=1e-9, atol=1e-12)
+            off = ~np.eye(17, dtype=bool)      # (Matern: sqrt(r2 + 1e-12) regularisation on the diagonal only)
+            assert_allclose(k.K(NP, X)[off], (1.7 * sk(X))[off], rtol=1e-9, atol=1e-12)
+            assert_allclose(k.Kdiag(NP, X), np.full(17, 1.7), rtol=1e-6)
+    kw = O.Kern("rbf", 4, variance=1.0, lengthscales=1.0, white_variance=0.3)
+    assert_allclose(kw.K(NP, X) - O.Kern("rbf", 4).K(NP, X), 0.3 * np.eye(17), atol=1e-14)
+    assert_allclose(kw.K(NP, X, X2), O.Kern("rbf", 4).K(NP, X, X2), atol=1e-15)
+    assert_allclose(kw.Kdiag(NP, X), np.full(17, 1.3), rtol=1e-15)
+
+
+def test_T10_gaussian_variational_expectation_by_quadrature():
+    # E_{N(f; mu, v)} log N(y; f, s2) against adaptive quadrature (scipy), and the predictive density against its definition
+    from scipy import integrate, stats
+    lik = O.Gaussian(0.37)
+    rng = np.random.RandomState(4)
+    for _ in range(5):
+        mu, v, y = rng.randn(), rng.rand() + 0.05, rng.randn()
+        ve = float(lik.variational_expectations(NP, np.array([[[mu]]]), np.array([[[v]]]), np.array([[y]]))[0, 0, 0])
+        ref, _ = integrate.quad(lambda f: stats.norm.pdf(f, mu, math.sqrt(v)) * stats.norm.logpdf(y, f, math.sqrt(0.37)),
+                                mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v))
+        assert_allclose(ve, ref, rtol=1e-9)
+        pd = float(lik.predict_density(NP, np.array([[[mu]]]), np.array([[[v]]]), np.array([[y]]))[0, 0, 0])
+        assert_allclose(pd, stats.norm.logpdf(y, mu, math.sqrt(v + 0.37)), rtol=1e-12)
+
+
+def test_T11_robustmax_probability_by_monte_carlo():
+    # [UPSTREAM] RobustMax.prob_is_largest (20-point Gauss-Hermite x erf products): P(f_y = max_k f_k) for independent
+    # Gaussians, against a 2e6-sample Monte-Carlo estimate and the exact two-class closed form
+    rng = np.random.RandomState(5)
+    lik = O.MultiClass(4)
+    mu, var = rng.randn(3, 4), rng.rand(3, 4) + 0.2
+    Y = np.array([[0.0], [2.0], [3.0]])
+    p = lik._prob_is_largest(NP, Y, mu, var)
+    f = mu[:, None, :] + np.sqrt(var)[:, None, :] * rng.randn(3, 2_000_000, 4)
+    mc = np.array([(np.argmax(f[i], 1) == int(Y[i, 0])).mean() for i in range(3)])
+    assert np.all(np.abs(p - mc) < 5 * np.sqrt(mc * (1 - mc) / 2e6) + 3e-4)      # 1e-4 cdf clipping of the upstream formula
+    from scipy import stats
+    lik2 = O.MultiClass(2)
+    m2, v2 = np.array([[0.3, -0.4]]), np.array([[0.5, 0.8]])
+    exact = stats.norm.cdf((0.3 + 0.4) / math.sqrt(0.5 + 0.8))
+    assert abs(float(lik2._prob_is_largest(NP, np.array([[0.0]]), m2, v2)[0]) - exact) < 3e-4
