@@ -14,6 +14,8 @@ void dsdgp_set_error(const char* fmt, ...) {
 
 extern "C" const char* dsdgp_last_error(void) { return g_err; }
 extern "C" int dsdgp_version(void) { return 100; }
+extern "C" int dsdgp_sizeof_layer_desc(void) { return (int)sizeof(dsdgp_layer_desc); }
+extern "C" int dsdgp_sizeof_model_desc(void) { return (int)sizeof(dsdgp_model_desc); }
 
 extern "C" int dsdgp_ctx_create(dsdgp_ctx** out, int device, void* stream) {
   DS_CHECK_ARG(out != nullptr);

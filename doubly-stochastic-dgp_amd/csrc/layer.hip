@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, (MPB <= 8 ? 2 : 1)) void k_layer_fwd(const Lay
     } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
       double acc = 0.0;
       for (int j = 0; j < Din; ++j) acc = fma(a.X[rc * Din + j], a.mean_A[j * a.D_out + d], acc);
-      mu += acc;
+      mu += acc + (a.mean_b ? a.mean_b[d] : 0.0);
     }
     if (rvalid) {
       for (int s = g; s < a.rep; s += 4) {

@@ -17,7 +17,8 @@ struct LayerFwdArgs {
   const double* TpT;    // (D_out x Mp x Mp) its transpose (split-M kernels read every weight as rows [i][k])
   const double* qmu;    // (Mp x D_out)
   int32_t mean_kind;
-  const double* mean_A; // (D_in x D_out) for the fixed Linear mean function
+  const double* mean_A; // (D_in x D_out) of the Linear mean function
+  const double* mean_b; // (D_out) bias of the Linear mean function or NULL
   const double* z;      // N(0,1) draws, element (s,i,d) at z[s*zs_s + i*zs_n + d*zs_d]; NULL -> F not produced
   int64_t zs_s, zs_n, zs_d;
   int64_t n_inner;      // minibatch rows per sample: output row o = s*n_inner + i

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
         double m2 = 0.0;
         for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
-        mu += m2;
+        mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
       }
       const double sd = sqrt(var + a.jitter);
       for (int s = 0; s < a.rep; ++s) {

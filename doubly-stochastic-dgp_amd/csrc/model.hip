@@ -23,6 +23,8 @@ struct LayerDev {
   double *V, *nL, *Sd, *klv;
   double *U, *n4, *PT, *UU, *Kbar, *wm, *wk;
   double *bigred, *thinq, *thinz, *hyp_red;
+  double* meanAB;              // (64 ti x DP16) [X;1]^T MB^T: gradient of a trainable Linear mean function (rows: D_in of A, then b)
+  int64_t off_mean_A, off_mean_b;   // -1: not a free parameter
   double *R2, *Zp1, *WZ;       // scaled squared distances of Z (Mp x Mp); [Z | 1] and wm [Z | 1] (Mp x DinP16, D_in > 32 only)
   double *klpart, *hyp2part;   // [NPART] KL partial sums ; [NPART][D_in + 2] Ku-side hyper-parameter partials
   double *wLbar, *wH, *wY, *wX;  // white=True: Cholesky-adjoint temporaries (Mp x Mp each)
@@ -50,6 +52,10 @@ struct LayerState {
   int nsplit_big_max, nsplit_thin_max;
   double *A, *E, *GW, *VB, *MB, *XT1;
   double *F, *mean, *var, *zbuf, *dF;
+  const double *meanA, *meanb;   // Linear mean function: A (fixed device array or inside theta), bias or NULL
+  int njobs;                     // weight-gradient jobs of this layer in the current plan
+  double* part_mean;             // split-K partials of the mean-function gradient product (only when it is trainable)
+  bool mean_grad;
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
@@ -160,7 +166,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->gp_wz = b.take<GemmProblem>(D.L);
   m->gp_w1 = b.take<GemmProblem>(2 * D.L); m->gp_w2 = b.take<GemmProblem>(D.L); m->gp_w3 = b.take<GemmProblem>(D.L);
   m->rjobs_cap = 0;
-  for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 4;
+  for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 5;
   m->rjobs = b.take<RedJob>(m->rjobs_cap);
   for (int l = 0; l < D.L; ++l) {
     LayerState& S = m->L[l];
@@ -198,6 +204,11 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
+    v.off_mean_A = (d.mean_kind == DSDGP_MEAN_LINEAR) ? d.off_mean_A : -1;
+    v.off_mean_b = (d.mean_kind == DSDGP_MEAN_LINEAR) ? d.off_mean_b : -1;
+    S.mean_grad = (v.off_mean_A >= 0 && d.trainable_mean_A) || (v.off_mean_b >= 0 && d.trainable_mean_b);
+    const int mrows = 64 * ceil_div(v.DinP16, 64);
+    v.meanAB = S.mean_grad ? b.take<double>((size_t)mrows * v.DP16) : nullptr;
     v.R2 = b.take<double>(MM);
     v.Zp1 = b.take<double>(Mp * v.DinP16); v.WZ = b.take<double>(Mp * v.DinP16);
     S.R_max = (int64_t)m->s_max * m->n_max;
@@ -205,7 +216,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.ld_max = round_up(Rin_max, 16);
     S.A = b.take<double>(Mp * S.ld_max); S.E = b.take<double>(Mp * S.ld_max); S.GW = b.take<double>(Mp * S.ld_max);
     S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
-    S.XT1 = b.take<double>(v.DinP16 * S.ld_max);
+    S.XT1 = b.take<double>((size_t)round_up(v.DinP16, 64) * S.ld_max);   // rows >= DinP16 stay zero: whole 64-row tiles for the mean-gradient product
     S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
     S.var = b.take<double>(S.R_max * d.D_out); S.zbuf = b.take<double>(S.R_max * d.D_out + 2);
     S.prop = (l + 1 < D.L) ? d.input_prop_dim : 0;     // the last layer's concatenation is host glue (nothing consumes it)
@@ -219,8 +230,9 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mp * (v.DP16 + v.DinP16));
+    S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
-    S.wj = b.take<WgradJob>(d.D_out + 3);
+    S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
   }
@@ -712,6 +724,13 @@ __global__ __launch_bounds__(256) void k_asm_params(const LayerDev* __restrict__
     }
     grad[v.off_q_sqrt + idx] = gq;
   }
+  // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
+  if (v.meanAB) {
+    if (v.off_mean_A >= 0)
+      for (int64_t idx = t0; idx < (int64_t)Din * Dout; idx += nth) grad[v.off_mean_A + idx] = v.meanAB[(idx / Dout) * v.DP16 + idx % Dout];
+    if (v.off_mean_b >= 0)
+      for (int64_t idx = t0; idx < Dout; idx += nth) grad[v.off_mean_b + idx] = v.meanAB[(int64_t)Din * v.DP16 + idx];
+  }
   // q_mu: A mbar + kl_w Ku^-1 q_mu
   for (int64_t idx = t0; idx < (int64_t)M * Dout; idx += nth) {
     const int i = (int)(idx / Dout), d = (int)(idx % Dout);
@@ -870,7 +889,7 @@ static int validate_desc(const dsdgp_model_desc* d) {
     DS_CHECK_ARG(y.input_prop_dim >= 0 && y.input_prop_dim <= y.D_in);
     if (l > 0) DS_CHECK_ARG(y.D_in == d->layers[l - 1].D_out + d->layers[l - 1].input_prop_dim);   // layers.py:105-110
     if (y.mean_kind == DSDGP_MEAN_IDENTITY) DS_CHECK_ARG(y.D_in == y.D_out);
-    if (y.mean_kind == DSDGP_MEAN_LINEAR) DS_CHECK_ARG(y.mean_A != nullptr);
+    if (y.mean_kind == DSDGP_MEAN_LINEAR) DS_CHECK_ARG(y.mean_A != nullptr || y.off_mean_A >= 0);
   }
   return DSDGP_OK;
 }
@@ -920,6 +939,11 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   }
   hipStream_t st = ctx->stream;
   DS_HIP(hipMemsetAsync(workspace, 0, total, st));
+  for (int l = 0; l < desc->L; ++l) {
+    LayerState& S = m->L[l];
+    S.meanA = (S.dev.off_mean_A >= 0) ? theta + S.dev.off_mean_A : S.d.mean_A;
+    S.meanb = (S.dev.off_mean_b >= 0) ? theta + S.dev.off_mean_b : nullptr;
+  }
   const int L = desc->L;
   std::vector<LayerDev> ld(L);
   std::vector<PotrfItem> items(L);
@@ -1041,6 +1065,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     mark(y.off_kvar, 1, y.trainable_kvar);
     mark(y.off_kls, y.ard ? y.D_in : 1, y.trainable_kls);
     if (y.has_white) mark(y.off_wvar, 1, y.trainable_wvar);
+    if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_A >= 0) mark(y.off_mean_A, (int64_t)y.D_in * y.D_out, y.trainable_mean_A);
+    if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_b >= 0) mark(y.off_mean_b, y.D_out, y.trainable_mean_b);
   }
   if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, desc->trainable_lik_var);
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1195,7 +1221,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.X = Xin; a.Rin = Rin; a.rep = rep;
     a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
     a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.TpT = v.TpT; a.qmu = v.qmu;
-    a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
+    a.mean_kind = St.d.mean_kind; a.mean_A = St.meanA; a.mean_b = St.meanb;
     a.jitter = m->desc.jitter;
     a.n_inner = n;
     a.z = nullptr;
@@ -1291,6 +1317,16 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, tjz, v.DinP16, start, 0,
                                  v.DinP16 / 16, 0, 0};
     start += nt * ti * tjz;
+    int njobs_l = v.D_out + 3;
+    if (St.mean_grad) {
+      // trainable Linear mean function: d loss / d [A ; b] = [X ; 1]^T MB^T  (XT1 is zero-padded to whole 16*NI-row tiles)
+      const int tim = ceil_div(v.DinP16 / 16, NI), tjm = ceil_div(v.DP16 / 16, NI);
+      jobs.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, start, 0, v.DP16 / 16, 0, 0});
+      start += nt * tim * tjm;
+      red.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, nt, 0, 0, 0, 0});
+      njobs_l = v.D_out + 4;
+    }
+    St.njobs = njobs_l;
     St.tot_big = start;
     St.tot_thin = 0;
     red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
@@ -1363,7 +1399,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       b.zp = Pv.z_used; b.zp_s = Pv.zs_s; b.zp_n = Pv.zs_n; b.zp_d = Pv.zs_d; b.n_inner = n;
       b.varp = Pv.var; b.Dp = Pv.dev.D_out; b.prop = Pv.prop; b.jitter = m->desc.jitter;
     }
-    b.mean_kind = St.d.mean_kind; b.mean_A = St.d.mean_A;
+    b.mean_kind = St.d.mean_kind; b.mean_A = St.meanA;
     b.hyp_part = St.hyp_part;
     if (sm_chain_enabled())
       DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
@@ -1378,7 +1414,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       ws = m->side;
       if (!m->fin.done) DS_TRY(launch_finalize(m, m->side));   // needs the likelihood partials (main, before ev_bwd) and KL (side)
     }
-    DS_TRY(wgrad_launch(ctx, St.wj, 3 + v.D_out, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
+    DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
   }
   if (overlap) {
     DS_HIP(hipEventRecord(m->ev_side, m->side));
@@ -1510,7 +1546,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.X = X; a.Rin = n; a.rep = 1;
   a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
   a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.TpT = v.TpT; a.qmu = v.qmu;
-  a.mean_kind = St.d.mean_kind; a.mean_A = St.d.mean_A;
+  a.mean_kind = St.d.mean_kind; a.mean_A = St.meanA; a.mean_b = St.meanb;
   a.jitter = m->desc.jitter;
   a.n_inner = n;
   a.mean = mean; a.var = var;
@@ -1675,7 +1711,7 @@ __global__ void k_fullcov_combine(const double* __restrict__ Kff, const double* 
   }
 }
 __global__ void k_add_mean_fn(double* __restrict__ mean, const double* __restrict__ X, int64_t n, int D_in, int D_out,
-                              int mean_kind, const double* __restrict__ A) {
+                              int mean_kind, const double* __restrict__ A, const double* __restrict__ bias) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * D_out; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / D_out;
     const int d = (int)(idx % D_out);
@@ -1684,6 +1720,7 @@ __global__ void k_add_mean_fn(double* __restrict__ mean, const double* __restric
       v += X[i * D_in + d];
     } else if (mean_kind == DSDGP_MEAN_LINEAR) {
       for (int j = 0; j < D_in; ++j) v = fma(X[i * D_in + j], A[j * D_out + d], v);
+      if (bias) v += bias[d];
     }
     mean[idx] = v;
   }
@@ -1745,7 +1782,7 @@ extern "C" int dsdgp_model_layer_conditional_full(dsdgp_model* m, int32_t l, con
   const int nb = (int)std::min<int64_t>(2048, ceil_div(NN * D, 256));
   hipLaunchKernelGGL(k_fullcov_combine, dim3(nb), dim3(256), 0, ctx->stream, Kff, Q, P, n, D, var);
   hipLaunchKernelGGL(k_add_mean_fn, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, mean, X, n, v.D_in, D,
-                     St.d.mean_kind, St.d.mean_A);
+                     St.d.mean_kind, St.meanA, St.meanb);
   DS_HIP(hipGetLastError());
   if (v.has_white) {
     // add the White variance on the diagonal of every output's covariance (Kff of a Sum kernel)

@@ -36,9 +36,11 @@ class LayerDesc(C.Structure):
                 ("trainable_Z", C.c_int32), ("trainable_q_mu", C.c_int32), ("trainable_q_sqrt", C.c_int32),
                 ("trainable_kvar", C.c_int32), ("trainable_kls", C.c_int32), ("trainable_wvar", C.c_int32),
                 ("input_prop_dim", C.c_int32),
+                ("trainable_mean_A", C.c_int32), ("trainable_mean_b", C.c_int32),
                 ("mean_A", C.c_void_p),
                 ("off_Z", C.c_int64), ("off_q_mu", C.c_int64), ("off_q_sqrt", C.c_int64),
-                ("off_kvar", C.c_int64), ("off_kls", C.c_int64), ("off_wvar", C.c_int64)]
+                ("off_kvar", C.c_int64), ("off_kls", C.c_int64), ("off_wvar", C.c_int64),
+                ("off_mean_A", C.c_int64), ("off_mean_b", C.c_int64)]
 
 
 class ModelDesc(C.Structure):
@@ -52,6 +54,8 @@ _lib = None
 
 _PROTOS = {
     "dsdgp_version": (C.c_int, []),
+    "dsdgp_sizeof_layer_desc": (C.c_int, []),
+    "dsdgp_sizeof_model_desc": (C.c_int, []),
     "dsdgp_last_error": (C.c_char_p, []),
     "dsdgp_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "dsdgp_ctx_destroy": (C.c_int, [C.c_void_p]),

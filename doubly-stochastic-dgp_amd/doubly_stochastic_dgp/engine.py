@@ -114,16 +114,17 @@ class Engine:
             ld.ard = int(stat.ARD)
             ld.has_white = int(wk is not None)
             ld.mean_kind = _MEAN[layer.mean_function.kind]
+            ld.off_mean_A = ld.off_mean_b = -1
+            mf_in_theta = False
             if layer.mean_function.kind == "linear":
                 A = np.asarray(layer.mean_function.A._value, dtype=np.float64)
                 if A.shape != (Din, Dout):
                     raise ValueError("Linear mean function has the wrong shape")
-                if layer.mean_function.A.trainable:
-                    raise NotImplementedError("a trainable Linear mean function is not on the built path: "
-                                              "init_layers_linear fixes it (layer_initializations.py:41-42)")
-                tA = self.ctx.to_device(A)
-                self._mean_A.append(tA)
-                ld.mean_A = tA.data_ptr()
+                mf_in_theta = layer.mean_function.in_theta()
+                if not mf_in_theta:                       # fixed map, no bias: a constant device array
+                    tA = self.ctx.to_device(A)
+                    self._mean_A.append(tA)
+                    ld.mean_A = tA.data_ptr()
 
             def add(p, kind, name):
                 nonlocal off
@@ -146,6 +147,9 @@ class Engine:
             ld.trainable_kls = int(add(stat.lengthscales, "pos", "kls"))
             if wk is not None:
                 ld.trainable_wvar = int(add(wk.variance, "pos", "wvar"))
+            if mf_in_theta:
+                ld.trainable_mean_A = int(add(layer.mean_function.A, "id", "mean_A"))
+                ld.trainable_mean_b = int(add(layer.mean_function.b, "id", "mean_b"))
         if isinstance(self.likelihood, Gaussian):
             d.lik_kind = _lib.LIK_GAUSSIAN
             p = self.likelihood.variance
@@ -410,6 +414,9 @@ class Engine:
             names[id(stat.lengthscales)] = f"l{l}.kern_lengthscales_raw"
             if wk is not None:
                 names[id(wk.variance)] = f"l{l}.white_variance_raw"
+            if layer.mean_function.kind == "linear":
+                names[id(layer.mean_function.A)] = f"l{l}.mean_A"
+                names[id(layer.mean_function.b)] = f"l{l}.mean_b"
         if isinstance(self.likelihood, Gaussian):
             names[id(self.likelihood.variance)] = "lik_variance_raw"
         for p, off, cnt, kind in self.entries:

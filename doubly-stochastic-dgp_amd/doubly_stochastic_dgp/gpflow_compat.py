@@ -194,14 +194,20 @@ class Identity(MeanFunction):
 
 
 class Linear(MeanFunction):
+    """[UPSTREAM] gpflow.mean_functions.Linear: y = X A + b with A (D_in, D_out) and b (D_out).  Both are free parameters
+    unless fixed with set_trainable(False) (init_layers_linear fixes its PCA / padding maps, layer_initializations.py:41-42);
+    trainable or biased instances are optimised on the device like every other parameter."""
     kind = "linear"
 
     def __init__(self, A=None, b=None):
-        A = np.ones((1, 1)) if A is None else np.asarray(A, dtype=np.float64)
-        self.A = Parameter(A, trainable=False)      # fixed in DGP: layer_initializations.py:42
-        if b is not None and np.any(np.asarray(b) != 0):
-            raise NotImplementedError("Linear mean function with a bias is not used by init_layers_linear")
-        self.b = None
+        A = np.ones((1, 1)) if A is None else np.atleast_2d(np.asarray(A, dtype=np.float64))
+        b = np.zeros(A.shape[1]) if b is None else np.broadcast_to(np.asarray(b, dtype=np.float64).ravel(), (A.shape[1],)).copy()
+        self.A = Parameter(A)
+        self.b = Parameter(b)
+
+    def in_theta(self):
+        """Whether A / b must live in the optimiser's parameter vector (else: a fixed map without bias)."""
+        return self.A.trainable or self.b.trainable or bool(np.any(self.b.value != 0.0))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -46,6 +46,9 @@ enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1 };       /* dgp.py:57, u
 
 /* ---- context ---------------------------------------------------------------------------------------- */
 int dsdgp_version(void);
+/* sizeof(dsdgp_layer_desc) / sizeof(dsdgp_model_desc) as compiled: a binding checks its struct mirrors against these. */
+int dsdgp_sizeof_layer_desc(void);
+int dsdgp_sizeof_model_desc(void);
 const char* dsdgp_last_error(void);
 /* stream: a hipStream_t (as void*) to enqueue on, or NULL for a library-owned stream. */
 int dsdgp_ctx_create(dsdgp_ctx** out, int device, void* stream);
@@ -95,7 +98,9 @@ typedef struct {
   int32_t mean_kind;               /* DSDGP_MEAN_* */
   int32_t trainable_Z, trainable_q_mu, trainable_q_sqrt, trainable_kvar, trainable_kls, trainable_wvar;
   int32_t input_prop_dim;          /* Layer(input_prop_dim) layers.py:36-50,105-117: the next layer sees [X[:, :p] | samples] */
-  const double* mean_A;            /* device, (D_in x D_out) for DSDGP_MEAN_LINEAR (fixed: layer_initializations.py:42) */
+  int32_t trainable_mean_A, trainable_mean_b;   /* only meaningful when the corresponding off_mean_* >= 0 */
+  const double* mean_A;            /* device, (D_in x D_out) for DSDGP_MEAN_LINEAR when fixed (layer_initializations.py:41-42);
+                                      ignored when off_mean_A >= 0 */
   /* offsets (in doubles) into the flat unconstrained parameter vector theta: */
   int64_t off_Z;                   /* (M, D_in)                       feature.Z           layers.py:153 */
   int64_t off_q_mu;                /* (M, D_out)                      layers.py:146-147 */
@@ -103,6 +108,9 @@ typedef struct {
   int64_t off_kvar;                /* scalar, softplus^-1(variance)   [UPSTREAM] transforms.positive */
   int64_t off_kls;                 /* 1 or D_in values, softplus^-1(lengthscales) */
   int64_t off_wvar;                /* scalar (if has_white) */
+  /* [UPSTREAM] mean_functions.Linear(A, b) as a free parameter (a user-supplied final mean function, dgp.py:187): */
+  int64_t off_mean_A;              /* (D_in, D_out) row-major inside theta, or -1: use the fixed mean_A pointer */
+  int64_t off_mean_b;              /* (D_out) inside theta, or -1: no bias */
 } dsdgp_layer_desc;
 
 typedef struct {

@@ -27,8 +27,12 @@ def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
         k = ld["kern"]
         spec_layers.append(dict(kind=k.kind, input_dim=k.input_dim, ARD=k.ARD,
                                 has_white=k.white_variance is not None,
-                                mean=ld["mean"].kind, mean_A=ld["mean"].A,
+                                mean=ld["mean"].kind, mean_A=ld["mean"].A, mean_trainable=bool(ld.get("mean_trainable")),
                                 input_prop_dim=ld.get("input_prop_dim")))
+        if ld.get("mean_trainable"):    # [UPSTREAM] mean_functions.Linear(A, b) as free parameters (identity transform)
+            state[f"l{i}.mean_A"] = np.array(ld["mean"].A, dtype=np.float64)
+            state[f"l{i}.mean_b"] = np.array(ld["mean"].b if ld["mean"].b is not None else np.zeros(ld["mean"].A.shape[1]),
+                                             dtype=np.float64)
         state[f"l{i}.Z"] = np.array(ld["Z"], dtype=np.float64)
         state[f"l{i}.q_mu"] = np.array(ld["q_mu"], dtype=np.float64)
         state[f"l{i}.q_sqrt"] = np.array(ld["q_sqrt"], dtype=np.float64)
@@ -55,7 +59,10 @@ def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
                       ARD=ls["ARD"],
                       white_variance=(O.positive_forward(xp, g("white_variance_raw"))
                                       if ls.get("has_white") else None))
-        mf = O.MeanFn(ls["mean"], A=ls.get("mean_A"))
+        if ls.get("mean_trainable"):
+            mf = O.MeanFn(ls["mean"], A=g("mean_A"), b=g("mean_b"))
+        else:
+            mf = O.MeanFn(ls["mean"], A=ls.get("mean_A"))
         layers.append(O.SVGPLayer(kern, g("Z"), g("q_mu"), g("q_sqrt"), mf,
                                   white=spec["white"], jitter=spec["jitter"],
                                   input_prop_dim=ls.get("input_prop_dim")))

@@ -763,6 +763,53 @@ def test_ragged_sizes(N, M, S):
         assert err <= 1e-7, (k, err)
 
 
+def test_trainable_linear_mean_function():
+    # [UPSTREAM] mean_functions.Linear(A, b) passed as the final mean function (dgp.py:187) with A and b free: forward with the
+    # bias, gradients of A and b ([X;1]^T MB^T through the split-K launch), an Adam step, and set_trainable(False) on b
+    from doubly_stochastic_dgp import settings
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import Gaussian, Linear
+    rng = np.random.RandomState(61)
+    N, D, M, S = 70, 3, 20, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 1.0), kern_spec("matern52", D, 1.2, 0.8)]
+    A0, b0 = 0.3 * rng.randn(D, 2), 0.5 * rng.randn(2)
+    lds = O.init_layers_linear(X, Y, Z, specs)
+    for l in lds:
+        l["q_mu"] = 0.3 * rng.randn(*l["q_mu"].shape)
+        l["q_sqrt"] = l["q_sqrt"] * 0.7 + 0.05 * np.tril(rng.randn(*l["q_sqrt"].shape))
+    lds[-1]["mean"] = O.MeanFn("linear", A=A0, b=b0)
+    lds[-1]["mean_trainable"] = True
+    sl, state = OM.state_from_layers(lds, lik_variance=0.2)
+    spec = dict(jitter=1e-6, white=False, likelihood="gaussian", layers=sl, num_classes=None)
+    with settings.temp_jitter(1e-6):
+        model = DGP(X, Y, Z, [product_kernel(k) for k in specs], Gaussian(variance=0.2), mean_function=Linear(A0, b0),
+                    num_samples=S, num_data=300)
+    for l, layer in zip(lds, model.layers):
+        layer.q_mu = l["q_mu"]
+        layer.q_sqrt = l["q_sqrt"]
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    _, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    _, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    assert_allclose(Fm[-1], Fm_o[-1], rtol=1e-9, atol=1e-10)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=300)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    assert set(g) == set(grads)
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-7, (k, err)
+    assert np.max(np.abs(grads["l1.mean_b"])) > 0
+    # one Adam step moves A and b; with b frozen it stays put
+    model.layers[-1].mean_function.b.set_trainable(False)
+    model.train_step(0.01, X=X, Y=Y, zs=zs, sync=True)
+    model.engine().sync_to_host()
+    assert_allclose(model.layers[-1].mean_function.b.value, b0, rtol=0, atol=0)
+    assert np.max(np.abs(model.layers[-1].mean_function.A.value - A0)) > 1e-3
+
+
 def test_empty_input_fails_loudly():
     from doubly_stochastic_dgp import _lib
     X, Y, spec, state, model, zs = _three_layer(N=20, M=10, S=2)

@@ -37,9 +37,10 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     _lib = _lib_or_skip()
-    # sizes the C side expects (LP64): dsdgp_layer_desc = 13*4 (+4 pad) + 8 + 6*8 ; model desc = 6*4 + 3*8 + 16 layers
-    assert ctypes.sizeof(_lib.LayerDesc) == 112
-    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 16 * 112
+    # the ctypes mirrors against the sizes the C side was compiled with (LP64): dsdgp_layer_desc = 16*4 + 8 + 8*8
+    lib = ctypes.CDLL(_lib.lib_path())
+    assert ctypes.sizeof(_lib.LayerDesc) == lib.dsdgp_sizeof_layer_desc() == 136
+    assert ctypes.sizeof(_lib.ModelDesc) == lib.dsdgp_sizeof_model_desc() == 48 + 16 * 136
     assert ctypes.sizeof(_lib.KernelSpec) == 40
 
 
