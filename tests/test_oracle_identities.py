@@ -366,3 +366,33 @@ def test_T11_robustmax_probability_by_monte_carlo():
     m2, v2 = np.array([[0.3, -0.4]]), np.array([[0.5, 0.8]])
     exact = stats.norm.cdf((0.3 + 0.4) / math.sqrt(0.5 + 0.8))
     assert abs(float(lik2._prob_is_largest(NP, np.array([[0.0]]), m2, v2)[0]) - exact) < 3e-4
+
+
+def test_trainable_linear_mean_restatement():
+    # [UPSTREAM] mean_functions.Linear(A, b) as free parameters of the last layer: autograd of the oracle vs central
+    # differences, and the bias shifts the predictive mean by exactly b
+    rng = np.random.RandomState(12)
+    N, D, M, S = 7, 2, 5, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    specs = [dict(kind="rbf", input_dim=D, variance=1.0, lengthscales=1.0, ARD=False, white_variance=None)] * 2
+    lds = O.init_layers_linear(X, Y, X[:M] + 0.01, specs)
+    for l in lds:
+        l["q_mu"] = 0.3 * rng.randn(*l["q_mu"].shape)
+    A0, b0 = 0.4 * rng.randn(D, 2), np.array([0.7, -0.2])
+    lds[-1]["mean"] = O.MeanFn("linear", A=A0, b=b0)
+    lds[-1]["mean_trainable"] = True
+    sl, state = OM.state_from_layers(lds, lik_variance=0.3)
+    assert state["l1.mean_A"].shape == (D, 2) and state["l1.mean_b"].shape == (2,)
+    spec = dict(jitter=1e-6, white=False, likelihood="gaussian", layers=sl, num_classes=None)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    _, Fm, _ = OM.propagate(spec, state, X, zs, S)
+    st0 = dict(state); st0["l1.mean_b"] = np.zeros(2)
+    _, Fm0, _ = OM.propagate(spec, st0, X, zs, S)
+    assert_allclose(Fm[-1] - Fm0[-1], np.broadcast_to(b0, Fm[-1].shape), rtol=1e-12, atol=1e-12)
+    v, g = OM.elbo_and_grad(spec, state, X, Y, zs, S)
+    for k, idx in (("l1.mean_A", (1, 0)), ("l1.mean_b", (1,)), ("l0.q_mu", (2, 1))):
+        e = np.zeros_like(state[k]); e[idx] = 1e-6
+        sp, sm = dict(state), dict(state)
+        sp[k], sm[k] = state[k] + e, state[k] - e
+        fd = (OM.elbo(spec, sp, X, Y, zs, S) - OM.elbo(spec, sm, X, Y, zs, S)) / 2e-6
+        assert abs(fd - g[k][idx]) <= 1e-6 * max(1.0, abs(fd)), (k, fd, g[k][idx])
