@@ -22,6 +22,12 @@ CASES = {
     # config-3-shaped slice: 5 layers, D=9, M=256, S=2
     "cfg3_slice": dict(N=48, D=9, DY=1, M=256, S=2, L=5, kind="rbf", ls=1.5, var=1.0, white=False, lik=1.0, jitter=1e-6,
                        seed=4, num_data=41157, zx=False),
+    # Matern-5/2 with ARD lengthscales + White kernel (Sum), whitened layers, two layers with a step down 3 -> 2
+    "ard_white_sum": dict(N=30, D=3, DY=2, M=12, S=3, L=2, kind="matern52", ls=[0.6, 1.0, 1.7], var=1.3, white=True, lik=0.1,
+                          jitter=1e-6, seed=5, num_data=90, zx=False, ard=True, wvar=0.05, dims=[3, 2]),
+    # MultiClass(3) / RobustMax likelihood, three layers (demo_mnist.ipynb:99-104 in miniature)
+    "multiclass": dict(N=24, D=2, DY=1, M=10, S=2, L=3, kind="rbf", ls=1.1, var=2.0, white=False, lik=None, jitter=1e-6,
+                       seed=6, num_data=100, zx=False, classes=3),
 }
 
 
@@ -32,8 +38,16 @@ def inputs(name):
     X = rng.uniform(size=(N, D)) if c["zx"] else rng.randn(N, D)
     Y = rng.randn(N, c["DY"])
     Z = X.copy() if c["zx"] else rng.randn(M, D) * 1.2
-    specs = [kern_spec(c["kind"], D, c["var"], c["ls"]) for _ in range(L)]
-    dims = [D] * (L - 1) + [c["DY"]]
+    if c.get("classes"):
+        Y = rng.randint(0, c["classes"], size=(N, 1)).astype(np.float64)
+    kdims = c.get("dims") or [D] * L                       # kernel input dims per layer (step-down cases)
+    specs = []
+    for d in kdims:
+        ls = c["ls"]
+        if c.get("ard"):
+            ls = list(np.asarray(ls, dtype=np.float64)[:d])
+        specs.append(kern_spec(c["kind"], d, c["var"], ls, ARD=bool(c.get("ard")), white_variance=c.get("wvar")))
+    dims = list(kdims[1:]) + [c.get("classes") or c["DY"]]
     zs = [rng.randn(S, N, d) for d in dims]
     return c, X, Y, Z, specs, zs
 
@@ -42,6 +56,7 @@ def build(name):
     """(spec, state, model-or-None, X, Y, zs, case): model is built only when the HIP library can be used."""
     from tests.helpers import make_case
     c, X, Y, Z, specs, zs = inputs(name)
-    spec, state, model = make_case(X, Y, Z, specs, white=c["white"], jitter=c["jitter"], lik_var=c["lik"], S=c["S"],
-                                   num_data=c["num_data"], seed=c["seed"], q_sqrt_scale=c.get("demo_scale"))
+    spec, state, model = make_case(X, Y, Z, specs, white=c["white"], jitter=c["jitter"], lik_var=c["lik"] or 1.0, S=c["S"],
+                                   num_data=c["num_data"], seed=c["seed"], q_sqrt_scale=c.get("demo_scale"),
+                                   num_classes=c.get("classes"))
     return spec, state, model, X, Y, zs, c
