@@ -195,7 +195,10 @@ class DGP_Base(Parameterized):
         eng.adam_step(lr, beta1, beta2, eps)
         if sync:
             eng.ctx.sync()
-            return float(eng.out4.cpu().numpy()[0]) if out is None else float(out[0])
+            o = eng.out4.cpu().numpy() if out is None else out
+            if o[3] != 0.0:      # asynchronous steps report a failed Kuu factorisation here ([UPSTREAM] tf.cholesky raises)
+                raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(o[3])})")
+            return float(o[0])
         return None
 
     # ------------------------------------------------------------------ dgp.py:100-126

@@ -7,9 +7,10 @@ class AdamOptimizer:
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
 
     def minimize(self, model, maxiter=1000):
-        for _ in range(int(maxiter)):
-            model.train_step(self.lr, self.b1, self.b2, self.eps)
-        model.engine().ctx.sync()
+        n = int(maxiter)
+        for it in range(n):
+            # steps are asynchronous; the last one synchronises and surfaces a failed Kuu factorisation (CholeskyError)
+            model.train_step(self.lr, self.b1, self.b2, self.eps, sync=(it == n - 1))
 
 
 class NatGradOptimizer:

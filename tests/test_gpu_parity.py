@@ -179,6 +179,13 @@ def test_cholesky_failure_raises():
     with settings.temp_jitter(-1e-3):
         with pytest.raises(_lib.CholeskyError):
             model.layers[0].conditional_ND(X)
+        # asynchronous training steps surface the failure at the next synchronising step / at the end of minimize()
+        from doubly_stochastic_dgp.training import AdamOptimizer
+        model.train_step(0.01)
+        with pytest.raises(_lib.CholeskyError):
+            model.train_step(0.01, sync=True)
+        with pytest.raises(_lib.CholeskyError):
+            AdamOptimizer(0.01).minimize(model, maxiter=3)
 
 
 # ---------------------------------------------------------------- model level (dgp.py:61-98)
