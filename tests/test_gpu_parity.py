@@ -817,6 +817,26 @@ def test_trainable_linear_mean_function():
     assert np.max(np.abs(model.layers[-1].mean_function.A.value - A0)) > 1e-3
 
 
+@pytest.mark.parametrize("L", [2, 4])
+def test_gradients_with_stream_overlap(L):
+    # large enough (n * S * Mp >= 2^20) that the side-stream overlap, the fused adjoint hand-off between inner layers and the
+    # likelihood-written last-layer adjoints are all active; 2 layers (no inner layer) and 4 layers (two inner layers)
+    rng = np.random.RandomState(70 + L)
+    N, D, M, S = 1500, 4, 64, 12
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[rng.permutation(N)[:M]] + 0.05 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 1.2)] * L
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=5000, lik_var=0.3)
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 1)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=5000)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - grads[k])) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-7, (k, err)
+
+
 def test_empty_input_fails_loudly():
     from doubly_stochastic_dgp import _lib
     X, Y, spec, state, model, zs = _three_layer(N=20, M=10, S=2)
