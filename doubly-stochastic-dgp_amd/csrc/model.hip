@@ -101,6 +101,8 @@ struct dsdgp_model {
   int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
+  bool uniform_big = false;     // all layers share M >= 449 (Mp >= 512): ONE batched multi-workgroup Cholesky for all layers
+  BigChol big_all;
   bool need_hyp_part = false;
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
   // arguments of the pending k_finalize (value + likelihood-variance gradient): launched on the side stream beside the
@@ -168,6 +170,16 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->rjobs_cap = 0;
   for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 5;
   m->rjobs = b.take<RedJob>(m->rjobs_cap);
+  // layers with the same (large) M keep their Ku / Lu^-1 / Lu^-T contiguous so that one batched factorisation serves them all
+  bool uniform = D.L > 1 && pad_M(D.layers[0].M) >= 512;
+  for (int l = 1; l < D.L; ++l) uniform = uniform && D.layers[l].M == D.layers[0].M;
+  m->uniform_big = uniform;
+  double *Kp_all = nullptr, *Linv_all = nullptr, *LinvT_all = nullptr, *scal_all = nullptr;
+  if (uniform) {
+    const size_t MM0 = (size_t)pad_M(D.layers[0].M) * pad_M(D.layers[0].M);
+    Kp_all = b.take<double>(D.L * MM0); Linv_all = b.take<double>(D.L * MM0); LinvT_all = b.take<double>(D.L * MM0);
+    scal_all = b.take<double>(D.L * 8);
+  }
   for (int l = 0; l < D.L; ++l) {
     LayerState& S = m->L[l];
     const dsdgp_layer_desc& d = D.layers[l];
@@ -186,8 +198,12 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.TpT = b.take<double>(d.D_out * MM);
     v.qmu = b.take<double>(Mp * d.D_out);
     v.qmu4 = b.take<double>(Mp * v.DP4);
-    v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.Kinv = b.take<double>(MM);
-    v.scal = b.take<double>(8);
+    if (uniform) {
+      v.Kp = Kp_all + l * MM; v.Linv = Linv_all + l * MM; v.LinvT = LinvT_all + l * MM; v.scal = scal_all + l * 8;
+    } else {
+      v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.scal = b.take<double>(8);
+    }
+    v.Kinv = b.take<double>(MM);
     v.V = b.take<double>(d.D_out * MM); v.nL = b.take<double>(Mp * v.DP4); v.Sd = b.take<double>(d.D_out * MM);
     v.klv = b.take<double>(8);
     v.U = b.take<double>(d.D_out * MM); v.n4 = b.take<double>(Mp * v.DP4); v.PT = b.take<double>(d.D_out * MM);
@@ -1017,7 +1033,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       DS_HIP(hipStreamSynchronize(st));
       St.big = Mp >= 512;
       if (St.big) {
-        DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
+        if (!m->uniform_big) DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
+        else if (l == 0) DS_TRY(bigchol_build(ctx, m->big_all, v.Kp, v.Linv, v.LinvT, v.scal, L, MM, 8, Mp, v.M, nullptr, false));
         DS_TRY(bigchol_build(ctx, St.big_ngA, v.ngA, v.ngLAinv, v.ngLAinvT, v.ngScal, v.D_out, MM, 2, Mp, v.M, nullptr, false));
         DS_TRY(bigchol_build(ctx, St.big_ngS, v.ngSplus, nullptr, nullptr, v.ngScal + 2 * v.D_out, v.D_out, MM, 2, Mp, v.M, nullptr, false));
         DS_TRY(bigchol_build(ctx, St.big_ngT, v.ngTI, v.ngTinv, nullptr, nullptr, v.D_out, MM, 0, Mp, v.M, nullptr, true));
@@ -1094,6 +1111,7 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
     hipStreamDestroy(m->side);
     for (int l = 0; l < m->desc.L; ++l) {
+      if (l == 0) bigchol_free(m->big_all);
       bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngS); bigchol_free(m->L[l].big_ngT);
     }
     delete m;
@@ -1134,7 +1152,9 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
-  if (mp_max >= 512) {
+  if (m->uniform_big) {
+    DS_TRY(bigchol_run(ctx, m->big_all));
+  } else if (mp_max >= 512) {
     for (int l = 0; l < L; ++l) {
       if (m->L[l].big) DS_TRY(bigchol_run(ctx, m->L[l].big_k));
       else DS_TRY(potrf_launch(ctx, m->potrf_items + l, 1, m->L[l].dev.Mp));
