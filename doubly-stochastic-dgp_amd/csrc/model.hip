@@ -101,7 +101,7 @@ struct dsdgp_model {
   int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
-  bool uniform_big = false;     // all layers share M >= 449 (Mp >= 512): ONE batched multi-workgroup Cholesky for all layers
+  bool uniform_big = false;     // all layers share M and Mp >= 256: ONE batched multi-workgroup Cholesky for all layers
   BigChol big_all;
   bool need_hyp_part = false;
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
@@ -132,6 +132,13 @@ struct Bump {
   }
 };
 
+// padded inducing count from which the multi-workgroup blocked Cholesky / inverse replaces the one-workgroup kernel: 512, or
+// 256 when all layers share M and are factorised as ONE batch (measured: config 3 +2 %; per-layer sequences at 256 would lose
+// to the single launch that factors all layers side by side)
+static int big_mp(bool uniform) {
+  static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
+  return uniform ? v : 512;
+}
 static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
   static const int scale = getenv("DSDGP_WGRAD_TARGET") ? atoi(getenv("DSDGP_WGRAD_TARGET")) : 1024;   // tuning knob (tasks for the big jobs)
   target_tasks = (int)((int64_t)target_tasks * scale / 1024);
@@ -171,7 +178,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   for (int l = 0; l < D.L; ++l) m->rjobs_cap += D.layers[l].D_out + 5;
   m->rjobs = b.take<RedJob>(m->rjobs_cap);
   // layers with the same (large) M keep their Ku / Lu^-1 / Lu^-T contiguous so that one batched factorisation serves them all
-  bool uniform = D.L > 1 && pad_M(D.layers[0].M) >= 512;
+  bool uniform = D.L > 1 && pad_M(D.layers[0].M) >= big_mp(true);
   for (int l = 1; l < D.L; ++l) uniform = uniform && D.layers[l].M == D.layers[0].M;
   m->uniform_big = uniform;
   double *Kp_all = nullptr, *Linv_all = nullptr, *LinvT_all = nullptr, *scal_all = nullptr;
@@ -1031,7 +1038,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       }
       DS_HIP(hipMemcpyAsync(St.ng_items, it.data(), it.size() * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
       DS_HIP(hipStreamSynchronize(st));
-      St.big = Mp >= 512;
+      St.big = Mp >= big_mp(m->uniform_big);
       if (St.big) {
         if (!m->uniform_big) DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
         else if (l == 0) DS_TRY(bigchol_build(ctx, m->big_all, v.Kp, v.Linv, v.LinvT, v.scal, L, MM, 8, Mp, v.M, nullptr, false));
@@ -1154,7 +1161,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
   if (m->uniform_big) {
     DS_TRY(bigchol_run(ctx, m->big_all));
-  } else if (mp_max >= 512) {
+  } else if (mp_max >= big_mp(false)) {
     for (int l = 0; l < L; ++l) {
       if (m->L[l].big) DS_TRY(bigchol_run(ctx, m->L[l].big_k));
       else DS_TRY(potrf_launch(ctx, m->potrf_items + l, 1, m->L[l].dev.Mp));
