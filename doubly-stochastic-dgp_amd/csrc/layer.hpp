@@ -27,9 +27,12 @@ struct LayerFwdArgs {
   double* mean;         // (rep*Rin x D_out) or NULL
   double* var;          // (rep*Rin x D_out) or NULL
   double* Asave;        // (Mp x ldA): A = Ku^{-1} Kuf (white: Lu^{-1} Kuf), kept for the backward pass, or NULL
+  double* Csave;        // [row block][D_out][Mp slots][16 rows]: c_d = q_sqrt_d^T a of every output in LDS slot order, kept for the
+                        // backward pass (split-M kernels), or NULL
   int64_t ldA;
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
   double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
+  int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
 };
 
 struct LayerBwdArgs {
@@ -45,6 +48,10 @@ struct LayerBwdArgs {
   const double* Sd;     // (D_out x Mp x Mp)  q_sqrt q_sqrt^T
   const double* qmu4;   // (Mp x DP4)
   const double* Asave;
+  const double* Csave;  // [row block][D_out][Mp][16] from the forward chain: abar += q_sqrt_d (2 vbar_d c_d) — a triangular product — replaces
+                        // the dense 2 vbar_d S_d a (split-M kernels; NULL selects the S_d form)
+  const double* Tp;     // (D_out x Mp x Mp) q_sqrt, and its transpose (Csave form)
+  const double* TpT;
   int64_t ldA;
   const double* VB;     // (D_out.. x ldA)  d loss / d var, transposed, zero beyond Rin
   const double* MB;     // (>=DP4 x ldA)    d loss / d mean, transposed, zero padded
@@ -63,6 +70,7 @@ struct LayerBwdArgs {
   const double* varp;   // the previous layer's variances (Rin x Dp)
   int32_t Dp, prop;     // previous layer's D_out, input_prop_dim
   double jitter;
+  int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
 };
 
 // out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]

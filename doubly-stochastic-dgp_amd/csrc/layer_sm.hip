@@ -71,13 +71,13 @@ static inline constexpr int sm_db(int NW) { return NW == 4 ? 8 : (NW == 8 ? 4 : 
 struct SmLds {
   int xs, act, red, total;
 };
-static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide) {
+static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide, int nbuf = 1) {
   SmLds L;
   int o = 0;
   const int xch = D_in < XCH ? D_in : XCH;
   L.xs = o; o += 16 * (xch + 1);
   o = (int)round_up(o, 2);
-  L.act = o; o += Mp * 16;
+  L.act = o; o += nbuf * Mp * 16;   // nbuf = 2: the Csave backward chain double-buffers its staged operand (Mp <= 256)
   L.red = o;
   const bool mu_early = (NW == 4) && !wide;
   const int db = sm_db(NW);
@@ -305,6 +305,23 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
       double p = 0.0, mu = 0.0;
       if (act) {
+        if (a.Csave) {
+          // c_d for the backward chain, BLOCK-major: the (Mp x 16) tile of (row block, output d) is one contiguous 16*Mp*8-byte
+          // run stored in LDS slot order, so this store and the backward staging are plain streaming copies (an M-major
+          // layout like Asave put every 128-byte run on its own page: TLB- and DRAM-page-hostile at D_out*Mp runs per block)
+          const int64_t r = r0 + c;
+          double* __restrict__ Cd = a.Csave + ((int64_t)blockIdx.x * Dout + d) * (Mp * 16) + c;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ib = Own<MPB, NW>::ib(wave, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const double cv = (r < a.Rin) ? cacc[q][t] : 0.0;
+              if (a.flags & 1) __builtin_nontemporal_store(cv, &Cd[out_slot<D4>(ib, g, t) * 16]);
+              else Cd[out_slot<D4>(ib, g, t) * 16] = cv;
+            }
+          }
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
@@ -361,7 +378,8 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 // ------------------------------------------------------------------------------------------------------
 // backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * NW + wave).
 // ------------------------------------------------------------------------------------------------------
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
+// CS: abar's variance part from the saved c_d (triangular q_sqrt_d products, staged through LDS) instead of dense S_d a
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
 __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
@@ -389,11 +407,67 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     for (int t = 0; t < 4; ++t) {
       const double v = (act && rin) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] : 0.0;
       av[q][t] = v;
-      if (act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
+      if (!CS && act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
     }
   }
-  __syncthreads();
   double gsum = 0.0;
+  if constexpr (CS) {
+    // cbar_d = 2 vbar_d c_d staged into LDS ([k][16 rows], B-operand order), abar += q_sqrt_d cbar_d: out block ib sums kb <= ib.
+    // Mp <= 256: two staging buffers (the loads of output d+1 fly during the products of d, one barrier per output);
+    // Mp >= 512: LDS holds one buffer (two barriers per output, loads still prefetched).
+    constexpr bool DBUF = (MPB <= 16);
+    constexpr int NS = Mp * 16 / (NW * 64 * 2);   // staged element PAIRS per thread (16-byte loads / LDS stores)
+    double* buf1 = DBUF ? actb + Mp * 16 : actb;
+    const int e0 = 2 * tid;                       // pair i of this thread: elements e0 + i * NW * 128 (+1) of the tile; rows scc, scc + 1
+    const int scc = e0 & 15;
+    const bool sin = r0 + scc < a.ldA;            // ldA is a multiple of 16: scc + 1 is inside too
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 tmp[NS];
+    auto stage_load = [&](int d) {
+      const d2 v2 = sin ? 2.0 * *reinterpret_cast<const d2*>(a.VB + (int64_t)d * a.ldA + r0 + scc) : (d2){0, 0};
+      const double* __restrict__ Cd = a.Csave + ((int64_t)blockIdx.x * Dout + d) * (Mp * 16) + e0;
+      if (a.flags & 1) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) tmp[i] = v2 * __builtin_nontemporal_load(reinterpret_cast<const d2*>(Cd + i * NW * 128));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) tmp[i] = v2 * *reinterpret_cast<const d2*>(Cd + i * NW * 128);
+      }
+    };
+    auto stage_store = [&](double* buf) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) *reinterpret_cast<d2*>(buf + e0 + i * NW * 128) = tmp[i];
+    };
+    constexpr bool PREF = (NW < 16);            // NW = 16 (1024 threads, 128-VGPR cap): no prefetch across the products (spills)
+    if (PREF) stage_load(0);
+    if (DBUF) stage_store(actb);
+    for (int d = 0; d < Dout; ++d) {
+      gsum += rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
+      double* cur = (DBUF && (d & 1)) ? buf1 : actb;
+      if (DBUF) {
+        if (d + 1 < Dout) stage_load(d + 1);
+        __syncthreads();
+      } else {
+        __syncthreads();          // the products of output d-1 are done with the buffer
+        if (!PREF) stage_load(d);
+        stage_store(actb);
+        __syncthreads();
+        if (PREF && d + 1 < Dout) stage_load(d + 1);
+      }
+      if (act) {
+        const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
+        const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int ib = Own<MPB, NW>::ib(wave, q);
+#pragma unroll 4
+          for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(Td, TdT, cur, ib, kb, g, c, acc[q]);
+        }
+      }
+      if (DBUF && d + 1 < Dout) stage_store((d & 1) ? actb : buf1);
+    }
+  } else {
+  __syncthreads();
   for (int d = 0; d < Dout; ++d) {
     const double vd = rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
     gsum += vd;
@@ -428,6 +502,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         }
       }
     }
+  }
   }
   if (act) {
     for (int sp = 0; sp < a.DP4 / 4; ++sp) {
@@ -514,7 +589,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         const double w = ok ? kbar * dk : 0.0;
         bb[q][t] = w;
         if (rin) {
-          a.E[(int64_t)m * a.ldA + r] = e;
+          if (a.E) a.E[(int64_t)m * a.ldA + r] = e;     // NULL: d loss / d Ku is assembled from the P_d (model.hip, alg_g)
           a.GW[(int64_t)m * a.ldA + r] = w;
         }
       }
@@ -608,8 +683,12 @@ int sm_chain_enabled() {
 // waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
 // one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
 #define SM_SMALL_BLOCKS 160
-static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
+static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd, bool cs = false) {
   static const int on = getenv("DSDGP_SM_SMALL") ? atoi(getenv("DSDGP_SM_SMALL")) : 1;
+  static const int cs_nw4 = getenv("DSDGP_CS_NW4") ? atoi(getenv("DSDGP_CS_NW4")) : 0;
+  // Csave backward at M = 128: 8 waves own ONE row block each, so the triangular q_sqrt_d products are unbalanced (1..8 blocks);
+  // 4 waves own a balanced pair (w, 7 - w)
+  if (cs && cs_nw4 && Mp == 128 && nblk > SM_SMALL_BLOCKS) return false;
   // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
   // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
   // (the 4-wave forward instance has the early-mean specialisation)
@@ -619,6 +698,7 @@ static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
 static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {
   return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
 }
+// upper bound over both variants (rows of hyp_part are written per wave: unused rows stay zero)
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in, true) * ceil_div(ld, 16); }
 
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
@@ -645,9 +725,9 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
-  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE);
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
+static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
+  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE, (CS && MPB <= 16) ? 2 : 1);
   const size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) {
     dsdgp_set_error("layer_bwd(sm): needs %zu B LDS (> 160 KiB)", lds);
@@ -657,14 +737,18 @@ static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
     {
       static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
       if ((int)lds > lds_set) {
-        DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = (int)lds;
       }
     }
   ProfScope ps(ctx, "layer_bwd");
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
+}
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
+static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
+  return a.Csave ? bwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, true>(ctx, a) : bwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, false>(ctx, a);
 }
 
 #define SM_CASE2(FN, MPB, NW, KIND, ARGS)                                                              \
@@ -700,7 +784,7 @@ int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_
 }
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
   const bool wide = a.D_in > XCH;
-  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in, true)) {
+  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in, true, a.Csave != nullptr)) {
     SM_SMALL_CASE(bwd_sm_go, 8, (ctx, a))
     SM_SMALL_CASE(bwd_sm_go, 16, (ctx, a))
   }

@@ -27,6 +27,12 @@ struct LayerDev {
   int64_t off_mean_A, off_mean_b;   // -1: not a free parameter
   double *R2, *Zp1, *WZ;       // scaled squared distances of Z (Mp x Mp); [Z | 1] and wm [Z | 1] (Mp x DinP16, D_in > 32 only)
   double *klpart, *hyp2part;   // [NPART] KL partial sums ; [NPART][D_in + 2] Ku-side hyper-parameter partials
+  // alg_g: sum_r e_r a_r^T is assembled from the (already needed) P_d and A mbar^T instead of a split-K product over the rows:
+  //   sum_r e a^T = sum_d (2 Ku^-1 S_d - I) P_d + n (A mbar^T)^T   (e = Ku^-1 abar - g a, abar = sum_d 2 vbar_d S_d a + q_mu mbar)
+  // KS_d = Ku^-1 S_d (parameter-only, side stream), GS_d = KS_d P_d (same launch as P_d T_d).  Chosen per layer when the row
+  // count dwarfs D_out * M (2 D_out M^3 flops instead of 2 M^2 R, and the chain stops writing E).
+  double *KS, *GS;
+  int32_t alg_g, need_tpt;   // need_tpt: some chain kernel reads q_sqrt^T (Mp >= 512 row-oriented loads; the Csave backward chain)
   double *wLbar, *wH, *wY, *wX;  // white=True: Cholesky-adjoint temporaries (Mp x Mp each)
   // natural-gradient temporaries, (D_out x Mp x Mp) each unless noted
   double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngSplus, *ngTheta1 /* D_out x Mp */, *ngScal /* 4 x D_out */;
@@ -50,7 +56,7 @@ struct LayerState {
   int64_t R_max;    // max output rows (s_max * n_max)
   int64_t ld_max;
   int nsplit_big_max, nsplit_thin_max;
-  double *A, *E, *GW, *VB, *MB, *XT1;
+  double *A, *C, *E, *GW, *VB, *MB, *XT1;
   double *F, *mean, *var, *zbuf, *dF;
   const double *meanA, *meanb;   // Linear mean function: A (fixed device array or inside theta), bias or NULL
   int njobs;                     // weight-gradient jobs of this layer in the current plan
@@ -135,6 +141,17 @@ struct Bump {
 // padded inducing count from which the multi-workgroup blocked Cholesky / inverse replaces the one-workgroup kernel: 512, or
 // 256 when all layers share M and are factorised as ONE batch (measured: config 3 +2 %; per-layer sequences at 256 would lose
 // to the single launch that factors all layers side by side)
+// the forward chain keeps c_d = q_sqrt_d^T a (D_out x Mp doubles per row) so that the backward chain's abar = sum_d 2 vbar_d S_d a
+// becomes the triangular product sum_d q_sqrt_d (2 vbar_d c_d): half the MFMAs of that loop for D_out x Mp x 8 bytes per row of
+// HBM traffic each way (cfg 2: 164 MB per 20 000-row layer, streamed under MFMA-bound kernels)
+static int dbg_flags() {
+  static const int f = getenv("DSDGP_DBG") ? atoi(getenv("DSDGP_DBG")) : 0;
+  return f;
+}
+static bool save_c_enabled() {
+  static const int on = getenv("DSDGP_SAVE_C") ? atoi(getenv("DSDGP_SAVE_C")) : 1;
+  return on && sm_chain_enabled();
+}
 static int big_mp(bool uniform) {
   static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
   return uniform ? v : 512;
@@ -151,7 +168,8 @@ static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks)
 }
 
 static void wgrad_shapes(int Mp, int& NI, int& ti) {
-  NI = (Mp % 64 == 0) ? 4 : 2;
+  static const int ni_env = getenv("DSDGP_WGRAD_NI") ? atoi(getenv("DSDGP_WGRAD_NI")) : 0;   // tuning knob: 2 -> 32x32 tiles
+  NI = (Mp % 64 == 0 && ni_env != 2) ? 4 : 2;
   ti = Mp / (16 * NI);
 }
 
@@ -169,8 +187,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->lik_dvar = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
   m->potrf_items = b.take<PotrfItem>(D.L);
   m->gp_fwd = b.take<GemmProblem>(4 * D.L);
-  m->gp_bwd1 = b.take<GemmProblem>(3 * D.L);
-  m->gp_pt = b.take<GemmProblem>(D.L);
+  m->gp_bwd1 = b.take<GemmProblem>(4 * D.L);
+  m->gp_pt = b.take<GemmProblem>(2 * D.L);
   m->gp_bwd2 = b.take<GemmProblem>(D.L);
   m->gp_wz = b.take<GemmProblem>(D.L);
   m->gp_w1 = b.take<GemmProblem>(2 * D.L); m->gp_w2 = b.take<GemmProblem>(D.L); m->gp_w3 = b.take<GemmProblem>(D.L);
@@ -227,6 +245,14 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
+    {
+      static const int alg_env = getenv("DSDGP_ALG_G") ? atoi(getenv("DSDGP_ALG_G")) : -1;   // -1: heuristic, 0: never, 1: always
+      const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
+      v.alg_g = (!D.white && sm_chain_enabled() && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
+      v.need_tpt = (v.Mp >= 512 || save_c_enabled()) ? 1 : 0;
+      v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
+      v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
+    }
     v.off_mean_A = (d.mean_kind == DSDGP_MEAN_LINEAR) ? d.off_mean_A : -1;
     v.off_mean_b = (d.mean_kind == DSDGP_MEAN_LINEAR) ? d.off_mean_b : -1;
     S.mean_grad = (v.off_mean_A >= 0 && d.trainable_mean_A) || (v.off_mean_b >= 0 && d.trainable_mean_b);
@@ -238,6 +264,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
     S.ld_max = round_up(Rin_max, 16);
     S.A = b.take<double>(Mp * S.ld_max); S.E = b.take<double>(Mp * S.ld_max); S.GW = b.take<double>(Mp * S.ld_max);
+    S.C = save_c_enabled() ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
     S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
     S.XT1 = b.take<double>((size_t)round_up(v.DinP16, 64) * S.ld_max);   // rows >= DinP16 stay zero: whole 64-row tiles for the mean-gradient product
     S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
@@ -248,7 +275,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int tj_big = v.Mp / (16 * NI);
-    S.nsplit_big_max = choose_nsplit(ti * tj_big + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
+    S.nsplit_big_max = choose_nsplit((v.alg_g ? 0 : ti * tj_big) + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
                                      S.ld_max / 16, 1024);
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
@@ -310,7 +337,7 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
   for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
     const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
     v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
-    if (Mp >= 512)   // only the row-oriented (32-byte load) chain kernels of the large-M path read q_sqrt^T
+    if (v.need_tpt)
       v.TpT[idx] = (j < M && i <= j) ? theta[v.off_q_sqrt + ((int64_t)d * M + j) * M + i] : 0.0;
   }
   for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
@@ -502,7 +529,7 @@ __global__ __launch_bounds__(256) void k_finalize(const LayerDev* __restrict__ l
     }
     out[0] = w * a - kl_weight * kl;
     out[1] = w * a;
-    out[2] = kl;
+    out[2] = kl_weight * kl;   // weighted like out[0]: the data-parallel SUM over ranks (kl_weight = 1/world) is then KL itself
     out[3] = info;
     if (with_grad && grad && off_lik >= 0) grad[off_lik] = -w * b * lik_const[1];
   }
@@ -673,8 +700,20 @@ __global__ __launch_bounds__(256) void k_asm_kbar(const LayerDev* __restrict__ l
       if (v.white) {
         kb = 0.5 * (v.wX[i * Mp + j] + v.wX[j * Mp + i]);   // KL(white) does not depend on Ku (layers.py:243-244)
       } else {
-        kb = -0.5 * (G[i * Mp + j] + G[j * Mp + i]) +
-             kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
+        double gsym;
+        if (v.alg_g) {
+          // sym(sum_r e a^T) = sum_d (GS_d + GS_d^T - P_d) + 1/2 (n t^T + t n^T),  t = A mbar^T (thinq)
+          double gs = 0.0, nt = 0.0;
+          for (int d = 0; d < v.D_out; ++d) {
+            const int64_t o = (int64_t)d * Mp * Mp;
+            gs += (v.GS[o + idx] + v.GS[o + j * Mp + i]) - v.bigred[(int64_t)Mp * Mp + o + idx];
+            nt += v.n4[i * v.DP4 + d] * v.thinq[j * v.DP16 + d] + v.n4[j * v.DP4 + d] * v.thinq[i * v.DP16 + d];
+          }
+          gsym = gs + 0.5 * nt;
+        } else {
+          gsym = 0.5 * (G[i * Mp + j] + G[j * Mp + i]);
+        }
+        kb = -gsym + kl_w * (0.5 * v.D_out * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
       }
       const double r2 = v.R2[idx];
       double k, dk;
@@ -1000,6 +1039,12 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
     P.lower_only = 1; P.tri = 1;                                                                       //   only tril(P_d T_d) is read
     gpt.push_back(P);
+    if (v.alg_g) {
+      fill_gemm(P, v.Kinv, v.Sd, v.KS, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);         // KS_d = Ku^-1 S_d
+      g1.push_back(P);
+      fill_gemm(P, v.KS, v.bigred + MM, v.GS, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0); // GS_d = KS_d P_d
+      gpt.push_back(P);
+    }
     fill_gemm(P, v.U, v.U, v.UU, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);              // U_d U_d^T
     P.lower_only = 1; P.tri = 16;
     g2.push_back(P);
@@ -1267,6 +1312,8 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
     a.Asave = save ? St.A : nullptr;
+    a.Csave = save ? St.C : nullptr;
+    a.flags = dbg_flags();
     a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
@@ -1314,18 +1361,19 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int64_t MM = (int64_t)v.Mp * v.Mp;
-    std::vector<WgradJob> jobs(v.D_out + 3);
+    std::vector<WgradJob> jobs;
     // G is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
-    // of the K splits, so every task carries about the same number of MFMAs
+    // of the K splits, so every task carries about the same number of MFMAs.  alg_g layers have no G job (k_asm_kbar
+    // assembles sum_r e a^T from the P_d).
     const int n_off = ti * (ti - 1) / 2;
     const double dfrac = (NI + 1) / (2.0 * NI);
-    int ns = choose_nsplit(ti * ti + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
+    int ns = choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
     St.ns_big = ns;
     const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
     int start = 0;
-    for (int j = 0; j <= v.D_out; ++j) {
-      WgradJob& J = jobs[j];
+    for (int j = v.alg_g ? 1 : 0; j <= v.D_out; ++j) {
+      WgradJob J{};
       J.P = (j == 0) ? St.E : St.A;
       J.Q = St.A;
       J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
@@ -1334,30 +1382,31 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.sym = (j >= 1) ? 1 : 0; J.qrows16 = v.Mp / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
       J.ns_diag = ns_diag; J.pad = 0;
       start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
+      jobs.push_back(J);
       red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16});   // mirror at 16-block granularity
     }
     // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
     const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI), nt = ns;
     St.ns_thin = nt;
-    jobs[v.D_out + 1] = WgradJob{St.A, St.MB, nullptr, St.part_thin, ti, tjq, v.DP16, start, 0, v.DP16 / 16, 0, 0};
+    double* const out_q = St.part_thin;
+    double* const out_z = St.part_thin + (int64_t)nt * v.Mp * v.DP16;
+    jobs.push_back(WgradJob{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, start, 0, v.DP16 / 16, 0, 0});
     start += nt * ti * tjq;
-    jobs[v.D_out + 2] = WgradJob{St.GW, St.XT1, nullptr, St.part_thin + (int64_t)nt * v.Mp * v.DP16, ti, tjz, v.DinP16, start, 0,
-                                 v.DinP16 / 16, 0, 0};
+    jobs.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, start, 0, v.DinP16 / 16, 0, 0});
     start += nt * ti * tjz;
-    int njobs_l = v.D_out + 3;
     if (St.mean_grad) {
       // trainable Linear mean function: d loss / d [A ; b] = [X ; 1]^T MB^T  (XT1 is zero-padded to whole 16*NI-row tiles)
       const int tim = ceil_div(v.DinP16 / 16, NI), tjm = ceil_div(v.DP16 / 16, NI);
       jobs.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, start, 0, v.DP16 / 16, 0, 0});
       start += nt * tim * tjm;
       red.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, nt, 0, 0, 0, 0});
-      njobs_l = v.D_out + 4;
     }
+    const int njobs_l = (int)jobs.size();
     St.njobs = njobs_l;
     St.tot_big = start;
     St.tot_thin = 0;
-    red.push_back(RedJob{jobs[v.D_out + 1].out, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
-    red.push_back(RedJob{jobs[v.D_out + 2].out, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
+    red.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
+    red.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
     red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0});
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MM * sizeof(double), ctx->stream));
@@ -1417,7 +1466,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
-    b.Asave = St.A; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = St.E; b.GW = St.GW;
+    b.flags = dbg_flags(); b.Asave = St.A; b.Csave = St.C; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
     if (sm && l >= 2) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
       LayerState& Pv = m->L[l - 1];

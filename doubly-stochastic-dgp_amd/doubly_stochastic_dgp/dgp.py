@@ -22,14 +22,20 @@ class Minibatch:
         self.rng = np.random.default_rng(seed)
         self._perm = None
         self._pos = 0
+        self._epoch = 0
+
+    def _new_epoch(self):
+        """Draw the next epoch's permutation.  EVERY regeneration bumps the epoch counter: callers key their device copy of
+        the permutation on it (a minibatch that straddles an epoch boundary regenerates inside next_indices)."""
+        self._perm = self.rng.permutation(self.n_rows)
+        self._pos = 0
+        self._epoch += 1
 
     def next_span(self):
         """(epoch permutation, start) of the next minibatch when it lies inside one epoch, else None (caller falls back to
         next_indices).  Lets the device keep one uploaded permutation per epoch instead of one index upload per step."""
         if self._perm is None or self._pos >= self.n_rows:
-            self._perm = self.rng.permutation(self.n_rows)
-            self._pos = 0
-            self._epoch = getattr(self, "_epoch", 0) + 1
+            self._new_epoch()
         if self._pos + self.batch_size > self.n_rows:
             return None
         start = self._pos
@@ -41,8 +47,7 @@ class Minibatch:
         need = self.batch_size
         while need > 0:
             if self._perm is None or self._pos >= self.n_rows:
-                self._perm = self.rng.permutation(self.n_rows)
-                self._pos = 0
+                self._new_epoch()
             take = min(need, self.n_rows - self._pos)
             out.append(self._perm[self._pos:self._pos + take])
             self._pos += take
@@ -61,6 +66,7 @@ class DGP_Base(Parameterized):
         self.minibatch_size = int(minibatch_size) if minibatch_size else None
         self._minibatch = Minibatch(self.X_data.shape[0], self.minibatch_size, seed=0) if self.minibatch_size else None
         self.likelihood = BroadcastingLikelihood(likelihood)                    # dgp.py:57
+        self.likelihood.check_targets(self.Y_data)
         self.layers = list(layers)                                              # dgp.py:59
         self.white = bool(self.layers[0].white) if self.layers else False
         object.__setattr__(self, "_eng", None)
@@ -166,6 +172,8 @@ class DGP_Base(Parameterized):
         eng = self.engine()
         if X is None:
             X, Y = self.next_minibatch()
+        elif not hasattr(Y, "data_ptr"):
+            self.likelihood.check_targets(Y)
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)                 # dgp.py:96-97
@@ -185,6 +193,8 @@ class DGP_Base(Parameterized):
         eng = self.engine()
         if X is None:
             X, Y = self.next_minibatch()
+        elif not hasattr(Y, "data_ptr"):
+            self.likelihood.check_targets(Y)
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)
@@ -196,6 +206,8 @@ class DGP_Base(Parameterized):
         if sync:
             eng.ctx.sync()
             o = eng.out4.cpu().numpy() if out is None else out
+            if out is None and world > 1:
+                o = o.copy(); o[3] /= world
             if o[3] != 0.0:      # asynchronous steps report a failed Kuu factorisation here ([UPSTREAM] tf.cholesky raises)
                 raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(o[3])})")
             return float(o[0])

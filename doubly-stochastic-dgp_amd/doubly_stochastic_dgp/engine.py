@@ -123,8 +123,12 @@ class Engine:
                 mf_in_theta = layer.mean_function.in_theta()
                 if not mf_in_theta:                       # fixed map, no bias: a constant device array
                     tA = self.ctx.to_device(A)
-                    self._mean_A.append(tA)
+                    self._mean_A.append((layer.mean_function, tA))
                     ld.mean_A = tA.data_ptr()
+                    # still owned: a later `mean_function.A = W`, a non-zero b or set_trainable(True) must reach the device
+                    for p in (layer.mean_function.A, layer.mean_function.b):
+                        if self not in p._owners:
+                            p._owners.append(self)
 
             def add(p, kind, name):
                 nonlocal off
@@ -200,6 +204,8 @@ class Engine:
             self._dev_dirty = False
 
     def _upload_if_needed(self):
+        if self._host_dirty and any(mf.in_theta() for mf, _ in self._mean_A):
+            self._structure_dirty = True       # a fixed Linear map gained a bias / became trainable: it moves into theta
         if settings.jitter != self.jitter or self._structure_dirty:
             self.sync_to_host()
             self.jitter = float(settings.jitter)
@@ -207,12 +213,18 @@ class Engine:
             for p, *_ in self.entries:
                 if self in p._owners:
                     p._owners.remove(self)
+            for mf, _ in self._mean_A:
+                for p in (mf.A, mf.b):
+                    if self in p._owners:
+                        p._owners.remove(self)
             self._build_layout()
             n, s = self.n_max, self.s_max
             self._destroy()
             self._host_dirty = True
             self._ensure(n, s)
         if self._host_dirty:
+            for mf, tA in self._mean_A:            # fixed maps: refresh the constant device copy in place (same pointer)
+                tA.copy_(self.ctx.torch.as_tensor(np.ascontiguousarray(mf.A._value, dtype=np.float64)))
             th = self._pack_host()
             self.theta.copy_(self.ctx.torch.as_tensor(th))
             self._host_dirty = False
@@ -235,25 +247,33 @@ class Engine:
         self.n_max = self.s_max = 0
 
     def _ensure(self, n, s):
+        """(Re)create the device model for up to n rows x s samples.  Only the workspace depends on (n, s): theta, the
+        gradient buffer and the Adam moments / step count are allocated once per parameter layout and SURVIVE a re-creation
+        (a predict_* call with more rows or samples than the training shape must not reset the optimiser — TF keeps its
+        Adam slots across predictions)."""
         if self.model is not None and n <= self.n_max and s <= self.s_max:
             return
-        self.sync_to_host()
         n_max, s_max = max(n, self.n_max), max(s, self.s_max)
         self._destroy()
         torch = self.ctx.torch
         nbytes = C.c_int64()
         _lib.check(self.lib.dsdgp_model_workspace_bytes(C.byref(self.desc), n_max, s_max, C.byref(nbytes)))
         dev = f"cuda:{self.ctx.device}"
+        self.workspace = None                      # release the old workspace before allocating the larger one
         self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
         base = self.workspace.data_ptr()
         self._ws_ptr = (base + 255) // 256 * 256
-        self.theta = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
-        # gradient and the 4 result scalars share one buffer so that data-parallel runs need ONE all-reduce per step
-        self.gradbuf = torch.zeros(self.n_theta + 4, dtype=torch.float64, device=dev)
-        self.grad = self.gradbuf[:self.n_theta]
-        self.adam_m = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
-        self.adam_v = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
-        self.out4 = self.gradbuf[self.n_theta:]
+        fresh = getattr(self, "theta", None) is None or self.theta.numel() != self.n_theta
+        if fresh:
+            self.theta = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+            # gradient and the 4 result scalars share one buffer so that data-parallel runs need ONE all-reduce per step
+            self.gradbuf = torch.zeros(self.n_theta + 4, dtype=torch.float64, device=dev)
+            self.grad = self.gradbuf[:self.n_theta]
+            self.adam_m = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+            self.adam_v = torch.zeros(self.n_theta, dtype=torch.float64, device=dev)
+            self.out4 = self.gradbuf[self.n_theta:]
+            self.adam_t = 0
+            self._host_dirty = True
         h = C.c_void_p()
         _lib.check(self.lib.dsdgp_model_create(self.ctx.handle, C.byref(self.desc), n_max, s_max, ptr(self.theta),
                                                ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
@@ -262,9 +282,7 @@ class Engine:
         self.n_max, self.s_max = n_max, s_max
         if getattr(self, "_sample_w", None) is not None:       # DGP_Quad weights survive a model re-creation
             self.set_sample_weights(self._sample_w)
-        self._host_dirty = True
         self._needs_prepare = True
-        self.adam_t = 0
 
     # ------------------------------------------------------------------ compute
     def _zs_args(self, zs, S, n):

@@ -55,7 +55,20 @@ class BroadcastingLikelihood:
             raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
                                       "(Gaussian, MultiClass are)")
 
+    def check_targets(self, Y):
+        """MultiClass: Y must hold integer class labels in [0, num_classes) — the device kernel indexes its per-class
+        accumulators with them ([UPSTREAM] tf.one_hot / gather would error or zero-fill; one-hot or NaN targets are a bug)."""
+        if not self.needs_broadcasting:
+            return
+        Y = np.asarray(Y, dtype=np.float64)
+        K = self.likelihood.num_classes
+        if Y.ndim != 2 or Y.shape[1] != 1:
+            raise ValueError(f"MultiClass targets must have shape (N, 1) with labels in [0, {K}), got {Y.shape}")
+        if not np.all(np.isfinite(Y)) or np.any(Y != np.floor(Y)) or np.any(Y < 0) or np.any(Y >= K):
+            raise ValueError(f"MultiClass targets must be integer labels in [0, {K})")
+
     def _run(self, mode, Fmu, Fvar, Y, weights=None):
+        self.check_targets(Y)
         from . import _lib
         from .engine import Context, ptr
         ctx = Context.get()

@@ -152,7 +152,9 @@ int dsdgp_model_propagate(dsdgp_model* m, const double* X, int64_t n, int32_t S,
  * loss = -(data_scale * sum_n E_log_p_Y - kl_weight * sum_l KL_l) w.r.t. theta written to `grad`
  * (stands in for tf.gradients [UPSTREAM]).  data_scale = num_data / n_global (dgp.py:96-97); kl_weight = 1, or
  * 1/world_size when the row-sharded data-parallel all-reduce sums ranks.
- * out (device, 4 doubles): [elbo_local, data_term (scaled), KL_sum, potrf_info]. */
+ * out (device, 4 doubles): [elbo_local, data_term (scaled), kl_weight * KL_sum, potrf_info (0 ok, else 1-based failing pivot)].
+ * Every entry but the last sums over data-parallel ranks to the single-process value; potrf_info is identical on all ranks
+ * (parameters are replicated), i.e. the sum is world_size * pivot. */
 int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S,
                      const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
                      double kl_weight, int with_grad, double* out);

@@ -1,0 +1,257 @@
+"""-m gpu tests added in round 2: host/device coherence fixes (minibatch epochs, optimiser state across model re-creation,
+fixed Linear maps, label validation), the layer-level sample_from_conditional (layers.py:76-119), triangular solves at
+n up to 1024, and an ill-conditioning suite at the conditioning k-means inducing points reach after training.
+
+Tolerances are stated per test; the reference's own bar is rtol = atol = 1e-7 (1 layer) / 1e-6 (2 layers)
+(/root/reference/tests/test_dgp.py:101-106).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import dgp_oracle as O
+from oracle import model as OM
+from tests.helpers import kern_spec, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from doubly_stochastic_dgp.engine import Context
+    return Context.get()
+
+
+def _dev(ctx, a):
+    return ctx.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------- host / device coherence
+def test_minibatch_rows_follow_the_permutation_across_epochs():
+    """N % B != 0: minibatches straddle epoch boundaries; every gathered batch must be X[perm-stream indices] — sampling
+    without replacement inside each epoch, rows of X and Y paired (dgp.py:50-52)."""
+    from doubly_stochastic_dgp.dgp import Minibatch
+    rng = np.random.RandomState(0)
+    N, B = 25, 10
+    X = rng.randn(N, 3)
+    Y = np.arange(N, dtype=np.float64)[:, None]
+    spec, state, model = make_case(X, Y, X[:8].copy(), [kern_spec("rbf", 3)], S=1, minibatch_size=B)
+    ref = Minibatch(N, B, seed=0)              # the model's own stream (seed 0, dgp.py:51-52)
+    seen = []
+    for _ in range(23):
+        want = ref.next_indices()
+        Xb, Yb = model.next_minibatch()
+        assert np.array_equal(Yb.cpu().numpy()[:, 0], want.astype(np.float64))
+        assert np.array_equal(Xb.cpu().numpy(), X[want])
+        seen.append(want)
+    seen = np.concatenate(seen)
+    for e in range(len(seen) // N):
+        assert sorted(seen[e * N:(e + 1) * N]) == list(range(N))
+
+
+def _small_model(seed=0, N=60, D=3, M=16, S=2):
+    rng = np.random.RandomState(seed)
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 1.0)] * 2
+    spec, state, model = make_case(X, Y, Z, specs, S=S, seed=seed)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 1)]
+    return X, Y, spec, state, model, zs
+
+
+def test_adam_state_survives_a_larger_predict():
+    """predict_* with more rows / samples than the training shape re-creates the device model; the Adam moments, the step
+    count and theta must carry over (TF keeps its Adam slots across predictions)."""
+    X, Y, _, _, a, zs = _small_model()
+    _, _, _, _, b, _ = _small_model()
+    Xnew = np.random.RandomState(5).randn(4 * X.shape[0], X.shape[1])
+    for _ in range(3):
+        a.train_step(0.01, X=X, Y=Y, zs=zs)
+        b.train_step(0.01, X=X, Y=Y, zs=zs)
+    m, v = a.predict_f(Xnew, 9)                 # n = 240 > 60, S = 9 > 2 -> _ensure() grows the workspace
+    assert m.shape == (9, Xnew.shape[0], 1) and np.all(np.isfinite(m)) and np.all(v > 0)
+    assert a.engine().adam_t == 3
+    for _ in range(3):
+        a.train_step(0.01, X=X, Y=Y, zs=zs)
+        b.train_step(0.01, X=X, Y=Y, zs=zs)
+    # not bitwise: the larger workspace changes split-K counts / the alg_g choice, i.e. summation orders (~1e-15 relative)
+    for la, lb in zip(a.layers, b.layers):
+        assert_allclose(la.q_mu.value, lb.q_mu.value, rtol=1e-9, atol=1e-12)
+        assert_allclose(la.q_sqrt.value, lb.q_sqrt.value, rtol=1e-9, atol=1e-12)
+        assert_allclose(la.feature.Z.value, lb.feature.Z.value, rtol=1e-9, atol=1e-12)
+    assert_allclose(a.likelihood.likelihood.variance.value, b.likelihood.likelihood.variance.value, rtol=1e-9)
+    # a wiped optimiser state would restart Adam's bias correction: the first step after it moves every entry by ~lr
+    assert a.engine().adam_t == 6
+
+
+def test_fixed_linear_map_assignment_reaches_the_device():
+    """init_layers_linear's PCA map is a fixed device constant (layer_initializations.py:41-42); assigning a new A, or a
+    non-zero bias, must still be seen by the next evaluation."""
+    rng = np.random.RandomState(2)
+    N, S = 40, 2
+    X, Y = rng.randn(N, 5), rng.randn(N, 1)
+    Z = X[:12].copy()
+    specs = [kern_spec("rbf", 5), kern_spec("rbf", 2)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S)
+    zs = [rng.randn(S, N, 2), rng.randn(S, N, 1)]
+    assert model.layers[0].mean_function.kind == "linear"
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, state, X, Y, zs, S), rtol=1e-9)
+    W2 = rng.randn(5, 2)
+    model.layers[0].mean_function.A = W2
+    spec["layers"][0]["mean_A"] = W2
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, state, X, Y, zs, S), rtol=1e-9)
+    bias = np.array([0.3, -0.2])
+    model.layers[0].mean_function.b = bias       # a biased map moves into theta (structure change)
+    spec["layers"][0]["mean_trainable"] = True
+    state["l0.mean_A"], state["l0.mean_b"] = W2.copy(), bias.copy()
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, state, X, Y, zs, S), rtol=1e-9)
+
+
+def test_multiclass_labels_checked_before_launch():
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import MultiClass, RBF
+    rng = np.random.RandomState(0)
+    X = rng.randn(20, 2)
+    with pytest.raises(ValueError):
+        DGP(X, np.full((20, 1), 3.0), X[:5], [RBF(2)], MultiClass(3), num_outputs=3)
+    model = DGP(X, rng.randint(0, 3, (20, 1)).astype(float), X[:5], [RBF(2)], MultiClass(3), num_outputs=3)
+    assert np.isfinite(model.compute_log_likelihood())
+    with pytest.raises(ValueError):
+        model.compute_log_likelihood(X, np.eye(3)[rng.randint(0, 3, 20)])      # one-hot targets passed by mistake
+
+
+# ---------------------------------------------------------------- layer-level surface (layers.py:52-119)
+@pytest.mark.parametrize("white", [False, True])
+def test_layer_sample_from_conditional_diag(white):
+    """Layer.sample_from_conditional(X, z, full_cov=False) at LAYER level: conditional_SND + reparameterize as separate
+    device calls, against the oracle's layer."""
+    rng = np.random.RandomState(4)
+    N, D, M, S, Dout = 33, 3, 12, 4, 2
+    X, Y = rng.randn(N, D), rng.randn(N, Dout)
+    Z = X[:M] + 0.05 * rng.randn(M, D)
+    spec, state, model = make_case(X, Y, Z, [kern_spec("matern52", D, 1.3, 0.7)], white=white, S=S)
+    om = OM.build(O.NP, spec, state, S)
+    XS = rng.randn(S, N, D)
+    z = rng.randn(S, N, Dout)
+    f, m, v = model.layers[0].sample_from_conditional(XS, z=z, full_cov=False)
+    fo, mo, vo = om.layers[0].sample_from_conditional(O.NP, XS, z=z, full_cov=False)
+    assert f.shape == (S, N, Dout)
+    assert_allclose(m, mo, rtol=1e-9, atol=1e-10)
+    assert_allclose(v, vo, rtol=1e-9, atol=1e-10)
+    assert_allclose(f, fo, rtol=1e-9, atol=1e-10)
+    # z = None draws from the device generator: same moments, different sample
+    f2, m2, v2 = model.layers[0].sample_from_conditional(XS, z=None)
+    assert_allclose(m2, mo, rtol=1e-9, atol=1e-10)
+    zz = (f2 - m2) / np.sqrt(v2 + spec["jitter"])
+    assert abs(zz.mean()) < 0.2 and 0.7 < zz.std() < 1.3
+
+
+# ---------------------------------------------------------------- triangular solves at the sizes cfg 4 / 5 use
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("n,nrhs", [(256, 500), (512, 300), (1024, 200)])
+def test_trsm_large(ctx, trans, n, nrhs):
+    """dsdgp_trsm is an explicit blocked inverse + GEMM; forward error scales with cond(L).  Well-conditioned L: rtol 1e-10;
+    the residual bar |L x - b| <= 1e-13 n |L| |x| is what a backward-stable solve would meet."""
+    import scipy.linalg as sla
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n)
+    L = np.tril(rng.randn(n, n)) / np.sqrt(n) + 2.0 * np.eye(n)
+    B = rng.randn(n, nrhs)
+    dL, dB = _dev(ctx, L), _dev(ctx, B)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_trsm(ctx.handle, trans, n, nrhs, _p(dL), n, _p(dB), nrhs))
+    ctx.sync()
+    Xs = dB.cpu().numpy()
+    ref = sla.solve_triangular(L, B, lower=True, trans=trans)
+    assert_allclose(Xs, ref, rtol=1e-10, atol=1e-11)
+    Lop = L.T if trans else L
+    assert np.linalg.norm(Lop @ Xs - B) <= 1e-13 * n * np.linalg.norm(L) * np.linalg.norm(Xs)
+
+
+# ---------------------------------------------------------------- ill-conditioning
+def _near_duplicate_case(white, sep, N=48, D=2, M=24, S=3, jitter=1e-6, seed=7):
+    """Inducing points in near-duplicate pairs `sep` apart (what k-means centres of clustered data drift to during
+    training): cond(Ku) ~ 2 / (jitter + sep^2)."""
+    rng = np.random.RandomState(seed)
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    base = rng.randn(M // 2, D)
+    Z = np.concatenate([base, base + sep * rng.randn(M // 2, D)])
+    specs = [kern_spec("rbf", D, 1.0, 1.0), kern_spec("rbf", D, 1.0, 1.0)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, jitter=jitter, seed=seed)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 1)]
+    K = O.Kern("rbf", D).K(O.NP, Z) + jitter * np.eye(M)
+    return X, Y, spec, state, model, zs, np.linalg.cond(K)
+
+
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("sep,tol", [(1e-2, 1e-7), (1e-4, 1e-6), (0.0, 1e-6)])
+def test_ill_conditioned_inducing_points(white, sep, tol):
+    """Explicit Lu^-1 / Ku^-1 products vs the oracle's backward-stable trsm form at cond(Ku) up to ~1e7 (jitter 1e-6 bounds
+    it: duplicated points give 2 / jitter).  Bar = the reference's own test tolerance (1e-7 one layer, 1e-6 two layers,
+    tests/test_dgp.py:101-106); the forward error of BOTH forms grows like cond * eps here."""
+    from doubly_stochastic_dgp import settings
+    X, Y, spec, state, model, zs, cond = _near_duplicate_case(white, sep)
+    assert cond > (1e3 if sep >= 1e-2 else 1e6)
+    with settings.temp_jitter(1e-6):
+        Fs_o, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, 3)
+        Fs, Fm, Fv = model.propagate(X, S=3, zs=zs)
+        for l in range(2):
+            assert_allclose(Fm[l], Fm_o[l], rtol=tol, atol=tol)
+            assert_allclose(Fv[l], Fv_o[l], rtol=tol, atol=tol)
+        ref, gref = OM.elbo_and_grad(spec, state, X, Y, zs, 3)
+        got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+        assert_allclose(got, ref, rtol=tol)
+        assert_allclose([layer.KL() for layer in model.layers], [l.KL(O.NP) for l in OM.build(O.NP, spec, state, 3).layers],
+                        rtol=tol)
+        g = model.engine().gradient_dict()
+        # gradients of an ill-conditioned Ku are themselves ill-conditioned (both sides lose cond * eps): 1e3 x the value bar
+        for k in gref:
+            scale = np.max(np.abs(gref[k])) + 1e-12
+            assert np.max(np.abs(-gref[k] - g[k])) <= 1e3 * tol * scale, (k, cond)
+
+
+def test_ill_conditioned_smaller_jitter_1e10():
+    """jitter 1e-9 with 1e-5-separated pairs: cond(Ku) ~ 1e9..1e10.  Values stay within 1e-4 of the oracle (cond * eps ~ 1e-6
+    per solve, two chained layers); a non-finite or wildly different result would flag a breakdown of the explicit inverse."""
+    from doubly_stochastic_dgp import settings
+    with settings.temp_jitter(1e-9):
+        X, Y, spec, state, model, zs, cond = _near_duplicate_case(False, 1e-5, jitter=1e-9)
+        assert cond > 1e9
+        _, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, 3)
+        _, Fm, Fv = model.propagate(X, S=3, zs=zs)
+        assert np.all(np.isfinite(Fm[-1])) and np.all(np.isfinite(Fv[-1]))
+        assert_allclose(Fm[-1], Fm_o[-1], rtol=1e-4, atol=1e-4)
+        assert_allclose(Fv[-1], Fv_o[-1], rtol=1e-4, atol=1e-4)
+        assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, state, X, Y, zs, 3), rtol=1e-4)
+
+
+def test_negative_variance_gives_nan_like_the_reference():
+    """utils.py:41 takes (var + jitter) ** 0.5 with NO clamp: a variance below -jitter yields NaN samples, not a silently
+    clamped value.  Forced here with q_sqrt = 0 and a negative jitter (var = Kdiag - k^T Ku^-1 k ~ 0 at the inducing points)."""
+    from doubly_stochastic_dgp import settings
+    rng = np.random.RandomState(1)
+    N, D, M, S = 20, 2, 10, 2
+    X = rng.randn(N, D)
+    X[:M] = X[:M]                                   # the first M rows ARE the inducing points: var there ~ 0
+    spec, state, model = make_case(X, rng.randn(N, 1), X[:M].copy(), [kern_spec("rbf", D)], S=S, randomize=False)
+    model.layers[0].q_sqrt = np.zeros((1, M, M))
+    state["l0.q_sqrt"] = np.zeros((1, M, M))
+    z = [rng.randn(S, N, 1)]
+    mean, var = model.layers[0].conditional_ND(X)
+    assert np.all(np.abs(var[:M]) < 1e-4)
+    with settings.temp_jitter(1e-6):
+        spec["jitter"] = 1e-6
+        Fs, _, Fv = model.propagate(X, S=S, zs=z)
+        Fs_o, _, Fv_o = OM.propagate(spec, state, X, z, S)
+        assert_allclose(Fv[0], Fv_o[0], rtol=1e-6, atol=1e-9)
+    from doubly_stochastic_dgp.utils import reparameterize
+    v = np.array(Fv[0])
+    v[0, :M] = -1e-3                                # below -jitter: the reference's sqrt returns NaN there
+    out = reparameterize(np.zeros_like(v), v, z[0])
+    assert np.all(np.isnan(out[0, :M])) and np.all(np.isfinite(out[0, M:]))

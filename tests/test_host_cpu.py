@@ -139,3 +139,35 @@ def test_shard_terms_rejects_empty_minibatch():
     assert shard_terms(7372, 1000, 8) == (7372 / 8000.0, 0.125)
     with pytest.raises(ValueError):
         shard_terms(100, 0, 1)
+
+
+def test_minibatch_span_epoch_is_bumped_by_every_regeneration():
+    """A minibatch that straddles an epoch boundary regenerates the permutation inside next_indices(); the spans that follow
+    must announce a NEW epoch so that the device copy of the permutation is refreshed (N % B != 0 is the normal case, e.g.
+    7372 / 1000)."""
+    from doubly_stochastic_dgp.dgp import Minibatch
+    N, B = 25, 10
+    mb, ref = Minibatch(N, B, seed=3), Minibatch(N, B, seed=3)
+    uploaded_epoch, perm_dev = None, None
+    for _ in range(40):
+        want = ref.next_indices()                      # the plain stream of indices (ground truth)
+        span = mb.next_span()
+        if span is not None:
+            perm, start, epoch = span
+            if epoch != uploaded_epoch:                # what DGP_Base.next_minibatch does with its device copy
+                perm_dev, uploaded_epoch = perm.copy(), epoch
+            got = perm_dev[start:start + B]
+        else:
+            got = mb.next_indices()
+        assert np.array_equal(got, want)
+
+
+def test_multiclass_targets_are_validated():
+    from doubly_stochastic_dgp.gpflow_compat import Gaussian, MultiClass
+    from doubly_stochastic_dgp.utils import BroadcastingLikelihood
+    lik = BroadcastingLikelihood(MultiClass(3))
+    lik.check_targets(np.array([[0.0], [2.0], [1.0]]))
+    for bad in (np.array([[3.0]]), np.array([[-1.0]]), np.array([[0.5]]), np.array([[np.nan]]), np.eye(3)):
+        with pytest.raises(ValueError):
+            lik.check_targets(bad)
+    BroadcastingLikelihood(Gaussian()).check_targets(np.array([[0.3, -7.0]]))   # real-valued targets: nothing to check
