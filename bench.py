@@ -8,9 +8,14 @@ Adam(0.01) update — i.e. one `session.run(opt_op)` of demos/demo_regression_UC
 data (real UCI data cannot be downloaded): N_data=7372, D=8, widths 8->8->8->1, RBF, M=128, S=20, minibatch 1000, fp64,
 white=False, inner q_sqrt * 1e-5.  Inputs are resident in HBM before the timed region.
 
-N>1: one process per GPU (torch.distributed / RCCL); every rank takes its own 1000-row minibatch x all S samples (rows are
-independent through all layers), the flat gradient is summed with ONE all-reduce per step; value = N * global steps/s
-(minibatch-1000 ELBO steps per second, whole job) -> "scaling": "weak".
+N>1: one process per GPU (torch.distributed / RCCL).  Default `--scaling strong` (BASELINE's metric at N GPUs): the GLOBAL
+minibatch stays 1000 rows x S=20, every rank takes 1000/N rows x all S samples (rows are independent through all layers), the
+flat gradient is summed with one all-reduce per step and every rank applies the same Adam update; value = global steps/s
+(NO x N).  `--scaling weak` keeps 1000 rows per GPU (global batch 1000 N) and reports N x steps/s.
+
+Timing protocol: the secondary measurements (forward-only evals/s, predict_f rows/s, per-kernel HIP-event times, the
+sub-rooflines) run FIRST and bring the GPU to its steady clocks; then W untimed warm-up steps, then EXACTLY K steps between
+barrier + synchronize -> `value`.  A separate loop times >= 200 single steps with events for median / p10 / p90.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HIP-event timed dominant kernel) and
 `cpu_baseline` (the CPU oracle — a port of the GPflow/TF op sequence, NOT TF itself — timed on this box's host cores).
@@ -72,13 +77,13 @@ def default_Z(X, M, seed=0):
         return X[rng.permutation(X.shape[0])[:M]].copy()
 
 
-def build_model(cfg, rank, world):
+def build_model(cfg, rank, world, mb_local):
     from doubly_stochastic_dgp.dgp import DGP
     from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian
     X, Y = make_synthetic(cfg["n_data"], cfg["D"], seed=0)
     Z = default_Z(X, cfg["M"], seed=0)
     kernels = [RBF(cfg["D"]) for _ in range(cfg["L"])]
-    model = DGP(X, Y, Z, kernels, Gaussian(), num_samples=cfg["S"], minibatch_size=cfg["mb"])
+    model = DGP(X, Y, Z, kernels, Gaussian(), num_samples=cfg["S"], minibatch_size=mb_local)
     for layer in model.layers[:-1]:
         layer.q_sqrt = layer.q_sqrt.value * 1e-5                      # demo_regression_UCI.ipynb:183
     if world > 1:
@@ -118,12 +123,70 @@ def cpu_baseline(cfg, X, Y, Z, budget_s=20.0):
                        f"GPflow/TF op sequence incl. autograd + Adam; not TF itself), {el:.1f} s")
 
 
+def sub_rooflines(ctx):
+    """The two sub-rooflines north_star names besides the fused chain:
+    * Gram build (a MATERIALISED Kuf, layers.py:184, dsdgp_gram): HBM-bound, algorithmic bytes 8 n n2 + 8 D (n + n2), against
+      8 TB/s; HIP-event timed here, FETCH/WRITE_SIZE counters of the same launches in profiles/r02_gram_pmc.md;
+    * Cholesky + triangular inverse of Kuu at M = 1024 (layers.py:172,186-188: the multi-workgroup blocked path),
+      2 M^3 / 3 flops against the 78.6 TFLOP/s fp64 MFMA peak."""
+    import ctypes as C
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.default_rng(1)
+    out = {"gram": [], "potrf_trtri": []}
+    ls = np.ones(1)
+    ctx.prof_enable(True)
+    for (M, R, D) in ((128, 20000, 8), (256, 40000, 9), (512, 40960, 30), (1024, 50000, 8)):
+        Z, X = ctx.to_device(rng.standard_normal((M, D))), ctx.to_device(rng.standard_normal((R, D)))
+        o = ctx.empty(M, R)
+        spec = _lib.KernelSpec(kind=0, input_dim=D, ard=0, has_white=0, variance=1.0, white_variance=0.0,
+                               lengthscales=ls.ctypes.data_as(_lib.c_double_p))
+
+        def call():
+            _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), C.c_void_p(Z.data_ptr()), M, C.c_void_p(X.data_ptr()), R,
+                                          0.0, C.c_void_p(o.data_ptr()), R))
+        for _ in range(3):
+            call()
+        ctx.prof_read("gram")
+        for _ in range(20):
+            call()
+        ms, cnt = ctx.prof_read("gram")
+        nbytes = 8 * M * R + 8 * D * (M + R)
+        gbs = nbytes / (ms / cnt * 1e-3) / 1e9
+        out["gram"].append(dict(n=M, n2=R, D=D, us_per_launch=round(1e3 * ms / cnt, 2), algorithmic_MB=round(nbytes / 1e6, 1),
+                                bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4)))
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian
+    for M in (128, 1024):
+        Xs = rng.standard_normal((M + 64, 8))
+        m1 = DGP(Xs, Xs[:, :1], Xs[:M] + 0.01 * rng.standard_normal((M, 8)), [RBF(8)], Gaussian(), num_samples=1)
+        e1 = m1.engine()
+        e1.prepare()
+        ctx.prof_read("potrf")
+        reps = 5
+        for _ in range(reps):
+            e1._needs_prepare = True
+            e1.prepare()
+        ms, cnt = ctx.prof_read("potrf")
+        fl = 2.0 * M ** 3 / 3.0
+        tf = fl / (ms / reps * 1e-3) / 1e12
+        out["potrf_trtri"].append(dict(n=M, us=round(1e3 * ms / reps, 1), algorithmic_gflop=round(fl / 1e9, 3), bound="mfma",
+                                       achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                       frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                       note="one matrix; latency-bound launch sequence" if M >= 512 else
+                                            "one LDS-resident workgroup; latency-bound"))
+    ctx.prof_enable(False)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = global minibatch fixed at 1000 (BASELINE's metric), weak = 1000 rows per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiler runs)")
     args = ap.parse_args()
 
     import torch
@@ -138,10 +201,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
-    cfg = CFG
-    model, X, Y, Z = build_model(cfg, rank, world)
+    cfg = dict(CFG)
+    if args.scaling == "strong" and world > 1:
+        if cfg["mb"] % world:
+            raise SystemExit(f"strong scaling needs the global minibatch {cfg['mb']} divisible by {world}")
+        mb_local = cfg["mb"] // world
+    else:
+        mb_local = cfg["mb"]
+    model, X, Y, Z = build_model(cfg, rank, world, mb_local)
     eng = model.engine()
     ctx = eng.ctx
+    cfg_local = dict(cfg, mb=mb_local)        # per-GPU shard: what one launch of this rank processes
 
     def barrier():
         if world > 1:
@@ -149,6 +219,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):
+        model.train_step(0.01)
+    torch.cuda.synchronize()
+
+    evals_per_s = predict_rows_per_s = None
+    prof = {}
+    sub = {}
+    steady = None
+    if not args.no_extras:
+        # secondary metrics: forward-only ELBO evals/s and predict_f rows/s (per rank)
+        n_ev = 50
+        Xb, Yb = model.next_minibatch()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_ev):
+            eng.elbo(Xb, Yb, cfg["S"], seed=i, data_scale=1.0, with_grad=False, sync=False)
+        torch.cuda.synchronize()
+        evals_per_s = n_ev / (time.perf_counter() - t1)
+        Xs = ctx.to_device(X[:1000])
+        eng.propagate(Xs, 100, seed=1, want=("mean", "var"))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(20):
+            eng.propagate(Xs, 100, seed=i, want=("mean", "var"))
+        torch.cuda.synchronize()
+        predict_rows_per_s = 20 * 100 * 1000 / (time.perf_counter() - t1)
+
+        # per-kernel HIP-event timing on the launch streams (events perturb the pipeline slightly, hence a separate loop); the
+        # wgrad/backward side-stream overlap is switched off here so that each duration is the kernel's own
+        os.environ["DSDGP_NO_OVERLAP"] = "1"
+        ctx.prof_enable(True)
+        nprof = 20
+        for _ in range(nprof):
+            model.train_step(0.01)
+        torch.cuda.synchronize()
+        for name in ("layer_fwd", "layer_bwd", "wgrad", "gemm", "potrf"):
+            ms, cnt = ctx.prof_read(name)
+            prof[name] = dict(ms_per_step=ms / nprof, launches_per_step=cnt / nprof)
+        ctx.prof_enable(False)
+        os.environ["DSDGP_NO_OVERLAP"] = "0"
+        if rank == 0:
+            sub = sub_rooflines(ctx)
+        # steady-state distribution: single steps bracketed by events on the launch stream (ctx stream == torch's current stream)
+        nst = 300
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)]
+        for _ in range(20):
+            model.train_step(0.01)
+        evs[0].record()
+        for i in range(nst):
+            model.train_step(0.01)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nst)])
+        steady = dict(n=nst, median_ms=round(float(np.median(ts)), 4), p10_ms=round(float(np.percentile(ts, 10)), 4),
+                      p90_ms=round(float(np.percentile(ts, 90)), 4), mean_ms=round(float(ts.mean()), 4),
+                      note="per-step HIP events on the launch stream; the gradient all-reduce (N>1) is inside each step")
+
+    # ---- the contract's timed region: W warm-up steps, then EXACTLY K steps
     for _ in range(args.warmup):
         model.train_step(0.01)
     barrier()
@@ -164,75 +292,61 @@ def main():
         dt = float(t.item())
     elbo = model.train_step(0.01, sync=True)
 
-    # secondary metrics (untimed region of the contract): forward-only ELBO evals/s and predict_f rows/s
-    n_ev = 50
-    Xb, Yb = model.next_minibatch()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(n_ev):
-        eng.elbo(Xb, Yb, cfg["S"], seed=i, data_scale=1.0, with_grad=False, sync=False)
-    torch.cuda.synchronize()
-    evals_per_s = n_ev / (time.perf_counter() - t1)
-    Xs = ctx.to_device(X[:1000])
-    eng.propagate(Xs, 100, seed=1, want=("mean", "var"))
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(20):
-        eng.propagate(Xs, 100, seed=i, want=("mean", "var"))
-    torch.cuda.synchronize()
-    predict_rows_per_s = 20 * 100 * 1000 / (time.perf_counter() - t1)
-
-    # per-kernel HIP-event timing on the launch streams (separate loop: events perturb the pipeline slightly); the
-    # wgrad/backward side-stream overlap is switched off here so that each duration is the kernel's own
-    os.environ["DSDGP_NO_OVERLAP"] = "1"
-    ctx.prof_enable(True)
-    nprof = 20
-    for _ in range(nprof):
-        model.train_step(0.01)
-    torch.cuda.synchronize()
-    prof = {}
-    for name in ("layer_fwd", "layer_bwd", "wgrad", "gemm", "potrf"):
-        ms, cnt = ctx.prof_read(name)
-        prof[name] = dict(ms_per_step=ms / nprof, launches_per_step=cnt / nprof)
-    ctx.prof_enable(False)
-    os.environ["DSDGP_NO_OVERLAP"] = "0"
-    fl = algorithmic_flops(cfg)
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md: 2*FETCH_SIZE + WRITE_SIZE,
-    # same command, gfx950 correction of MI355X_MICROARCH.md); None when the profile is not shipped
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("wgrad", "k_wgrad<4, 4>")):
-            hit = [v for k, v in pmc.items() if k.startswith(key)]
-            if hit:
-                traffic[name] = round(hit[0]["traffic_MB_per_launch"] * 1e6)
-    except Exception:
-        pass
+    fl = algorithmic_flops(cfg_local)
+    fl_global = algorithmic_flops(cfg)
+    # HBM bytes per launch: NOT measured in this process (PMC counters need rocprofv3) — read from the committed summary of
+    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (2*FETCH + WRITE, the gfx950
+    # correction of MI355X_MICROARCH.md) and labelled with its source; null when no current profile is shipped
+    traffic, traffic_source = {}, None
+    for cand in ("r02_pmc_traffic.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                pmc = json.load(f)
+            for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("wgrad", "k_wgrad<")):
+                hit = [v for k, v in pmc.items() if k.startswith(key)]
+                if hit:
+                    n_l = sum(h["launches"] for h in hit)
+                    traffic[name] = round(sum(h["traffic_MB_per_launch"] * h["launches"] for h in hit) / n_l * 1e6)
+            traffic_source = f"profiles/{cand} (separate rocprofv3 --pmc passes of this command, not measured in this run)"
+            break
+        except Exception:
+            pass
     roof_all = {}
     for name in ("layer_fwd", "layer_bwd", "wgrad"):
+        if name not in prof:
+            continue
         ms = prof[name]["ms_per_step"]
         ach = fl[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof_all[name] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                              frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name),
+                              frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name), traffic_source=traffic_source,
                               ms_per_step=round(ms, 4), launches_per_step=prof[name]["launches_per_step"],
                               algorithmic_gflop_per_step=round(fl[name] / 1e9, 3))
-    dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])
-    roofline = dict(roof_all[dominant], kernel=dominant)
+    roofline = None
+    if roof_all:
+        dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])
+        roofline = dict(roof_all[dominant], kernel=dominant)
 
     if rank == 0:
         steps_per_s = args.steps / dt
+        weak = args.scaling == "weak" and world > 1
+        value = steps_per_s * (world if weak else 1)
         out = {
-            "metric": "ELBO-steps/sec", "value": round(steps_per_s * world, 3), "unit": "steps/s (minibatch-1000 ELBO+grad+Adam steps, whole job)",
+            "metric": "ELBO-steps/sec", "value": round(value, 3),
+            "unit": ("steps/s (minibatch-1000-per-GPU ELBO+grad+Adam steps x GPUs, whole job)" if weak else
+                     "steps/s (global-minibatch-1000 ELBO+grad+Adam steps, whole job)"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-layer DS-DGP, kin8nm-shaped (7372x8), RBF, M=128, S=20, minibatch=1000 per GPU, "
-                                   "fp64, white=False (BASELINE.json configs[1])",
-                       "per_gpu_minibatch": cfg["mb"], "global_batch": cfg["mb"] * world, "num_samples": cfg["S"],
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "3-layer DS-DGP, kin8nm-shaped (7372x8), RBF, M=128, S=20, global minibatch "
+                                   f"{mb_local * world} ({mb_local} rows per GPU), fp64, white=False (BASELINE.json configs[1])",
+                       "per_gpu_minibatch": mb_local, "global_batch": mb_local * world, "num_samples": cfg["S"],
                        "inducing": cfg["M"], "layers": cfg["L"], "parallelism": f"row-sharded dp{world}"},
-            "roofline": roofline, "roofline_all": roof_all, "kernel_ms_per_step": prof,
-            "step_fraction_of_fp64_peak": round(fl["step"] * steps_per_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-            "elbo_evals_per_s": round(evals_per_s, 2), "predict_f_rows_per_s": round(predict_rows_per_s, 1),
+            "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "kernel_ms_per_step": prof,
+            "step_time": steady,
+            "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world
+                                                / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+            "elbo_evals_per_s": None if evals_per_s is None else round(evals_per_s, 2),
+            "predict_f_rows_per_s": None if predict_rows_per_s is None else round(predict_rows_per_s, 1),
             "final_elbo": elbo,
         }
         if world == 1 and not args.no_cpu_baseline:

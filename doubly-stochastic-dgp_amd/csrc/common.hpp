@@ -56,9 +56,15 @@ struct dsdgp_ctx {
   size_t scratch_bytes = 0;
   int prof_on = 0;
   std::map<std::string, ProfSlot> prof;
+  // pinned staging ring for the small host->device descriptor uploads of the primitive entry points (kernel hyper-parameters,
+  // GEMM / factorisation descriptors): the copy is enqueued from pinned memory and the call returns — no stream synchronisation
+  char* pin = nullptr;
+  size_t pin_bytes = 0, pin_off = 0;
 };
 
 int ctx_scratch(dsdgp_ctx* ctx, size_t bytes, void** out);
+// asynchronous upload of a small host object to device memory `dst` on the ctx stream (the host copy may die on return)
+int ctx_upload(dsdgp_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 // RAII-ish profiling bracket: records HIP events on the ctx stream around a launch when profiling is enabled.
 struct ProfScope {

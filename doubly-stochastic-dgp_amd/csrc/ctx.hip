@@ -49,6 +49,7 @@ extern "C" int dsdgp_ctx_destroy(dsdgp_ctx* ctx) {
       hipEventDestroy(ev.second);
     }
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return DSDGP_OK;
@@ -71,6 +72,30 @@ int ctx_scratch(dsdgp_ctx* ctx, size_t bytes, void** out) {
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;
+  return DSDGP_OK;
+}
+
+int ctx_upload(dsdgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  const size_t RING = 1 << 20;
+  if (!ctx->pin) {
+    DS_HIP(hipHostMalloc((void**)&ctx->pin, RING, hipHostMallocDefault));
+    ctx->pin_bytes = RING;
+    ctx->pin_off = 0;
+  }
+  const size_t need = (size_t)round_up((int64_t)bytes, 64);
+  if (need > ctx->pin_bytes) {        // larger than the ring: a plain (synchronised) copy
+    DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+    return DSDGP_OK;
+  }
+  if (ctx->pin_off + need > ctx->pin_bytes) {
+    DS_HIP(hipStreamSynchronize(ctx->stream));     // wrap-around: once per MiB of descriptors
+    ctx->pin_off = 0;
+  }
+  char* slot = ctx->pin + ctx->pin_off;
+  ctx->pin_off += need;
+  memcpy(slot, src, bytes);
+  DS_HIP(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
   return DSDGP_OK;
 }
 

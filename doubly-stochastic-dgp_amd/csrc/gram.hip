@@ -95,8 +95,7 @@ extern "C" int dsdgp_gram(dsdgp_ctx* ctx, const dsdgp_kernel* kern, const double
   for (int j = 0; j < D; ++j) hyp[HYP_ILS + j] = 1.0 / kern->lengthscales[kern->ard ? j : 0];
   void* scr;
   DS_TRY(ctx_scratch(ctx, hyp.size() * sizeof(double), &scr));
-  DS_HIP(hipMemcpyAsync(scr, hyp.data(), hyp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  DS_HIP(hipStreamSynchronize(ctx->stream));
+  DS_TRY(ctx_upload(ctx, scr, hyp.data(), hyp.size() * sizeof(double)));     // asynchronous (pinned staging ring)
   const double diag_add = symmetric ? (hyp[HYP_WVAR] + jitter) : 0.0;
   return gram_launch(ctx, kern->kind, X, n, X2, n2, D, (const double*)scr, diag_add, symmetric, out, ld_out);
 }

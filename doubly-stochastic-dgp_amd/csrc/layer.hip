@@ -581,14 +581,126 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
       }
 }
 
+// Cooperative form: ONE WORKGROUP per (job, split, tile) task; its four waves take a quarter of the split's row range each and
+// reduce their accumulators through LDS in a fixed order ((w0 + w2) + (w1 + w3)) before wave 0 stores the partial.  Same
+// wave-level parallelism with a quarter of the split-K partials (less traffic for k_reduce_grouped, which is bandwidth /
+// latency-bound), or twice the waves per SIMD at half the partials — fp64 MFMA needs >= 2 waves per SIMD for its pipe rate.
+template <int NI, int NJ>
+__global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
+                                                    int64_t Rp, int total_tasks) {
+  __shared__ double red[2 * NI * NJ * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int w = blockIdx.x;
+  int jb = 0;
+  while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
+  const WgradJob J = jobs[jb];
+  int local = w - J.task_start;
+  int split, tile_i, tile_j, ns_eff = nsplit;
+  if (J.sym) {
+    const int n_off = J.ti * (J.ti - 1) / 2;
+    if (local < nsplit * n_off) {
+      split = local / n_off;
+      local = local % n_off;
+      tile_i = 1;
+      while (tile_i * (tile_i + 1) / 2 <= local) ++tile_i;
+      tile_j = local - tile_i * (tile_i - 1) / 2;
+    } else {
+      local -= nsplit * n_off;
+      split = local / J.ti;
+      tile_i = tile_j = local % J.ti;
+      ns_eff = J.ns_diag;
+    }
+  } else {
+    const int tiles = J.ti * J.tj;
+    split = local / tiles;
+    local = local % tiles;
+    tile_i = local / J.tj;
+    tile_j = local % J.tj;
+  }
+  const int64_t nch = Rp / 16;
+  const int64_t s_lo = split * nch / ns_eff, s_hi = (split + 1) * nch / ns_eff;
+  const int64_t c_lo = s_lo + (s_hi - s_lo) * wave / 4, c_hi = s_lo + (s_hi - s_lo) * (wave + 1) / 4;
+  const int njv = (J.qrows16 - NJ * tile_j < NJ) ? J.qrows16 - NJ * tile_j : NJ;
+  d4 acc[NI][NJ];
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
+  const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
+  const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
+  const bool diag = J.sym && tile_i == tile_j && NI == NJ;
+  if (diag)
+    wgrad_loop<NI, NJ, false, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else if (njv == NJ)
+    wgrad_loop<NI, NJ, false, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else
+    wgrad_loop<NI, NJ, true, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+  // fixed-order tree over the four waves: slot s of a wave's accumulator lives at red[region][s][lane]
+  constexpr int NS = NI * NJ * 4;
+  if (wave >= 2) {
+    double* r = red + (wave - 2) * NS * 64 + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[((ii * NJ + jj) * 4 + t) * 64] = acc[ii][jj][t];
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const double* r = red + wave * NS * 64 + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ii][jj][t] += r[((ii * NJ + jj) * 4 + t) * 64];
+  }
+  __syncthreads();
+  if (wave == 1) {
+    double* r = red + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[((ii * NJ + jj) * 4 + t) * 64] = acc[ii][jj][t];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const double* r = red + lane;
+  const int rowsP = 16 * NI * J.ti;
+  double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      if (jj < njv && !(diag && jj > ii)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] =
+              acc[ii][jj][t] + r[((ii * NJ + jj) * 4 + t) * 64];
+      }
+}
+
+int wgrad_coop_enabled() {
+  static const int on = getenv("DSDGP_WGRAD_COOP") ? atoi(getenv("DSDGP_WGRAD_COOP")) : 1;
+  return on;
+}
+
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
                  int NI, int NJ, hipStream_t stream) {
   hipStream_t st = stream ? stream : ctx->stream;
   ProfScope ps(ctx, "wgrad", st);
-  const dim3 grid(ceil_div(total_tasks, 4)), blk(256);
+  const bool coop = wgrad_coop_enabled();
+  const dim3 grid(coop ? total_tasks : ceil_div(total_tasks, 4)), blk(256);
 #define WG_CASE(I, Jn)                                                                                              \
   if (NI == I && NJ == Jn) {                                                                                        \
-    hipLaunchKernelGGL((k_wgrad<I, Jn>), grid, blk, 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks); \
+    if (coop)                                                                                                       \
+      hipLaunchKernelGGL((k_wgrad_coop<I, Jn>), grid, blk, 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);    \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_wgrad<I, Jn>), grid, blk, 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);         \
     DS_HIP(hipGetLastError());                                                                                      \
     return DSDGP_OK;                                                                                                \
   }

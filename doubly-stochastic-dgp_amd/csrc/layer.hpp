@@ -94,6 +94,7 @@ int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kin
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
                  int NI, int NJ, hipStream_t stream = nullptr);
 size_t layer_fwd_lds_bytes(int Mp, int D_in);
+int wgrad_coop_enabled();   // one workgroup per split-K task, four waves reducing through LDS (default) instead of one wave per task
 // split-M variants (layer_sm.hip): 4 waves cooperate on one block of 16*CB rows
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);

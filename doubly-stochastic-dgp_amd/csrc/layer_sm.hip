@@ -62,6 +62,26 @@ struct Own {
   static __device__ __forceinline__ bool active(int wave) { return MPB >= NW || wave < MPB; }
 };
 
+// Row-block ownership of the Csave backward d-loop (abar += q_sqrt_d cbar_d, a TRIANGULAR product: row block ib costs ib + 1
+// k-blocks).  8-wave workgroups at Mp = 128 / 256 split into four LIGHT waves, which also stage cbar_d from global memory into
+// LDS, and four HEAVY waves, which never issue those loads: vmcnt retires loads in order, so a wave that has the (HBM-latency)
+// cbar_{d+1} loads in flight stalls at its first (L2-latency) weight fetch — with every wave staging, each output paid the full
+// HBM latency (measured: 67 % of the wave cycles parked, backward chain 1.45x SLOWER than the dense S_d form).  Waves w and w + 4
+// share a SIMD: light wave s + heavy wave 4 + s carry the same MFMA count on every SIMD (9 blocks at Mp = 128, 34 at Mp = 256).
+template <int MPB, int NW>
+struct OwnCS {
+  static constexpr bool CUSTOM = (NW == 8) && (MPB == 8 || MPB == 16);
+  static constexpr int NQ = CUSTOM ? MPB / 8 : Own<MPB, NW>::NQ;
+  static constexpr int NLOAD = CUSTOM ? 4 : NW;      // waves that stage cbar_d
+  static __device__ __forceinline__ int ib(int wave, int q) {
+    if constexpr (!CUSTOM) return Own<MPB, NW>::ib(wave, q);
+    if constexpr (MPB == 8) return wave < 4 ? wave : 11 - wave;                         // light: 0..3 ; heavy: 7, 6, 5, 4
+    if (wave < 4) return q == 0 ? 7 - wave : wave;                                      // light: (7 - s, s)
+    return q == 0 ? 19 - wave : 4 + wave;                                               // heavy: (15 - s, 8 + s), s = wave - 4
+  }
+  static __device__ __forceinline__ bool active(int wave) { return CUSTOM || Own<MPB, NW>::active(wave); }
+};
+
 // outputs per epilogue group of the forward chain: their variance / mean partials are parked in LDS, ONE barrier per group,
 // then all threads write the group's mean / var / F as contiguous runs (the per-output form paid a barrier and 16 scattered
 // 8-byte stores per output).  Double-buffered by group parity.  NW = 16 keeps one output per group (LDS is full at M = 1024).
@@ -77,13 +97,16 @@ static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide, int n
   const int xch = D_in < XCH ? D_in : XCH;
   L.xs = o; o += 16 * (xch + 1);
   o = (int)round_up(o, 2);
-  L.act = o; o += nbuf * Mp * 16;   // nbuf = 2: the Csave backward chain double-buffers its staged operand (Mp <= 256)
-  L.red = o;
+  L.act = o; o += Mp * 16;
+  L.red = o;                        // nbuf = 2 (Csave backward chain, Mp <= 256): the second staging buffer; it is free again when the
+                                    // epilogue needs `red`, so the two share the space
   const bool mu_early = (NW == 4) && !wide;
   const int db = sm_db(NW);
   const int red_fwd = NW * 16 + 2 * db * NW * 16 + (mu_early ? NW * 16 * D_out : 2 * db * NW * 16);   // s1 | 2 x [db] s2 | mean partials
   const int red_bwd = NW * 16 * xch;                            // dX partials of one chunk
-  o += red_fwd > red_bwd ? red_fwd : red_bwd;
+  int red = red_fwd > red_bwd ? red_fwd : red_bwd;
+  if (nbuf == 2 && red < Mp * 16) red = Mp * 16;
+  o += red;
   L.total = o;
   return L;
 }
@@ -317,8 +340,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const double cv = (r < a.Rin) ? cacc[q][t] : 0.0;
-              if (a.flags & 1) __builtin_nontemporal_store(cv, &Cd[out_slot<D4>(ib, g, t) * 16]);
-              else Cd[out_slot<D4>(ib, g, t) * 16] = cv;
+              Cd[out_slot<D4>(ib, g, t) * 16] = cv;
             }
           }
         }
@@ -340,9 +362,15 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
     __syncthreads();
-    // epilogue of the group: thread e <-> (row cc, output dd); a row's gs outputs are contiguous in mean / var / F
-    for (int e = tid; e < 16 * gs; e += NW * 64) {
-      const int cc = e / gs, dd = e % gs, d = d0 + dd;
+    // epilogue of the group: thread e <-> (sample s, row cc, output dd); a row's gs outputs are contiguous in mean / var / F.
+    // The first layer writes `rep` = S output rows per input row: those are spread over the threads too (one thread walking
+    // its S rows serially — z load, three stores each — was a third of that latency-bound launch); a Linear mean function keeps
+    // the per-row form (its D_in-long dot product is not worth repeating per sample).
+    const bool flat = a.rep > 1 && a.mean_kind != DSDGP_MEAN_LINEAR;
+    const int n_items = 16 * gs * (flat ? a.rep : 1);
+    for (int e = tid; e < n_items; e += NW * 64) {
+      const int s0 = flat ? e / (16 * gs) : 0, e2 = e % (16 * gs);
+      const int cc = e2 / gs, dd = e2 % gs, d = d0 + dd;
       const int64_t r = r0 + cc;
       if (r >= a.Rin) continue;
       double s1 = 0.0, s2sum = 0.0, mu = 0.0;
@@ -361,7 +389,8 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
         mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
       }
       const double sd = sqrt(var + a.jitter);
-      for (int s = 0; s < a.rep; ++s) {
+      const int s_lo = flat ? s0 : 0, s_hi = flat ? s0 + 1 : a.rep;
+      for (int s = s_lo; s < s_hi; ++s) {
         const int64_t orow = (int64_t)s * a.Rin + r;
         const int64_t o = orow * Dout + d;
         if (a.mean) a.mean[o] = mu;
@@ -415,30 +444,33 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     // cbar_d = 2 vbar_d c_d staged into LDS ([k][16 rows], B-operand order), abar += q_sqrt_d cbar_d: out block ib sums kb <= ib.
     // Mp <= 256: two staging buffers (the loads of output d+1 fly during the products of d, one barrier per output);
     // Mp >= 512: LDS holds one buffer (two barriers per output, loads still prefetched).
+    using OC = OwnCS<MPB, NW>;
     constexpr bool DBUF = (MPB <= 16);
-    constexpr int NS = Mp * 16 / (NW * 64 * 2);   // staged element PAIRS per thread (16-byte loads / LDS stores)
-    double* buf1 = DBUF ? actb + Mp * 16 : actb;
-    const int e0 = 2 * tid;                       // pair i of this thread: elements e0 + i * NW * 128 (+1) of the tile; rows scc, scc + 1
+    constexpr int NLT = OC::NLOAD * 64;             // staging threads
+    constexpr int NS = Mp * 16 / (NLT * 2);         // staged element PAIRS per staging thread (16-byte loads / LDS stores)
+    double* buf1 = DBUF ? smem + L.red : actb;
+    const bool stager = tid < NLT;
+    const int e0 = 2 * tid;                         // pair i of this thread: elements e0 + i * 2 NLT (+1) of the tile; rows scc, scc + 1
     const int scc = e0 & 15;
-    const bool sin = r0 + scc < a.ldA;            // ldA is a multiple of 16: scc + 1 is inside too
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2 tmp[NS];
     auto stage_load = [&](int d) {
-      const d2 v2 = sin ? 2.0 * *reinterpret_cast<const d2*>(a.VB + (int64_t)d * a.ldA + r0 + scc) : (d2){0, 0};
+      if (!stager) return;
+      const d2 v2 = 2.0 * *reinterpret_cast<const d2*>(a.VB + (int64_t)d * a.ldA + r0 + scc);
       const double* __restrict__ Cd = a.Csave + ((int64_t)blockIdx.x * Dout + d) * (Mp * 16) + e0;
-      if (a.flags & 1) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) tmp[i] = v2 * __builtin_nontemporal_load(reinterpret_cast<const d2*>(Cd + i * NW * 128));
-      } else {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) tmp[i] = v2 * *reinterpret_cast<const d2*>(Cd + i * NW * 128);
-      }
+      for (int i = 0; i < NS; ++i) tmp[i] = v2 * *reinterpret_cast<const d2*>(Cd + i * 2 * NLT);
     };
     auto stage_store = [&](double* buf) {
+      if (!stager) return;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) *reinterpret_cast<d2*>(buf + e0 + i * NW * 128) = tmp[i];
+      for (int i = 0; i < NS; ++i) *reinterpret_cast<d2*>(buf + e0 + i * 2 * NLT) = tmp[i];
     };
     constexpr bool PREF = (NW < 16);            // NW = 16 (1024 threads, 128-VGPR cap): no prefetch across the products (spills)
+    d4 cacc[OC::NQ];
+#pragma unroll
+    for (int q = 0; q < OC::NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
+    const bool cact = OC::active(wave);
     if (PREF) stage_load(0);
     if (DBUF) stage_store(actb);
     for (int d = 0; d < Dout; ++d) {
@@ -454,17 +486,43 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         __syncthreads();
         if (PREF && d + 1 < Dout) stage_load(d + 1);
       }
-      if (act) {
+      if (cact) {
         const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
         const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
+        for (int q = 0; q < OC::NQ; ++q) {
+          const int ib = OC::ib(wave, q);
 #pragma unroll 4
-          for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(Td, TdT, cur, ib, kb, g, c, acc[q]);
+          for (int kb = 0; kb <= ib; ++kb) cacc[q] = chain_block<Mp, D4>(Td, TdT, cur, ib, kb, g, c, cacc[q]);
         }
       }
       if (DBUF && d + 1 < Dout) stage_store((d & 1) ? actb : buf1);
+    }
+    // mean part (abar += q_mu mbar) and hand-over of abar through LDS, under the d-loop's ownership
+    if (cact) {
+      for (int sp = 0; sp < a.DP4 / 4; ++sp) {
+        const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
+#pragma unroll
+        for (int q = 0; q < OC::NQ; ++q)
+          cacc[q] = mfma_f64(a.qmu4[(int64_t)(16 * OC::ib(wave, q) + c) * a.DP4 + 4 * sp + g], bv, cacc[q]);
+      }
+    }
+    __syncthreads();   // the last staged operand is consumed -> abar goes into the first buffer
+    if (cact) {
+#pragma unroll
+      for (int q = 0; q < OC::NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) actb[out_slot<D4>(OC::ib(wave, q), g, t) * 16 + c] = cacc[q][t];
+    }
+    __syncthreads();
+    if (WHITE) {       // a1bar = abar - 2 gsum a1, applied by the waves that hold those rows of a1 (standard ownership)
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) actb[out_slot<D4>(Own<MPB, NW>::ib(wave, q), g, t) * 16 + c] -= 2.0 * gsum * av[q][t];
+      }
+      __syncthreads();
     }
   } else {
   __syncthreads();
@@ -504,6 +562,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     }
   }
   }
+  if constexpr (!CS) {
   if (act) {
     for (int sp = 0; sp < a.DP4 / 4; ++sp) {
       const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
@@ -527,6 +586,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     }
   }
   __syncthreads();
+  }
   // b = Ku^{-1} abar (dense)   |   white: kbar = Lu^{-T} a1bar (k-blocks >= own block)
   d4 bb[NQ];
 #pragma unroll

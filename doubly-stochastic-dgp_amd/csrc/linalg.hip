@@ -506,8 +506,7 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   for (int b = 0; b < batch; ++b) {
     items[b] = PotrfItem{P + (size_t)b * np * np, nullptr, nullptr, scal_d + 2 * b, np, np, n, 0, 0, 0};
   }
-  DS_HIP(hipMemcpyAsync(items_d, items.data(), batch * sizeof(PotrfItem), hipMemcpyHostToDevice, ctx->stream));
-  DS_HIP(hipStreamSynchronize(ctx->stream));  // items vector is stack-lifetime
+  DS_TRY(ctx_upload(ctx, items_d, items.data(), batch * sizeof(PotrfItem)));   // asynchronous (pinned staging ring)
   hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
   if (np >= 512 && np % 64 == 0) {
     // large matrices: multi-workgroup blocked path (temporary plan; the model path pre-builds its plans)
@@ -550,8 +549,7 @@ extern "C" int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, 
   const int total = gemm_plan(&P, 1);
   void* scr;
   DS_TRY(ctx_scratch(ctx, sizeof(GemmProblem), &scr));
-  DS_HIP(hipMemcpyAsync(scr, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
-  DS_HIP(hipStreamSynchronize(ctx->stream));
+  DS_TRY(ctx_upload(ctx, scr, &P, sizeof(P)));
   return gemm_launch(ctx, (const GemmProblem*)scr, 1, total);
 }
 
@@ -649,8 +647,7 @@ extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const 
   P.transA = trans ? 1 : 0; P.transB = 0;
   P.batch = 1; P.alpha = 1.0; P.beta = 0.0;
   const int total = gemm_plan(&P, 1);
-  DS_HIP(hipMemcpyAsync(Pd, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
-  DS_HIP(hipStreamSynchronize(ctx->stream));
+  DS_TRY(ctx_upload(ctx, Pd, &P, sizeof(P)));
   return gemm_launch(ctx, Pd, 1, total);
 }
 

@@ -79,6 +79,7 @@ struct LayerState {
   int64_t Rin_used;
   int rep_used;
   int64_t ld_used;
+  bool c_used = false;   // the last forward stored c_d (Csave) for the backward chain
 };
 
 struct dsdgp_model {
@@ -148,20 +149,31 @@ static int dbg_flags() {
   static const int f = getenv("DSDGP_DBG") ? atoi(getenv("DSDGP_DBG")) : 0;
   return f;
 }
-static bool save_c_enabled() {
-  static const int on = getenv("DSDGP_SAVE_C") ? atoi(getenv("DSDGP_SAVE_C")) : 1;
-  return on && sm_chain_enabled();
+// read per call (not cached) so that the parity tests can force the Csave chain onto small shapes
+static int cs_min_dout() { return getenv("DSDGP_CS_MIN_DOUT") ? atoi(getenv("DSDGP_CS_MIN_DOUT")) : 3; }
+static int cs_min_blocks() { return getenv("DSDGP_CS_MIN_BLOCKS") ? atoi(getenv("DSDGP_CS_MIN_BLOCKS")) : 160; }
+// Policy (measured, profiles/r02_csave_notes.md): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %: the per-output products are
+// long enough to hide the staging latency); at Mp = 128 / 256 the d-loop turns from MFMA-throughput-bound into latency-bound and
+// the chain gets no faster (cfg 2) or slower (cfg 3, register pressure halves the occupancy), so those sizes keep the S_d form.
+//   DSDGP_SAVE_C = 0: never, 1 (default): Mp >= 512, 2: every size (parity tests force the small instances)
+static int save_c_mode() { return getenv("DSDGP_SAVE_C") ? atoi(getenv("DSDGP_SAVE_C")) : 1; }
+static bool save_c_enabled(int Mp = 1 << 30) {
+  const int mode = save_c_mode();
+  return sm_chain_enabled() && (mode >= 2 || (mode == 1 && Mp >= 512));
 }
 static int big_mp(bool uniform) {
   static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
   return uniform ? v : 512;
 }
+// target_tasks: tasks of the launch (1024 = one per SIMD).  Cooperative launches count WORKGROUP tasks (four waves each): the
+// default 512 gives two waves per SIMD with half the partials of the one-wave-per-task form at 1024.
 static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
-  static const int scale = getenv("DSDGP_WGRAD_TARGET") ? atoi(getenv("DSDGP_WGRAD_TARGET")) : 1024;   // tuning knob (tasks for the big jobs)
+  const bool coop = wgrad_coop_enabled() != 0;
+  static const int scale = getenv("DSDGP_WGRAD_TARGET") ? atoi(getenv("DSDGP_WGRAD_TARGET")) : (coop ? 512 : 1024);   // tuning knob
   target_tasks = (int)((int64_t)target_tasks * scale / 1024);
   int ns = target_tasks / (tiles_per_split > 0 ? tiles_per_split : 1);
   if (ns < 1) ns = 1;
-  int64_t cap = nchunks / 4;
+  int64_t cap = nchunks / (coop ? 8 : 4);      // every wave keeps at least two (coop) / four 16-row chunks
   if (cap < 1) cap = 1;
   if (ns > cap) ns = (int)cap;
   return ns;
@@ -246,10 +258,10 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
     {
-      static const int alg_env = getenv("DSDGP_ALG_G") ? atoi(getenv("DSDGP_ALG_G")) : -1;   // -1: heuristic, 0: never, 1: always
+      const int alg_env = getenv("DSDGP_ALG_G") ? atoi(getenv("DSDGP_ALG_G")) : -1;   // -1: heuristic, 0: never, 1: always (read per model)
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
       v.alg_g = (!D.white && sm_chain_enabled() && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
-      v.need_tpt = (v.Mp >= 512 || save_c_enabled()) ? 1 : 0;
+      v.need_tpt = (v.Mp >= 512 || save_c_enabled(v.Mp)) ? 1 : 0;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }
@@ -264,7 +276,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
     S.ld_max = round_up(Rin_max, 16);
     S.A = b.take<double>(Mp * S.ld_max); S.E = b.take<double>(Mp * S.ld_max); S.GW = b.take<double>(Mp * S.ld_max);
-    S.C = save_c_enabled() ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
+    S.C = save_c_enabled((int)Mp) ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
     S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
     S.XT1 = b.take<double>((size_t)round_up(v.DinP16, 64) * S.ld_max);   // rows >= DinP16 stay zero: whole 64-row tiles for the mean-gradient product
     S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
@@ -1312,7 +1324,11 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
     a.Asave = save ? St.A : nullptr;
-    a.Csave = save ? St.C : nullptr;
+    // c_d is kept for the backward chain where that pays: enough row blocks to hide the extra latency per output (the N-row first
+    // layer is a latency-bound launch) and enough outputs for the halved d-loop to matter
+    // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
+    St.c_used = save && St.C && (v.Mp >= 512 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
+    a.Csave = St.c_used ? St.C : nullptr;
     a.flags = dbg_flags();
     a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
     {
@@ -1466,7 +1482,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
-    b.flags = dbg_flags(); b.Asave = St.A; b.Csave = St.C; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
+    b.flags = dbg_flags(); b.Asave = St.A; b.Csave = St.c_used ? St.C : nullptr; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
     b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
     if (sm && l >= 2) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
       LayerState& Pv = m->L[l - 1];

@@ -255,3 +255,28 @@ def test_negative_variance_gives_nan_like_the_reference():
     v[0, :M] = -1e-3                                # below -jitter: the reference's sqrt returns NaN there
     out = reparameterize(np.zeros_like(v), v, z[0])
     assert np.all(np.isnan(out[0, :M])) and np.all(np.isfinite(out[0, M:]))
+
+
+# ---------------------------------------------------------------- Csave backward chain / alg_g on small shapes
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("M,D", [(20, 3), (40, 4), (128, 8), (200, 5)])
+def test_csave_chain_and_alg_g_gradients(monkeypatch, white, M, D):
+    """The production heuristics keep the c_d-saving backward chain and the algebraic dl/dKu assembly for large launches; force
+    both onto small, oracle-checkable shapes (every Mp instance 32..256, both ownership tables, white and non-white)."""
+    monkeypatch.setenv("DSDGP_SAVE_C", "2")
+    monkeypatch.setenv("DSDGP_CS_MIN_BLOCKS", "0")
+    monkeypatch.setenv("DSDGP_CS_MIN_DOUT", "1")
+    monkeypatch.setenv("DSDGP_ALG_G", "1")
+    rng = np.random.RandomState(M + D)
+    N, S = 70, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D) * 1.3
+    specs = [kern_spec("rbf", D, 1.1, 1.4), kern_spec("matern52", D, 0.9, 1.2), kern_spec("rbf", D, 1.0, 1.0)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=500)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
+    ref, gref = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=500)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    g = model.engine().gradient_dict()
+    for k in gref:
+        assert np.max(np.abs(-gref[k] - g[k])) <= 1e-7 * (np.max(np.abs(gref[k])) + 1e-12), k
