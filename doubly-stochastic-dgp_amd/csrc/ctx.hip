@@ -1,4 +1,5 @@
 // Context, error reporting, scratch and HIP-event profiling of libdsdgp.
+#include <dlfcn.h>
 #include <stdarg.h>
 
 #include "common.hpp"
@@ -124,6 +125,48 @@ extern "C" int dsdgp_prof_read(dsdgp_ctx* ctx, const char* name, double* total_m
   if (reset) {
     s.ms = 0.0;
     s.launches = 0;
+  }
+  return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RCCL all-reduce of the flat [gradient | scalars] buffer (include/dsdgp.h).  ncclAllReduce is resolved at first use from
+// the RCCL already in the process (a torch process ships its own librccl) or from librccl.so: no link-time dependency.
+// ------------------------------------------------------------------------------------------------------
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void* /*ncclComm_t*/, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+static nccl_allreduce_fn g_allreduce = nullptr;
+static nccl_errstr_fn g_errstr = nullptr;
+
+static int resolve_rccl() {
+  if (g_allreduce) return DSDGP_OK;
+  void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+  void* h = nullptr;
+  if (!sym) {
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (h) sym = dlsym(h, "ncclAllReduce");
+  }
+  if (!sym) {
+    dsdgp_set_error("dsdgp_allreduce: RCCL (ncclAllReduce) is not loadable in this process: %s", dlerror() ? dlerror() : "symbol not found");
+    return DSDGP_ERR_RCCL;
+  }
+  g_allreduce = (nccl_allreduce_fn)sym;
+  g_errstr = (nccl_errstr_fn)(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_allreduce(dsdgp_ctx* ctx, void* comm, double* buf, int64_t count) {
+  DS_CHECK_ARG(ctx && comm && buf && count > 0);
+  DS_TRY(resolve_rccl());
+  const int ncclFloat64 = 8, ncclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+  const int rc = g_allreduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, comm, ctx->stream);
+  if (rc != 0) {
+    dsdgp_set_error("dsdgp_allreduce: ncclAllReduce failed: %s", g_errstr ? g_errstr(rc) : "unknown RCCL error");
+    return DSDGP_ERR_RCCL;
   }
   return DSDGP_OK;
 }

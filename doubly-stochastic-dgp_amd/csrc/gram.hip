@@ -1,62 +1,87 @@
 // Materialised Gram assembly: feature.Kuu / feature.Kuf (layers.py:171,184 -> [UPSTREAM] kern.K).
-// HBM-bound: each workgroup builds a 16 x 256 output tile from LDS-staged, lengthscale-scaled row tiles of X and X2
-// (pairwise squared distances by direct differences, so r2 >= 0 and K(X,X) is exactly symmetric), and writes it with
-// fully coalesced 2 KB row segments.  Algorithmic bytes = 8 * n * n2 (output) + 8 * D * (n + n2) (inputs).
+// HBM-bound: each workgroup builds an 8 x 512 output tile (pairwise squared distances by direct differences, so r2 >= 0 and
+// K(X,X) is exactly symmetric) and writes it as 4 KB row segments of 16-byte non-temporal stores.  Algorithmic bytes = 8 * n * n2 (output) + 8 * D * (n + n2) (inputs).
 #include "common.hpp"
 
-#define GR_TI 16
-#define GR_TJ 256
-#define GR_DC 16
+#define GR_TI 8      // rows (X / inducing side) per workgroup
+#define GR_TJ 512    // columns (X2 / data side) per workgroup: two per thread -> 16-byte stores, 4 KB runs per output row
+#define GR_DC 8      // input dimensions per pass
 
+#define GR_LD (GR_TJ + 8)   // LDS row stride of the transposed X2 tile (doubles)
+
+// Each thread owns two adjacent columns and all GR_TI rows of the tile.  Per pass of GR_DC input dimensions the workgroup's
+// 512 X2 rows are read COALESCED (8 threads = one 64-byte row chunk: 4-8 cache lines per wave-instruction; one thread reading
+// its own rows with 8-byte loads touches 64 lines per instruction and the kernel turns texture-address-bound, measured 3x
+// slower), scaled by 1/lengthscale and parked TRANSPOSED in LDS ([dim][row]: a thread's two columns are one 16-byte read);
+// the GR_TI scaled X rows are LDS broadcasts; distances accumulate in registers and the 16 kernel values leave as 8 double2
+// non-temporal stores (1 KB per wave-instruction, 4 KB runs per output row).
 template <int KIND>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int64_t n, const double* __restrict__ X2,
                                               int64_t n2, int D, const double* __restrict__ hyp, double diag_add,
                                               int symmetric, double* __restrict__ out, int64_t ld) {
-  __shared__ double xi[GR_TI * GR_DC];
-  __shared__ double xj[GR_TJ * (GR_DC + 1)];
+  __shared__ __attribute__((aligned(16))) double xi[GR_TI * GR_DC];
+  __shared__ __attribute__((aligned(16))) double xj[GR_DC * GR_LD];
+  typedef double d2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * GR_TJ, i0 = (int64_t)blockIdx.y * GR_TI;
+  const int64_t jbase = (int64_t)blockIdx.x * GR_TJ, j0 = jbase + 2 * tid, i0 = (int64_t)blockIdx.y * GR_TI;
   const double s2 = hyp[HYP_VAR];
   const double* ils = hyp + HYP_ILS;
-  double r2[GR_TI];
+  double ra[GR_TI], rb[GR_TI];
 #pragma unroll
-  for (int ii = 0; ii < GR_TI; ++ii) r2[ii] = 0.0;
+  for (int ii = 0; ii < GR_TI; ++ii) ra[ii] = rb[ii] = 0.0;
+  const int sdd = tid % GR_DC, srow = tid / GR_DC;      // staging role: dimension sdd of rows srow + 32 q
   for (int d0 = 0; d0 < D; d0 += GR_DC) {
-    {
-      const int ii = tid / GR_DC, dd = tid % GR_DC;
-      double v = 0.0;
-      if (i0 + ii < n && d0 + dd < D) v = X[(i0 + ii) * D + d0 + dd] * ils[d0 + dd];
-      xi[tid] = v;
-    }
+    const int dc = (D - d0 < GR_DC) ? D - d0 : GR_DC;
+    if (d0 > 0) __syncthreads();
+    const int dq = d0 + (sdd < dc ? sdd : dc - 1);                       // clamped: every load is unconditional
+    const double sc = sdd < dc ? ils[dq] : 0.0;
+    double st[GR_TJ / 32];
 #pragma unroll
-    for (int q = 0; q < GR_DC; ++q) {
-      const int idx = tid + 256 * q;
-      const int row = idx / GR_DC, dd = idx % GR_DC;
-      double v = 0.0;
-      if (j0 + row < n2 && d0 + dd < D) v = X2[(j0 + row) * D + d0 + dd] * ils[d0 + dd];
-      xj[row * (GR_DC + 1) + dd] = v;
+    for (int q = 0; q < GR_TJ / 32; ++q) {
+      int64_t row = jbase + srow + 32 * q;
+      if (row > n2 - 1) row = n2 - 1;
+      st[q] = X2[row * D + dq];
     }
+    if (tid < GR_TI * GR_DC) {
+      const int ii = tid / GR_DC;
+      const int64_t row = (i0 + ii < n) ? i0 + ii : n - 1;
+      xi[tid] = X[row * D + dq] * sc;
+    }
+    // products are rounded by the LDS store on BOTH sides (no fused z - x * il): (i, j) and (j, i) see the same bits and
+    // K(X, X) is exactly symmetric
+#pragma unroll
+    for (int q = 0; q < GR_TJ / 32; ++q) xj[sdd * GR_LD + srow + 32 * q] = st[q] * sc;
     __syncthreads();
 #pragma unroll
     for (int dd = 0; dd < GR_DC; ++dd) {
-      const double v = xj[tid * (GR_DC + 1) + dd];
+      const d2 xx = *reinterpret_cast<const d2*>(&xj[dd * GR_LD + 2 * tid]);
 #pragma unroll
       for (int ii = 0; ii < GR_TI; ++ii) {
-        const double df = xi[ii * GR_DC + dd] - v;
-        r2[ii] = fma(df, df, r2[ii]);
+        const double z = xi[ii * GR_DC + dd];
+        const double da = z - xx[0], db = z - xx[1];
+        ra[ii] = fma(da, da, ra[ii]);
+        rb[ii] = fma(db, db, rb[ii]);
       }
     }
-    __syncthreads();
   }
-  const int64_t j = j0 + tid;
-  if (j < n2) {
+  if (j0 >= n2) return;
+  const bool pair = (j0 + 1 < n2) && ((ld & 1) == 0);       // 16-byte aligned pair store
 #pragma unroll
-    for (int ii = 0; ii < GR_TI; ++ii) {
-      const int64_t i = i0 + ii;
-      if (i < n) {
-        double k = kern_val<KIND>(r2[ii], s2);
-        if (symmetric && i == j) k += diag_add;
-        out[i * ld + j] = k;
+  for (int ii = 0; ii < GR_TI; ++ii) {          // values first (straight-line: the exps of all rows interleave) ...
+    const int64_t i = i0 + ii;
+    ra[ii] = kern_val<KIND>(ra[ii], s2) + ((symmetric && i == j0) ? diag_add : 0.0);
+    rb[ii] = kern_val<KIND>(rb[ii], s2) + ((symmetric && i == j0 + 1) ? diag_add : 0.0);
+  }
+#pragma unroll
+  for (int ii = 0; ii < GR_TI; ++ii) {          // ... then the stores
+    const int64_t i = i0 + ii;
+    if (i < n) {
+      double* o = out + i * ld + j0;
+      if (pair) {
+        __builtin_nontemporal_store((d2){ra[ii], rb[ii]}, reinterpret_cast<d2*>(o));
+      } else {
+        o[0] = ra[ii];
+        if (j0 + 1 < n2) o[1] = rb[ii];
       }
     }
   }

@@ -12,6 +12,7 @@ KERN_RBF, KERN_MATERN52 = 0, 1
 MEAN_ZERO, MEAN_IDENTITY, MEAN_LINEAR = 0, 1, 2
 LIK_GAUSSIAN, LIK_MULTICLASS = 0, 1
 ERR_NOT_SPD = -2
+ERR_RCCL = -6
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -99,6 +100,7 @@ _PROTOS = {
     "dsdgp_multiclass_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int, C.c_void_p, C.c_void_p]),
     "dsdgp_multiclass_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dsdgp_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

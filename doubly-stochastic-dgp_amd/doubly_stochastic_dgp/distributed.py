@@ -22,6 +22,13 @@ def allreduce_flat(buf, world):
     if world == 1:
         return buf
     import torch.distributed as dist
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        # test rig (two processes sharing one GPU, no RCCL peer): stage through the host; production runs use backend
+        # "nccl" (= RCCL) and reduce the device buffer in place on the shared stream
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
+        return buf
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 

@@ -35,7 +35,8 @@ typedef enum {
   DSDGP_ERR_NOT_SPD = -2,      /* tf.cholesky failure, layers.py:172 */
   DSDGP_ERR_HIP = -3,
   DSDGP_ERR_UNSUPPORTED = -4,
-  DSDGP_ERR_WORKSPACE = -5
+  DSDGP_ERR_WORKSPACE = -5,
+  DSDGP_ERR_RCCL = -6          /* dsdgp_allreduce: RCCL missing or a collective failed */
 } dsdgp_status;
 
 enum { DSDGP_KERN_RBF = 0, DSDGP_KERN_MATERN52 = 1 };            /* [UPSTREAM] gpflow.kernels */
@@ -193,6 +194,17 @@ int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, 
 
 /* N(0,1) float64 draws (Philox4x32-10 + Box–Muller), replaces tf.random_normal (layers.py:101-102). */
 int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out);
+
+/* Multi-GPU exchange step of the row-sharded ELBO (the step being sharded is dgp.py:92-98): in-place SUM of
+ * `count` doubles of `buf` over the ranks of `comm` on the ctx stream — ONE call per training step on the flat
+ * [gradient (n_theta) | elbo, data term, kl_weight * KL, potrf_info] buffer (`grad` of dsdgp_model_create with `out` of
+ * dsdgp_model_elbo pointing at grad + n_theta), between dsdgp_model_elbo(with_grad = 1, kl_weight = 1 / world,
+ * data_scale = num_data / (n_local * world)) and dsdgp_model_adam_step.
+ * comm: an RCCL communicator (ncclComm_t, one rank per GPU / process) created by the CALLER with RCCL's own
+ * ncclGetUniqueId / ncclCommInitRank; the library resolves ncclAllReduce from the RCCL already loaded in the process (or
+ * librccl.so) at first use, so libdsdgp.so itself carries no link-time dependency on RCCL.  Asynchronous.
+ * Returns DSDGP_ERR_RCCL when RCCL is unavailable or reports an error (see dsdgp_last_error). */
+int dsdgp_allreduce(dsdgp_ctx* ctx, void* comm, double* buf, int64_t count);
 
 /* Minibatch gather ([UPSTREAM] gpflow.params.Minibatch, dgp.py:51-52): dst[i,:] = src[idx[idx_offset+i],:], cols wide.
  * idx: device int64.  Index generation stays on the host (own RNG; TF's shuffle order is not reproducible). */

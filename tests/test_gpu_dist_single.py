@@ -48,3 +48,41 @@ def test_attach_allreduce_single_rank_nccl():
         assert float(t.sum().item()) == 4.0
     finally:
         dist.destroy_process_group()
+
+
+def test_cabi_allreduce_single_rank_rccl():
+    """dsdgp_allreduce (include/dsdgp.h) on a 1-rank RCCL communicator created through RCCL's own C API — what a non-torch
+    host does: ncclGetUniqueId -> ncclCommInitRank -> dsdgp_allreduce on the ctx stream.  Sum over one rank = identity."""
+    import ctypes as C
+    import torch
+    from doubly_stochastic_dgp import _lib
+    from doubly_stochastic_dgp.engine import Context
+    ctx = Context.get()
+    rccl = None
+    for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "no librccl.so on this box"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
+        t = ctx.to_device(x)
+        ctx.torch.cuda.current_stream().synchronize()
+        _lib.check(ctx.lib.dsdgp_allreduce(ctx.handle, comm, C.c_void_p(t.data_ptr()), t.numel()))
+        ctx.sync()
+        assert np.array_equal(t.cpu().numpy(), x)
+        rc = ctx.lib.dsdgp_allreduce(ctx.handle, None, C.c_void_p(t.data_ptr()), t.numel())
+        assert rc == -1                                   # DSDGP_ERR_BAD_ARG: no communicator
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -280,3 +280,21 @@ def test_csave_chain_and_alg_g_gradients(monkeypatch, white, M, D):
     g = model.engine().gradient_dict()
     for k in gref:
         assert np.max(np.abs(-gref[k] - g[k])) <= 1e-7 * (np.max(np.abs(gref[k])) + 1e-12), k
+
+
+@pytest.mark.parametrize("n,n2,D", [(130, 2050, 30), (8, 512, 1), (257, 1026, 9)])
+def test_gram_paired_store_path(ctx, n, n2, D):
+    """dsdgp_gram with an even leading dimension takes the 16-byte paired-store path; several passes over D (D > 8)."""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n)
+    X, X2 = rng.randn(n, D), rng.randn(n2, D)
+    ls = 0.5 + rng.rand(D)
+    k = O.Kern("matern52", D, variance=1.3, lengthscales=ls, ARD=True)
+    spec = _lib.KernelSpec(kind=1, input_dim=D, ard=1, has_white=0, variance=1.3, white_variance=0.0,
+                           lengthscales=ls.ctypes.data_as(_lib.c_double_p))
+    dX, dX2 = _dev(ctx, X), _dev(ctx, X2)
+    out = ctx.empty(n, n2)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, _p(dX2), n2, 0.0, _p(out), n2))
+    ctx.sync()
+    assert_allclose(out.cpu().numpy(), k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
