@@ -103,6 +103,12 @@ static inline int pad_M(int M) {
 // ------------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 typedef double d4 __attribute__((ext_vector_type(4)));
+// Pointers that reach a kernel through a descriptor in MEMORY (job lists, GemmProblem, PotrfItem, LayerDev) have no known
+// address space: the compiler emits flat_load / flat_store, which count on lgkmcnt as well as vmcnt — every LDS wait then also
+// waits for outstanding global traffic.  Hot loops cast such pointers to the global (1) or LDS (3) address space.
+typedef const double __attribute__((address_space(1)))* gcptr;
+typedef double __attribute__((address_space(1)))* gptr;
+typedef double __attribute__((address_space(3)))* lptr;
 
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), wave64.
 //   lane l: g = l>>4, c = l&15.   A operand = A[i=c][k=g];  B operand = B[k=g][j=c];

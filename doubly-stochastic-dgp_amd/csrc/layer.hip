@@ -490,19 +490,18 @@ int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kin
 // DIAG: diagonal tile of a symmetric result (P == Q): only the 16x16 blocks on or below the block diagonal are formed
 // (10 of 16 MFMAs per k-step at NI = NJ = 4); the reduction mirrors at 16-block granularity.
 template <int NI, int NJ, bool GUARD, bool DIAG>
-__device__ __forceinline__ void wgrad_loop(const double* __restrict__ Pp, const double* __restrict__ Qp,
-                                           const double* __restrict__ scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
+__device__ __forceinline__ void wgrad_loop(gcptr Pp, gcptr Qp, gcptr scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
                                            int njv, d4 (&acc)[NI][NJ]) {
   for (int64_t ch = c_lo; ch < c_hi; ++ch) {
     const int64_t rb = ch * 16;
     d4 pa[NI], qb[NJ];
 #pragma unroll
-    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4*>(Pp + (int64_t)16 * ii * ld + rb);
+    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Pp + (int64_t)16 * ii * ld + rb);
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
-      if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4*>(Qp + (int64_t)16 * jj * ld + rb);
+      if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Qp + (int64_t)16 * jj * ld + rb);
     if (scale) {
-      const d4 sc = *reinterpret_cast<const d4*>(scale + rb + 4 * g);
+      const d4 sc = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(scale + rb + 4 * g);
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj)
         if (!GUARD || jj < njv) qb[jj] *= sc;
@@ -559,17 +558,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradJob* __restrict__ jobs
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
-  const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
-  const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
+  gcptr Pp = (gcptr)(J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g);      // job descriptors live in memory: see gcptr
+  gcptr Qp = (gcptr)(J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g);
   const bool diag = J.sym && tile_i == tile_j && NI == NJ;
   if (diag)
-    wgrad_loop<NI, NJ, false, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, false, true>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   else if (njv == NJ)
-    wgrad_loop<NI, NJ, false, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, false, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   else
-    wgrad_loop<NI, NJ, true, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, true, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   const int rowsP = 16 * NI * J.ti;
-  double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
+  gptr o = (gptr)(J.out + (int64_t)split * rowsP * J.ldo);
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
@@ -627,15 +626,15 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
-  const double* __restrict__ Pp = J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g;
-  const double* __restrict__ Qp = J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g;
+  gcptr Pp = (gcptr)(J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g);      // job descriptors live in memory: see gcptr
+  gcptr Qp = (gcptr)(J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g);
   const bool diag = J.sym && tile_i == tile_j && NI == NJ;
   if (diag)
-    wgrad_loop<NI, NJ, false, true>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, false, true>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   else if (njv == NJ)
-    wgrad_loop<NI, NJ, false, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, false, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   else
-    wgrad_loop<NI, NJ, true, false>(Pp, Qp, J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop<NI, NJ, true, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   // fixed-order tree over the four waves: slot s of a wave's accumulator lives at red[region][s][lane]
   constexpr int NS = NI * NJ * 4;
   if (wave >= 2) {
@@ -671,7 +670,7 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
   if (wave != 0) return;
   const double* r = red + lane;
   const int rowsP = 16 * NI * J.ti;
-  double* __restrict__ o = J.out + (int64_t)split * rowsP * J.ldo;
+  gptr o = (gptr)(J.out + (int64_t)split * rowsP * J.ldo);
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii)
 #pragma unroll

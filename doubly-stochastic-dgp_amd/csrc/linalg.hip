@@ -3,6 +3,8 @@
 //   k_potrf_trtri   : blocked right-looking Cholesky (tf.cholesky, layers.py:172) with MFMA trailing update, followed by
 //                     the blocked triangular inverse that turns the two tf.matrix_triangular_solve calls of
 //                     layers.py:186,188 into MFMA products inside the layer chain kernel.
+#include <stdlib.h>
+
 #include "linalg.hpp"
 
 #define GT 64
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
   double ra[4], rb[4];
   auto gload = [&](int step) {
     const int b = b0 + step / ksteps, k0 = (ks_lo + step % ksteps) * GK;
-    const double* A = P.A + (int64_t)b * P.sA;
-    const double* B = P.B + (int64_t)b * P.sB;
+    gcptr A = (gcptr)(P.A + (int64_t)b * P.sA);
+    gcptr B = (gcptr)(P.B + (int64_t)b * P.sB);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int mm, kk;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
     }
     __syncthreads();
   }
-  double* C = P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC);
+  gptr C = (gptr)(P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC));
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -115,23 +117,184 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
       }
 }
 
-int gemm_plan(GemmProblem* host, int nprob) {
+// ------------------------------------------------------------------------------------------------------
+// Large-tile variant for the M >= 512 algebra (Ku^-1, Lu^-1 q_sqrt, U_d, U_d U_d^T, P_d T_d, natural-gradient products: up to
+// 2 M^3 flops each, D_out of them per layer): 128 x 128 output tile per workgroup, each of the 4 waves a 64 x 64 quadrant
+// (16 accumulators), K in steps of 16 through a DOUBLE-BUFFERED LDS pair (the global loads of step t+1 are issued before the
+// 64 MFMAs of step t, one barrier per step), 8 LDS operand reads per 16 MFMAs.  Same problem descriptor, structure hints and
+// epilogue as k_gemm_grouped (which keeps the small / thin problems: it wastes less on partial tiles).
+// ------------------------------------------------------------------------------------------------------
+#define BT 128
+#define BK 16
+#define BLD 144   // LDS row stride (doubles): 128 + 16 pad -> the g and g+1 k-rows of a fragment read sit 32 banks apart (conflict-free)
+
+__global__ __launch_bounds__(256) void k_gemm_big(const GemmProblem* __restrict__ probs, int nprob) {
+  __shared__ __attribute__((aligned(16))) double As[2][BK * BLD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * BLD];
+  const int bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  const GemmProblem P = probs[p];
+  int t = bid - P.tile_start;
+  const int tiles = P.tiles_m * P.tiles_n;
+  int b0, b1;
+  if (P.batch_reduce) {
+    b0 = 0;
+    b1 = P.batch;
+  } else {
+    b0 = t / tiles;
+    b1 = b0 + 1;
+    t = t % tiles;
+  }
+  const int m0 = (t / P.tiles_n) * BT, n0 = (t % P.tiles_n) * BT;
+  if (P.lower_only && n0 > m0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+  int kmin = 0, kmax = P.k;
+  if (P.tri & 1) kmin = max(kmin, n0);
+  if (P.tri & 2) kmax = min(kmax, m0 + BT);
+  if (P.tri & 4) kmax = min(kmax, n0 + BT);
+  if (P.tri & 8) kmin = max(kmin, m0);
+  const int ks_lo = kmin / BK;
+  const int ksteps = max(0, (kmax + BK - 1) / BK - ks_lo);
+  const int nsteps = (b1 - b0) * ksteps;
+  // staging roles.  "row-contiguous" operand (A not transposed / B transposed: element [x][k], k contiguous): thread takes
+  // row x = tid / 2, k = 8 (tid & 1) .. + 7.  "k-major" operand (A transposed / B not transposed: [k][x]): k = tid / 16,
+  // x = 8 (tid & 15) .. + 7.  Either way 64 contiguous bytes per thread.
+  double ra[8], rb[8];
+  auto gload = [&](int step) {
+    const int b = b0 + step / ksteps, k0 = (ks_lo + step % ksteps) * BK;
+    gcptr A = (gcptr)(P.A + (int64_t)b * P.sA);
+    gcptr B = (gcptr)(P.B + (int64_t)b * P.sB);
+    // interior chunks load UNCONDITIONALLY (eight loads in flight); a per-element guard puts every load in its own basic block
+    // and serialises eight memory round trips per operand (measured: 10x slower than the 64 x 64 kernel)
+    auto load8 = [&](gcptr src, bool row_ok, int first, int limit, double (&r)[8]) {
+      if (row_ok && first + 8 <= limit) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = src[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = (row_ok && first + u < limit) ? src[u] : 0.0;
+      }
+    };
+    if (!P.transA) {
+      const int mm = m0 + (tid >> 1), kk = k0 + 8 * (tid & 1);
+      load8(A + (int64_t)mm * P.lda + kk, mm < P.m, kk, P.k, ra);
+    } else {
+      const int kk = k0 + (tid >> 4), mm = m0 + 8 * (tid & 15);
+      load8(A + (int64_t)kk * P.lda + mm, kk < P.k, mm, P.m, ra);
+    }
+    if (P.transB) {
+      const int nn = n0 + (tid >> 1), kk = k0 + 8 * (tid & 1);
+      load8(B + (int64_t)nn * P.ldb + kk, nn < P.n, kk, P.k, rb);
+    } else {
+      const int kk = k0 + (tid >> 4), nn = n0 + 8 * (tid & 15);
+      load8(B + (int64_t)kk * P.ldb + nn, kk < P.k, nn, P.n, rb);
+    }
+  };
+  auto lstore = [&](int buf) {
+    if (!P.transA) {
+      const int mm = tid >> 1, kk = 8 * (tid & 1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) As[buf][(kk + u) * BLD + mm] = ra[u];
+    } else {
+      const int kk = tid >> 4, mm = 8 * (tid & 15);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) As[buf][kk * BLD + mm + u] = ra[u];
+    }
+    if (P.transB) {
+      const int nn = tid >> 1, kk = 8 * (tid & 1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) Bs[buf][(kk + u) * BLD + nn] = rb[u];
+    } else {
+      const int kk = tid >> 4, nn = 8 * (tid & 15);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) Bs[buf][kk * BLD + nn + u] = rb[u];
+    }
+  };
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+    for (int k4 = 0; k4 < BK; k4 += 4) {
+      double a[4], bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[buf][(k4 + g) * BLD + wr * 64 + 16 * i + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = Bs[buf][(k4 + g) * BLD + wc * 64 + 16 * j + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(a[i], bq[j], acc[i][j]);
+    }
+    if (step + 1 < nsteps) lstore(buf ^ 1);     // the other buffer: its last readers finished before the previous barrier
+    __syncthreads();
+  }
+  gptr C = (gptr)(P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC));
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + ib * 16 + g + 4 * r;
+        const int col = n0 + wc * 64 + jb * 16 + c;
+        if (row < P.m && col < P.n) {
+          double v = P.alpha * acc[ib][jb][r];
+          if (P.beta != 0.0) v += P.beta * C[(int64_t)row * P.ldc + col];
+          C[(int64_t)row * P.ldc + col] = v;
+          if ((P.tri & 16) && n0 < m0) C[(int64_t)col * P.ldc + row] = v;     // mirror of a symmetric result
+        }
+      }
+}
+
+// Launches whose largest problem is at least GEMM_BIG_MIN in both output dimensions take the 128 x 128 kernel; the planned
+// tile count carries the choice in GEMM_BIG_FLAG so that every call site keeps passing plan -> launch unchanged.
+#define GEMM_BIG_FLAG (1 << 30)
+#define GEMM_BIG_MIN 512
+static int gemm_big_enabled() {
+  static const int on = getenv("DSDGP_GEMM_BIG") ? atoi(getenv("DSDGP_GEMM_BIG")) : 1;
+  return on;
+}
+
+int gemm_plan(GemmProblem* host, int nprob, bool allow_big) {
+  int big = 0;
+  if (allow_big && gemm_big_enabled())
+    for (int i = 0; i < nprob; ++i)
+      if (host[i].m >= GEMM_BIG_MIN && host[i].n >= GEMM_BIG_MIN && host[i].k >= 64) big = 1;
+  const int T = big ? BT : GT;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     GemmProblem& P = host[i];
-    P.tiles_m = ceil_div(P.m, GT);
-    P.tiles_n = ceil_div(P.n, GT);
+    P.tiles_m = ceil_div(P.m, T);
+    P.tiles_n = ceil_div(P.n, T);
     P.tile_start = total;
     total += P.tiles_m * P.tiles_n * (P.batch_reduce ? 1 : P.batch);
   }
-  return total;
+  return big ? (total | GEMM_BIG_FLAG) : total;
 }
 
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream) {
+  const bool big = (total_tiles & GEMM_BIG_FLAG) != 0;
+  total_tiles &= ~GEMM_BIG_FLAG;
   if (total_tiles <= 0) return DSDGP_OK;
   hipStream_t st = stream ? stream : ctx->stream;
   ProfScope ps(ctx, "gemm", st);
-  hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+  if (big)
+    hipLaunchKernelGGL(k_gemm_big, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+  else
+    hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -183,6 +346,8 @@ struct Chol16<16> {
 // them in registers (the D layout of one 16x16 product is the B operand of the next), so there is no inter-wave
 // dependency and no barrier:  X_jj = Ljj^-1,  X_ij = -Lii^-1 * sum_{k=j}^{i-1} L_ik X_kj.
 #define POTRF_MAXNB 16
+template <bool INLDS> struct WPtr { typedef gptr type; };
+template <> struct WPtr<true> { typedef lptr type; };
 template <bool INLDS>
 __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict__ items, int nb_max) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -193,8 +358,10 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
   const PotrfItem it = items[blockIdx.x];
   const int n = it.n, nb = n / 16;
   const int ld = INLDS ? n + 4 : it.ld;
-  double* __restrict__ W = INLDS ? Xdall + nb_max * 16 * 17 : it.W;
-  double* __restrict__ Linv = it.Linv;
+  typename WPtr<INLDS>::type W;            // LDS-resident or global working matrix, never a generic (flat) pointer
+  if constexpr (INLDS) W = (lptr)(Xdall + nb_max * 16 * 17); else W = (gptr)it.W;
+  gptr Linv = (gptr)it.Linv;
+  gptr LinvT = (gptr)it.LinvT;
   const int ldi = it.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -219,7 +386,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
       for (int u = 0; u < 8; ++u) {
         const int idx = base + u * 256 + tid;
         const int i = idx / halfn, j2 = idx % halfn;
-        if (idx < tot && 2 * j2 <= (i | 15)) *reinterpret_cast<d2v*>(W + i * ld + 2 * j2) = v[u];
+        if (idx < tot && 2 * j2 <= (i | 15)) { W[i * ld + 2 * j2] = v[u][0]; W[i * ld + 2 * j2 + 1] = v[u][1]; }
       }
     }
   }
@@ -315,10 +482,47 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
         __builtin_amdgcn_wave_barrier();
         factor_diag(jb + 1);
       } else {
-        for (int id = wave; id < cnt; id += 3) {
-          int ib2 = 0;
+        // two tiles per iteration: their LDS loads, 4-MFMA chains and stores interleave (a lone tile is a ~2000-cycle
+        // load -> dependent MFMAs -> store chain; the trailing update was 55 % of the factorisation)
+        auto tile_of = [&](int id, int& ib2, int& kb2) {
+          ib2 = 0;
           while ((ib2 + 1) * (ib2 + 2) / 2 <= id) ++ib2;
-          const int kb2 = id - ib2 * (ib2 + 1) / 2;
+          kb2 = id - ib2 * (ib2 + 1) / 2;
+        };
+        int id = wave;
+        for (; id + 3 < cnt; id += 6) {
+          int ia, ka, ib_, kb_;
+          tile_of(id, ia, ka);
+          tile_of(id + 3, ib_, kb_);
+          const int ra0 = (jb + 1 + ia) * 16, ca0 = (jb + 1 + ka) * 16, rb0 = (jb + 1 + ib_) * 16, cb0 = (jb + 1 + kb_) * 16;
+          d4 accA, accB;
+          double a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            accA[r] = W[(int64_t)(ra0 + g + 4 * r) * ld + ca0 + c];
+            accB[r] = W[(int64_t)(rb0 + g + 4 * r) * ld + cb0 + c];
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            a1[s4] = W[(int64_t)(ra0 + c) * ld + j0 + 4 * s4 + g];
+            b1[s4] = W[(int64_t)(ca0 + c) * ld + j0 + 4 * s4 + g];
+            a2[s4] = W[(int64_t)(rb0 + c) * ld + j0 + 4 * s4 + g];
+            b2[s4] = W[(int64_t)(cb0 + c) * ld + j0 + 4 * s4 + g];
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            accA = mfma_f64(-a1[s4], b1[s4], accA);
+            accB = mfma_f64(-a2[s4], b2[s4], accB);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            W[(int64_t)(ra0 + g + 4 * r) * ld + ca0 + c] = accA[r];
+            W[(int64_t)(rb0 + g + 4 * r) * ld + cb0 + c] = accB[r];
+          }
+        }
+        for (; id < cnt; id += 3) {
+          int ib2, kb2;
+          tile_of(id, ib2, kb2);
           trail_tile(jb + 1 + ib2, jb + 1 + kb2, j0);
         }
       }
@@ -362,7 +566,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
         const int i = idx >> 4, j = idx & 15;
         const double v = Xi[i * 17 + j];
         Linv[(int64_t)(jb * 16 + i) * ldi + jb * 16 + j] = v;
-        if (it.LinvT) it.LinvT[(int64_t)(jb * 16 + j) * ldi + jb * 16 + i] = v;
+        if (LinvT) LinvT[(int64_t)(jb * 16 + j) * ldi + jb * 16 + i] = v;
       }
     }
     __syncthreads();
@@ -384,7 +588,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           Linv[(int64_t)(ib * 16 + g + 4 * t) * ldi + jb2 * 16 + c] = R[t];
-          if (it.LinvT) it.LinvT[(int64_t)(jb2 * 16 + c) * ldi + ib * 16 + g + 4 * t] = R[t];
+          if (LinvT) LinvT[(int64_t)(jb2 * 16 + c) * ldi + ib * 16 + g + 4 * t] = R[t];
         }
       }
       __syncthreads();
@@ -426,7 +630,7 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(const PotrfItem* __restrict
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           Linv[(int64_t)(ib * 16 + g + 4 * t) * ldi + jcol * 16 + c] = x[rel][t];
-          if (it.LinvT) it.LinvT[(int64_t)(jcol * 16 + c) * ldi + ib * 16 + g + 4 * t] = x[rel][t];
+          if (LinvT) LinvT[(int64_t)(jcol * 16 + c) * ldi + ib * 16 + g + 4 * t] = x[rel][t];
         }
       }
     }
@@ -734,10 +938,18 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     }
   std::vector<GemmProblem> gp;
   P.tiles.clear();
+  P.nprob.clear();
+  P.first.clear();
+  // one launch = a list of problems planned together (tile_start relative to the launch)
+  auto add_launch = [&](std::vector<GemmProblem>& list, bool allow_big) {
+    P.tiles.push_back(gemm_plan(list.data(), (int)list.size(), allow_big));
+    P.nprob.push_back((int)list.size());
+    P.first.push_back((int)gp.size());
+    for (auto& g : list) gp.push_back(g);
+  };
   auto add = [&](GemmProblem& g) {
-    P.tiles.push_back(gemm_plan(&g, 1));
-    g.tile_start = 0;
-    gp.push_back(g);
+    std::vector<GemmProblem> one{g};
+    add_launch(one, false);    // the blocked factorisation's K = 64 panels stay on the 64 x 64 kernel
   };
   auto mk = [&](const double* A, const double* B, double* C, int m, int nn, int k, int tA, int tB, double alpha, double beta, int lower) {
     GemmProblem g;
@@ -762,14 +974,34 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     }
   }
   if (P.want_inverse) {
-    for (int i = 1; i < nb; ++i) {
-      // T = L[i, 0:i] * X[0:i, 0:i]  ;  X[i, 0:i] = -X_ii * T
-      GemmProblem g1 = mk(W + (int64_t)i * 64 * n, Linv, Tbuf, 64, i * 64, i * 64, 0, 0, 1.0, 0.0, 0);
-      g1.ldc = n; g1.sC = (int64_t)64 * n;
-      add(g1);
-      GemmProblem g2 = mk(Linv + (int64_t)i * 64 * n + i * 64, Tbuf, Linv + (int64_t)i * 64 * n, 64, i * 64, 64, 0, 0, -1.0, 0.0, 0);
-      g2.ldb = n; g2.sB = (int64_t)64 * n;
-      add(g2);
+    // X = L^-1 by RECURSIVE DOUBLING over the 64 x 64 diagonal inverses the factor kernel left on Linv's diagonal: at block
+    // size s every pair of adjacent diagonal blocks [X11 0; X21 X22] gets X21 = -X22 (L21 X11), all n / 2s pairs (and all
+    // matrices of the batch) in ONE grouped launch per product: 2 log2(n / 64) launches (8 at n = 1024) instead of the
+    // 2 (n / 64 - 1) of the block-row recurrence, and the upper levels are big enough for the 128 x 128 kernel.
+    // T = L21 X11 is parked in the mirror position of the X21 block inside the scratch matrix S (LinvT when the caller wants
+    // it — the final transpose overwrites it — else a plan-owned n x n).
+    double* S = LinvT;
+    if (!S) {
+      DS_HIP(hipMalloc(&P.inv_block, (size_t)batch * n * n * sizeof(double)));
+      S = (double*)P.inv_block;
+    }
+    const int64_t sS = LinvT ? stride : (int64_t)n * n;
+    for (int sblk = 64; sblk < n; sblk *= 2) {
+      std::vector<GemmProblem> l1, l2;
+      for (int r0 = sblk; r0 < n; r0 += 2 * sblk) {
+        const int c0 = r0 - sblk;
+        const int rows = (n - r0 < sblk) ? n - r0 : sblk;      // ragged last pair (n / 64 not a power of two)
+        GemmProblem g1 = mk(W + (int64_t)r0 * n + c0, Linv + (int64_t)c0 * n + c0, S + (int64_t)r0 * n + c0, rows, sblk, sblk, 0, 0,
+                            1.0, 0.0, 0);
+        g1.sC = sS; g1.tri = 1;                                 // X11 lower-triangular: k >= n
+        l1.push_back(g1);
+        GemmProblem g2 = mk(Linv + (int64_t)r0 * n + r0, S + (int64_t)r0 * n + c0, Linv + (int64_t)r0 * n + c0, rows, sblk, rows, 0, 0,
+                            -1.0, 0.0, 0);
+        g2.sB = sS; g2.tri = 2;                                 // X22 lower-triangular: k <= m
+        l2.push_back(g2);
+      }
+      add_launch(l1, true);
+      add_launch(l2, true);
     }
   }
   const size_t ib = round_up(items.size() * sizeof(PotrfItem), 256), gb = round_up(gp.size() * sizeof(GemmProblem) + 256, 256);
@@ -782,6 +1014,8 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
 }
 
 void bigchol_free(BigChol& P) {
+  if (P.inv_block) hipFree(P.inv_block);
+  P.inv_block = nullptr;
   if (P.dev_block) hipFree(P.dev_block);
   if (P.tbuf_block) hipFree(P.tbuf_block);
   P.dev_block = nullptr;
@@ -792,6 +1026,14 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
   ProfScope ps(ctx, "potrf");
   const int nb = P.nb, batch = P.batch;
   int gi = 0;
+  auto launch = [&](int i) {
+    const bool big = (P.tiles[i] & (1 << 30)) != 0;
+    const int tiles = P.tiles[i] & ~(1 << 30);
+    if (big)
+      hipLaunchKernelGGL(k_gemm_big, dim3(tiles), dim3(256), 0, ctx->stream, P.gp + P.first[i], P.nprob[i]);
+    else
+      hipLaunchKernelGGL(k_gemm_grouped, dim3(tiles), dim3(256), 0, ctx->stream, P.gp + P.first[i], P.nprob[i]);
+  };
   if (!P.from_tri) {
     if (P.scal)
       for (int b = 0; b < batch; ++b) DS_HIP(hipMemsetAsync(P.scal + b * P.scal_stride, 0, 2 * sizeof(double), ctx->stream));
@@ -799,10 +1041,8 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
     for (int p = 0; p < nb; ++p) {
       hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(batch), dim3(256), lds, ctx->stream, P.diag_items + (size_t)p * batch, 4);
       if (p + 1 < nb) {
-        hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
-        ++gi;
-        hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
-        ++gi;
+        launch(gi++);
+        launch(gi++);
       }
     }
     hipLaunchKernelGGL(k_zero_upper_blocks, dim3(256, batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride);
@@ -810,12 +1050,7 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
     hipLaunchKernelGGL(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
   }
   if (P.want_inverse) {
-    for (int i = 1; i < nb; ++i) {
-      hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
-      ++gi;
-      hipLaunchKernelGGL(k_gemm_grouped, dim3(P.tiles[gi]), dim3(256), 0, ctx->stream, P.gp + gi, 1);
-      ++gi;
-    }
+    while (gi < (int)P.tiles.size()) launch(gi++);
     if (P.LinvT)
       hipLaunchKernelGGL(k_transpose_lower, dim3(256, batch), dim3(256), 0, ctx->stream, P.Linv, P.LinvT, P.n, P.stride);
   }

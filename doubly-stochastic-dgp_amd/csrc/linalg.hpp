@@ -31,8 +31,9 @@ struct PotrfItem {
   int32_t info_offset, pad2;   // added to a failing pivot index (position of this block inside a larger matrix)
 };
 
-// Fills tile_start/tiles_* of `host` problems, returns the total number of 64x64 tiles.
-int gemm_plan(GemmProblem* host, int nprob);
+// Fills tile_start/tiles_* of `host` problems, returns the total number of tiles (64 x 64, or 128 x 128 with the large-tile
+// kernel flagged in bit 30 when the launch holds a problem of at least 512 x 512 and allow_big): pass it to gemm_launch as is.
+int gemm_plan(GemmProblem* host, int nprob, bool allow_big = true);
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream = nullptr);
 // n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant
@@ -51,7 +52,9 @@ struct BigChol {
   int64_t stride = 0, scal_stride = 0;
   PotrfItem* diag_items = nullptr;     // device: nb * batch
   GemmProblem* gp = nullptr;           // device: per panel {solve, trailing}, then per block row {T, X}
-  std::vector<int> tiles;              // tile counts, same order as gp
+  std::vector<int> tiles;              // per launch: planned tile count (bit 30: large-tile kernel)
+  std::vector<int> nprob, first;       // per launch: number of problems and index of the first one in gp
+  void* inv_block = nullptr;           // plan-owned scratch of the recursive-doubling inverse (when no LinvT is requested)
   void* dev_block = nullptr;
   void* tbuf_block = nullptr;         // plan-owned Tbuf (when the caller passed none)
 };

@@ -38,6 +38,7 @@ struct LayerDev {
   double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngSplus, *ngTheta1 /* D_out x Mp */, *ngScal /* 4 x D_out */;
 };
 #define NPART 32
+#define PREP_BLOCKS 64      // minimum; large models take more (dsdgp_model::prep_blocks: ~2048 elements of q_sqrt per thread block pass)
 #define WIDE_DIN 32   // layers with D_in above this take the GEMM form of the Ku-side Z / lengthscale adjoints
 
 struct RedJob {
@@ -107,7 +108,7 @@ struct dsdgp_model {
   const double* sample_w = nullptr;   // DGP_Quad quadrature weights (borrowed), NULL = Monte-Carlo mean
   int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
-  int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64;
+  int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64, prep_blocks = PREP_BLOCKS;
   bool uniform_big = false;     // all layers share M and Mp >= 256: ONE batched multi-workgroup Cholesky for all layers
   BigChol big_all;
   bool need_hyp_part = false;
@@ -308,10 +309,9 @@ __device__ __forceinline__ double softplus_d(double x) { return x > 0 ? x + log1
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // parameter transforms + padding (LowerTriangular / positive transforms of layers.py:150 and [UPSTREAM] kernels)
-#define PREP_BLOCKS 64
 __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, double* __restrict__ lik_const, int64_t off_lik,
-                          int lik_gauss, int bx) {
-  const int tid0 = bx * blockDim.x + threadIdx.x, nth = PREP_BLOCKS * blockDim.x;
+                          int lik_gauss, int bx, int nprep) {
+  const int tid0 = bx * blockDim.x + threadIdx.x, nth = nprep * blockDim.x;
   if (tid0 == 0) {
     const double rv = theta[v.off_kvar];
     const double var = softplus_d(rv) + SOFTPLUS_LOWER;
@@ -348,9 +348,9 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
   }
   for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
     const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
-    v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
-    if (v.need_tpt)
-      v.TpT[idx] = (j < M && i <= j) ? theta[v.off_q_sqrt + ((int64_t)d * M + j) * M + i] : 0.0;
+    const double t = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+    v.Tp[idx] = t;
+    if (v.need_tpt) v.TpT[((int64_t)d * Mp + j) * Mp + i] = t;   // same (coalesced) read; the strided side is the store
   }
   for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
     v.qmu[idx] = (idx / v.D_out < M) ? theta[v.off_q_mu + idx] : 0.0;
@@ -402,12 +402,13 @@ __device__ void kuu_body(const LayerDev& v, const double* __restrict__ theta, do
 
 // ONE launch for the parameter transforms / padding (first PREP_BLOCKS block columns) and Ku (the rest), grid (x, L)
 __global__ __launch_bounds__(256) void k_prep_kuu(const double* __restrict__ theta, const LayerDev* __restrict__ layers,
-                                                  double* __restrict__ lik_const, int64_t off_lik, int lik_gauss, double jitter) {
+                                                  double* __restrict__ lik_const, int64_t off_lik, int lik_gauss, double jitter,
+                                                  int nprep) {
   const LayerDev v = layers[blockIdx.y];
-  if (blockIdx.x < PREP_BLOCKS)
-    prep_body(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x);
+  if ((int)blockIdx.x < nprep)
+    prep_body(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x, nprep);
   else
-    kuu_body(v, theta, jitter, blockIdx.x - PREP_BLOCKS, gridDim.x - PREP_BLOCKS);
+    kuu_body(v, theta, jitter, blockIdx.x - nprep, gridDim.x - nprep);
 }
 
 __device__ double block_sum_256(double x, double* sh) {
@@ -433,7 +434,25 @@ __global__ __launch_bounds__(256) void k_kl_part(const LayerDev* __restrict__ la
     acc -= 0.5 * log(t * t);                                            // layers.py:235
   }
   if (!v.white) {
-    for (int64_t idx = t0; idx < (int64_t)v.D_out * Mp * Mp; idx += nth) acc = fma(0.5 * v.V[idx], v.V[idx], acc);   // :239
+    {   // 1/2 |V|_F^2: 16-byte loads, four independent partial sums (a lone dependent chain ran at ~80 GB/s at M = 1024)
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const d2* V2 = reinterpret_cast<const d2*>(v.V);
+      const int64_t n2 = (int64_t)v.D_out * Mp * Mp / 2;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int64_t idx = t0;
+      for (; idx + 3 * nth < n2; idx += 4 * nth) {
+        const d2 x0 = V2[idx], x1 = V2[idx + nth], x2 = V2[idx + 2 * nth], x3 = V2[idx + 3 * nth];
+        a0 = fma(x0[0], x0[0], fma(x0[1], x0[1], a0));
+        a1 = fma(x1[0], x1[0], fma(x1[1], x1[1], a1));
+        a2 = fma(x2[0], x2[0], fma(x2[1], x2[1], a2));
+        a3 = fma(x3[0], x3[0], fma(x3[1], x3[1], a3));
+      }
+      for (; idx < n2; idx += nth) {
+        const d2 x0 = V2[idx];
+        a0 = fma(x0[0], x0[0], fma(x0[1], x0[1], a0));
+      }
+      acc += 0.5 * ((a0 + a1) + (a2 + a3));                                                                           // :239
+    }
     for (int64_t idx = t0; idx < (int64_t)Mp * v.DP4; idx += nth) acc = fma(0.5 * v.nL[idx], v.nL[idx], acc);       // :240-241
   } else {
     for (int64_t idx = t0; idx < (int64_t)v.D_out * Mp * Mp; idx += nth) acc = fma(0.5 * v.Tp[idx], v.Tp[idx], acc);  // :243
@@ -1040,9 +1059,13 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     fill_gemm(P, v.Linv, v.qmu4, v.nL, Mp, v.DP4, Mp, Mp, v.DP4, v.DP4, 0, 0, 1, 0, 0, 0, 0);        // Lu^-1 q_mu
     P.tri = 2;
     gf.push_back(P);
-    fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
-    P.lower_only = 1; P.tri = 2 | 4 | 16;                                                              //   lower x lower^T, symmetric
-    gf.push_back(P);
+    // S_d = q_sqrt_d q_sqrt_d^T feeds the dense backward chain and KS_d; layers whose backward chain always takes the Csave
+    // form (Mp >= 512) and that do not assemble dl/dKu algebraically never read it
+    if (!(sm_chain_enabled() && Mp >= 512 && save_c_enabled(Mp)) || v.alg_g) {
+      fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
+      P.lower_only = 1; P.tri = 2 | 4 | 16;                                                              //   lower x lower^T, symmetric
+      gf.push_back(P);
+    }
     fill_gemm(P, v.Kinv, v.Tp, v.U, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, 0, MM, MM, 0);            // U_d
     P.tri = 1;
     g1.push_back(P);
@@ -1066,6 +1089,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     }
     m->kuu_blocks = std::max(m->kuu_blocks, std::min(1024, (Mp / 16) * (Mp / 16)));
     asm_elems = std::max<int64_t>(asm_elems, (int64_t)v.D_out * v.M * v.M);
+    m->prep_blocks = (int)std::max<int64_t>(m->prep_blocks, std::min<int64_t>(2048, (int64_t)v.D_out * Mp * Mp / 2048));
     // white=True: d l/d Ku from d l/d Lu = -tril(G) through the Cholesky adjoint  Ku_bar = sym(Lu^-T Phi(Lu^T Lu_bar) Lu^-1)
     fill_gemm(P, v.bigred + MM, v.Tp, v.PT, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);   // P_d T_d
     w1.push_back(P);
@@ -1211,8 +1235,9 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
-  hipLaunchKernelGGL(k_prep_kuu, dim3(PREP_BLOCKS + m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
-                     m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter);
+  hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
+                     m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
+                     m->prep_blocks);
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
@@ -1504,11 +1529,14 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
-      if (!m->fin.done) DS_TRY(launch_finalize(m, m->side));   // needs the likelihood partials (main, before ev_bwd) and KL (side)
     }
     DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
   }
   if (overlap) {
+    // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
+    // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
+    // everything queued behind it on this stream waited with it
+    if (!m->fin.done) DS_TRY(launch_finalize(m, m->side));
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
   }

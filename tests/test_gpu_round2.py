@@ -298,3 +298,21 @@ def test_gram_paired_store_path(ctx, n, n2, D):
     _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, _p(dX2), n2, 0.0, _p(out), n2))
     ctx.sync()
     assert_allclose(out.cpu().numpy(), k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(512, 512, 512), (600, 520, 300), (1024, 513, 77), (700, 1030, 1024)])
+def test_gemm_large_tile_kernel(ctx, tA, tB, m, n, k):
+    """dsdgp_gemm with both output dimensions >= 512 runs the 128 x 128 double-buffered kernel (k_gemm_big): ragged edges,
+    every transpose combination, alpha / beta."""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(m + n + k + tA + 2 * tB)
+    A = rng.randn(*((k, m) if tA else (m, k)))
+    B = rng.randn(*((n, k) if tB else (k, n)))
+    Cc = rng.randn(m, n)
+    dA, dB, dC = _dev(ctx, A), _dev(ctx, B), _dev(ctx, Cc)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gemm(ctx.handle, tA, tB, m, n, k, 0.75, _p(dA), A.shape[1], _p(dB), B.shape[1], -1.25, _p(dC), n))
+    ctx.sync()
+    ref = 0.75 * (A.T if tA else A) @ (B.T if tB else B) - 1.25 * Cc
+    assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
