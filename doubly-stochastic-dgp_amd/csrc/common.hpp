@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -90,13 +91,24 @@ struct ProfScope {
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-// Padded inducing count used by every device-side M x M operand: next of {32,64,128,256,...} (power of two >= 32)
-// so that the register-resident chain kernels exist as a handful of template instances.
+// Padded inducing count used by every device-side M x M operand (identity pad on Ku, zero pad elsewhere).  The chain kernels
+// exist for every multiple of 16 up to 128, of 32 up to 256, of 64 up to 512 and of 128 up to 1024: M = 100 (the reference
+// demo size, demos/run_regression.py:57) runs as 112, not 128; M = 300 as 320, not 512.
 static inline int pad_M(int M) {
-  int p = 32;
-  while (p < M) p *= 2;
-  return p;
+  static const int pow2 = getenv("DSDGP_CHAIN_SM") && atoi(getenv("DSDGP_CHAIN_SM")) == 0;   // the generation-2 kernels (layer.hip)
+  if (pow2) {                                                                                // exist for powers of two only
+    int p = 32;
+    while (p < M) p *= 2;
+    return p;
+  }
+  if (M <= 32) return 32;
+  if (M <= 128) return (int)round_up(M, 16);
+  if (M <= 256) return (int)round_up(M, 32);
+  if (M <= 512) return (int)round_up(M, 64);
+  return (int)round_up(M, 128);
 }
+// Row count of the M-major per-row intermediates (A, E, GW) and of the weight-gradient results: whole 64 x 64 split-K tiles
+static inline int pad_Mw(int Mp) { return (int)round_up(Mp, 64); }
 
 // ------------------------------------------------------------------------------------------------------
 // device helpers

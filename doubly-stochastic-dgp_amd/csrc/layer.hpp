@@ -99,4 +99,5 @@ int wgrad_coop_enabled();   // one workgroup per split-K task, four waves reduci
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
 int sm_chain_enabled();
+int sm_cs_built(int Mp);     // the split-M backward chain has a Csave instance for this padded inducing count
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in);   // number of hyp_part rows the split-M backward writes for ld padded rows

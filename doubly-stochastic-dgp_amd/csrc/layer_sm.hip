@@ -1,741 +1,17 @@
-// "Split-M" SVGP_Layer chain (layers.py:178-219 + utils.py:40-41; math identical to layer.hip).
-//
-// Why: v_mfma_f64_16x16x4_f64 needs >= 2 wavefronts per SIMD to run at its pipe rate (a lone wave issues one MFMA per
-// ~59 ns, two waves one per ~45 ns per SIMD — profiles/r01_mfma_f64_microbench.txt), but a 20 000-row layer only has 1250
-// sixteen-row blocks for 1024 SIMDs.  Here the NW waves of a workgroup cooperate on ONE block of 16 data rows: wave w owns
-// the output row-blocks {w, P-1-w, P+w, 2P-1-w, ...} (P = 2 NW; paired so that triangular products carry equal work), the
-// activations live in ONE in-place LDS buffer in MFMA B-operand order ([k][16 rows]: 128-B rows, bank-conflict free), each
-// wave streams only ITS weight columns from L2 (no weight element is fetched twice inside a workgroup), and Z/l is read
-// through L1.  ~23 KB of LDS and < 100 VGPRs at M = 128 => 4-5 workgroups per CU: latency is hidden by thread-level
-// parallelism (explicit prefetching was measured slower because it costs occupancy).
-//   NW = 4  : Mp <= 256          NW = 8 : Mp = 512 (64 KB activation buffer)       NW = 16 : Mp = 1024 (128 KB)
-// Wide inputs (D_in > 64, e.g. the 784-pixel first MNIST layer) stage x/l through LDS in 64-column chunks.
+// Dispatch of the split-M SVGP_Layer chain kernels (layer_sm_impl.hpp).  The instances are compiled in three parts
+// (layer_sm_a / _b / _c.hip: padded inducing counts 32..112, 128..256, 320..1024) so that they build in parallel.
 #include <stdlib.h>
 
 #include "layer.hpp"
 
-#define XCH 64   // columns of x/l staged per chunk
+#define XCH 64
+int layer_fwd_sm_a(dsdgp_ctx*, const LayerFwdArgs&, int, int, int, int);
+int layer_fwd_sm_b(dsdgp_ctx*, const LayerFwdArgs&, int, int, int, int);
+int layer_fwd_sm_c(dsdgp_ctx*, const LayerFwdArgs&, int, int, int, int);
+int layer_bwd_sm_a(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
+int layer_bwd_sm_b(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
+int layer_bwd_sm_c(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
 
-// Operand order of the chain GEMMs — two variants, chosen per instance (measured, tools/ab_kernels.py):
-//  * D4 (NW >= 8, i.e. Mp >= 512): every weight matrix is read as plain rows W[i][k]: lane (g, c) of the wave that owns output
-//    row-block ib fetches W[16 ib + c][16 kb + 4 g .. + 3] with ONE 32-byte load and feeds its four values to the four MFMAs of
-//    the k-block, i.e. MFMA step s contracts k = 16 kb + 4 g + s (any bijection of k inside a 16-block is allowed as long as A
-//    and B agree).  The matching B row is 4 g + s, so the activation rows are stored PERMUTED in LDS (row 4 a + b of a block
-//    lives at slot 4 b + a): the B read of step s is slot 16 kb + 4 s + g, conflict-free with an immediate offset, and the loop
-//    carries one global load and no address arithmetic per four MFMAs (2x on the M = 512 / 1024 chains).
-//  * scalar (NW = 4, Mp <= 256): one 8-byte load per MFMA from the transposed matrix W^T[k][i] (k = 16 kb + 4 s + g, natural
-//    LDS order): each load instruction covers 4 full cache lines, which wins while the whole weight set is L1/L2-hot.
-template <bool D4>
-__device__ __forceinline__ int act_slot(int m) {
-  return D4 ? ((m & ~15) | ((m & 3) << 2) | ((m >> 2) & 3)) : m;
-}
-// slot of row (g + 4 t) of block ib — the MFMA D-layout rows this lane holds
-template <bool D4>
-__device__ __forceinline__ int out_slot(int ib, int g, int t) {
-  return D4 ? 16 * ib + 4 * g + t : 16 * ib + g + 4 * t;
-}
-
-// acc += W[16 ib + c][16 kb .. 16 kb + 15] . act[16 kb .. 16 kb + 15][c]
-//   WR = W as rows [i][k], WT = the same matrix transposed ([k][i]); Mp = leading dimension of both
-template <int Mp, bool D4>
-__device__ __forceinline__ d4 chain_block(const double* __restrict__ WR, const double* __restrict__ WT,
-                                          const double* __restrict__ actb, int ib, int kb, int g, int c, d4 acc) {
-  if constexpr (D4) {
-    const d4 w4 = *reinterpret_cast<const d4*>(WR + (int64_t)(16 * ib + c) * Mp + 16 * kb + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = mfma_f64(w4[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
-  } else {
-    const double* __restrict__ w = WT + (int64_t)(16 * kb + g) * Mp + 16 * ib + c;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = mfma_f64(w[(int64_t)(4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
-  }
-  return acc;
-}
-
-template <int MPB, int NW>
-struct Own {
-  static constexpr int NQ = (MPB >= NW) ? MPB / NW : 1;
-  static __device__ __forceinline__ int ib(int wave, int q) {
-    if (NQ >= 2) return (q & 1) ? (q >> 1) * (2 * NW) + (2 * NW - 1) - wave : (q >> 1) * (2 * NW) + wave;
-    return wave;
-  }
-  static __device__ __forceinline__ bool active(int wave) { return MPB >= NW || wave < MPB; }
-};
-
-// Row-block ownership of the Csave backward d-loop (abar += q_sqrt_d cbar_d, a TRIANGULAR product: row block ib costs ib + 1
-// k-blocks).  8-wave workgroups at Mp = 128 / 256 split into four LIGHT waves, which also stage cbar_d from global memory into
-// LDS, and four HEAVY waves, which never issue those loads: vmcnt retires loads in order, so a wave that has the (HBM-latency)
-// cbar_{d+1} loads in flight stalls at its first (L2-latency) weight fetch — with every wave staging, each output paid the full
-// HBM latency (measured: 67 % of the wave cycles parked, backward chain 1.45x SLOWER than the dense S_d form).  Waves w and w + 4
-// share a SIMD: light wave s + heavy wave 4 + s carry the same MFMA count on every SIMD (9 blocks at Mp = 128, 34 at Mp = 256).
-template <int MPB, int NW>
-struct OwnCS {
-  static constexpr bool CUSTOM = (NW == 8) && (MPB == 8 || MPB == 16);
-  static constexpr int NQ = CUSTOM ? MPB / 8 : Own<MPB, NW>::NQ;
-  static constexpr int NLOAD = CUSTOM ? 4 : NW;      // waves that stage cbar_d
-  static __device__ __forceinline__ int ib(int wave, int q) {
-    if constexpr (!CUSTOM) return Own<MPB, NW>::ib(wave, q);
-    if constexpr (MPB == 8) return wave < 4 ? wave : 11 - wave;                         // light: 0..3 ; heavy: 7, 6, 5, 4
-    if (wave < 4) return q == 0 ? 7 - wave : wave;                                      // light: (7 - s, s)
-    return q == 0 ? 19 - wave : 4 + wave;                                               // heavy: (15 - s, 8 + s), s = wave - 4
-  }
-  static __device__ __forceinline__ bool active(int wave) { return CUSTOM || Own<MPB, NW>::active(wave); }
-};
-
-// outputs per epilogue group of the forward chain: their variance / mean partials are parked in LDS, ONE barrier per group,
-// then all threads write the group's mean / var / F as contiguous runs (the per-output form paid a barrier and 16 scattered
-// 8-byte stores per output).  Double-buffered by group parity.  NW = 16 keeps one output per group (LDS is full at M = 1024).
-static inline constexpr int sm_db(int NW) { return NW == 4 ? 8 : (NW == 8 ? 4 : 1); }
-
-// LDS carve (doubles): xs | act | red
-struct SmLds {
-  int xs, act, red, total;
-};
-static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide, int nbuf = 1) {
-  SmLds L;
-  int o = 0;
-  const int xch = D_in < XCH ? D_in : XCH;
-  L.xs = o; o += 16 * (xch + 1);
-  o = (int)round_up(o, 2);
-  L.act = o; o += Mp * 16;
-  L.red = o;                        // nbuf = 2 (Csave backward chain, Mp <= 256): the second staging buffer; it is free again when the
-                                    // epilogue needs `red`, so the two share the space
-  const bool mu_early = (NW == 4) && !wide;
-  const int db = sm_db(NW);
-  const int red_fwd = NW * 16 + 2 * db * NW * 16 + (mu_early ? NW * 16 * D_out : 2 * db * NW * 16);   // s1 | 2 x [db] s2 | mean partials
-  const int red_bwd = NW * 16 * xch;                            // dX partials of one chunk
-  int red = red_fwd > red_bwd ? red_fwd : red_bwd;
-  if (nbuf == 2 && red < Mp * 16) red = Mp * 16;
-  o += red;
-  L.total = o;
-  return L;
-}
-
-// scaled squared distances of this wave's inducing rows to the block's 16 data rows, D layout, chunked over D_in
-template <int NQ, int MPB, int NW>
-__device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const double* __restrict__ X,
-                                          const double* __restrict__ ils, double* xs, int Din, int64_t r0, int64_t Rin,
-                                          int tid, int wave, int g, int c, bool act, d4 (&r2)[NQ]) {
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) r2[q] = (d4){0, 0, 0, 0};
-  for (int j0 = 0; j0 < Din; j0 += XCH) {
-    const int jn = (Din - j0 < XCH) ? Din - j0 : XCH;
-    if (j0 > 0) __syncthreads();
-    for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
-      const int rr = idx / jn, j = idx % jn;
-      int64_t row = r0 + rr;
-      if (row > Rin - 1) row = Rin - 1;
-      xs[rr * (jn + 1) + j] = X[row * Din + j0 + j] * ils[j0 + j];
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double* __restrict__ zr = zs + (int64_t)(16 * ib + g + 4 * t) * Din + j0;
-          double acc = r2[q][t];
-          for (int j = 0; j < jn; ++j) {
-            const double df = zr[j] - xs[c * (jn + 1) + j];
-            acc = fma(df, df, acc);
-          }
-          r2[q][t] = acc;
-        }
-      }
-    }
-  }
-}
-
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-__global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
-  constexpr bool D4 = (MPB >= 32);
-  constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
-  const int Din = a.D_in, Dout = a.D_out;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  double* xs = smem + L.xs;
-  double* actb = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
-  double* red_s1 = smem + L.red;                          // [NW][16]
-  constexpr int DB = sm_db(NW);
-  double* red_s2 = red_s1 + NW * 16;                      // [2][DB][NW][16]
-  double* red_mu = red_s2 + 2 * DB * NW * 16;             // MU_EARLY: [NW][Dout][16] ; else [2][DB][NW][16]
-  constexpr bool MU_EARLY = (NW == 4) && !WIDE;           // small-M kernels: all mean partials before the q_sqrt loop
-  const double* ils = a.hyp + HYP_ILS;
-  const int64_t r0 = (int64_t)blockIdx.x * 16;
-  const bool act = Own<MPB, NW>::active(wave);
-  const double s2 = a.hyp[HYP_VAR];
-
-  // [X^T ; 1] of this block for the Z-gradient product of the backward pass (coalesced 128-byte runs along the rows)
-  if (a.XT1 && blockIdx.y == 0) {
-    for (int idx = tid; idx < 16 * (Din + 1); idx += NW * 64) {
-      const int j = idx >> 4, rr = idx & 15;
-      const int64_t r = r0 + rr;
-      if (r < a.ldA) a.XT1[(int64_t)j * a.ldA + r] = (r < a.Rin) ? (j < Din ? a.X[r * Din + j] : 1.0) : 0.0;
-    }
-  }
-  // --- Kuf tile (layers.py:184): own row-blocks -> act
-  if constexpr (!WIDE) {
-    // D_in <= XCH: one staging pass, distances accumulated element by element (fewest live registers)
-    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
-      const int rr = idx / Din, j = idx % Din;
-      int64_t row = r0 + rr;
-      if (row > a.Rin - 1) row = a.Rin - 1;
-      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int m = 16 * ib + g + 4 * t;
-          const double* __restrict__ zr = a.Zs + (int64_t)m * Din;
-          double r2 = 0.0;
-          for (int j = 0; j < Din; ++j) {
-            const double df = zr[j] - xs[c * (Din + 1) + j];
-            r2 = fma(df, df, r2);
-          }
-          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
-        }
-      }
-    }
-  } else {
-    d4 r2[NQ];
-    sm_sqdist<NQ, MPB, NW>(a.Zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int m = 16 * ib + g + 4 * t;
-          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  d4 acc[NQ];
-  // --- a1 = Lu^{-1} k (layers.py:186): out block ib sums k-blocks kb <= ib ; weights LinvT[k][i]
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 4
-      for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(a.Linv, a.LinvT, actb, ib, kb, g, c, acc[q]);
-    }
-  }
-  {
-    double p = 0.0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) p = fma(acc[q][t], acc[q][t], p);
-    p = sum_groups(p);
-    if (g == 0) red_s1[wave * 16 + c] = act ? p : 0.0;
-  }
-  __syncthreads();   // every wave has finished reading k before a1 overwrites it in place
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
-    }
-  }
-  __syncthreads();
-  // --- a = Lu^{-T} a1 (layers.py:188): out block ib sums kb >= ib ; weights Linv[k][i]   (white: a = a1)
-  if (!WHITE) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 4
-        for (int kb = ib; kb < MPB; ++kb) acc[q] = chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, acc[q]);
-      }
-    }
-    __syncthreads();   // a1 fully consumed -> overwrite with a
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
-      }
-    }
-  }
-  // acc holds this wave's rows of "a": save for the backward pass, and the partial mean a . q_mu (layers.py:190)
-  if (act && a.Asave && blockIdx.y == 0) {
-    const int64_t r = r0 + c;
-    if (r < a.ldA) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = (r < a.Rin) ? acc[q][t] : 0.0;
-      }
-    }
-  }
-  if constexpr (MU_EARLY) {
-    for (int d = 0; d < Dout; ++d) {
-      double mu = 0.0;
-      if (act) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
-        }
-      }
-      mu = sum_groups(mu);
-      if (g == 0) red_mu[(wave * Dout + d) * 16 + c] = mu;
-    }
-  }
-  __syncthreads();
-
-  const double kdiag = a.hyp[HYP_KDIAG];
-  // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
-  const int dchunk = (Dout + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
-  for (int d0 = d_lo, grp = 0; d0 < d_hi; d0 += DB, ++grp) {
-    const int gs = (d_hi - d0 < DB) ? d_hi - d0 : DB;
-    double* rs2 = red_s2 + (grp & 1) * DB * NW * 16;
-    double* rmu_g = red_mu + (grp & 1) * DB * NW * 16;     // !MU_EARLY only
-    for (int dd = 0; dd < gs; ++dd) {
-      const int d = d0 + dd;
-      // --- c_d = q_sqrt_d^T a ; |c_d|^2 (replaces SK/B of layers.py:195-212): out block ib sums kb >= ib
-      d4 cacc[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
-      if (act) {
-        const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
-        const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 4
-          for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
-        }
-      }
-      double p = 0.0, mu = 0.0;
-      if (act) {
-        if (a.Csave) {
-          // c_d for the backward chain, BLOCK-major: the (Mp x 16) tile of (row block, output d) is one contiguous 16*Mp*8-byte
-          // run stored in LDS slot order, so this store and the backward staging are plain streaming copies (an M-major
-          // layout like Asave put every 128-byte run on its own page: TLB- and DRAM-page-hostile at D_out*Mp runs per block)
-          const int64_t r = r0 + c;
-          double* __restrict__ Cd = a.Csave + ((int64_t)blockIdx.x * Dout + d) * (Mp * 16) + c;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const double cv = (r < a.Rin) ? cacc[q][t] : 0.0;
-              Cd[out_slot<D4>(ib, g, t) * 16] = cv;
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            p = fma(cacc[q][t], cacc[q][t], p);
-            if constexpr (!MU_EARLY) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
-          }
-        }
-      }
-      p = sum_groups(p);
-      if constexpr (!MU_EARLY) mu = sum_groups(mu);
-      if (g == 0) {
-        rs2[(dd * NW + wave) * 16 + c] = p;
-        if constexpr (!MU_EARLY) rmu_g[(dd * NW + wave) * 16 + c] = mu;
-      }
-    }
-    __syncthreads();
-    // epilogue of the group: thread e <-> (sample s, row cc, output dd); a row's gs outputs are contiguous in mean / var / F.
-    // The first layer writes `rep` = S output rows per input row: those are spread over the threads too (one thread walking
-    // its S rows serially — z load, three stores each — was a third of that latency-bound launch); a Linear mean function keeps
-    // the per-row form (its D_in-long dot product is not worth repeating per sample).
-    const bool flat = a.rep > 1 && a.mean_kind != DSDGP_MEAN_LINEAR;
-    const int n_items = 16 * gs * (flat ? a.rep : 1);
-    for (int e = tid; e < n_items; e += NW * 64) {
-      const int s0 = flat ? e / (16 * gs) : 0, e2 = e % (16 * gs);
-      const int cc = e2 / gs, dd = e2 % gs, d = d0 + dd;
-      const int64_t r = r0 + cc;
-      if (r >= a.Rin) continue;
-      double s1 = 0.0, s2sum = 0.0, mu = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        s1 += red_s1[w * 16 + cc];
-        s2sum += rs2[(dd * NW + w) * 16 + cc];
-        mu += MU_EARLY ? red_mu[(w * Dout + d) * 16 + cc] : rmu_g[(dd * NW + w) * 16 + cc];
-      }
-      const double var = kdiag - s1 + s2sum;                               // layers.py:212-217
-      if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
-        mu += a.X[r * Din + d];
-      } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-        double m2 = 0.0;
-        for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
-        mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
-      }
-      const double sd = sqrt(var + a.jitter);
-      const int s_lo = flat ? s0 : 0, s_hi = flat ? s0 + 1 : a.rep;
-      for (int s = s_lo; s < s_hi; ++s) {
-        const int64_t orow = (int64_t)s * a.Rin + r;
-        const int64_t o = orow * Dout + d;
-        if (a.mean) a.mean[o] = mu;
-        if (a.var) a.var[o] = var;
-        if (a.F && a.z) {
-          const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
-          a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * NW + wave).
-// ------------------------------------------------------------------------------------------------------
-// CS: abar's variance part from the saved c_d (triangular q_sqrt_d products, staged through LDS) instead of dense S_d a
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
-__global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
-  constexpr bool D4 = (MPB >= 32);
-  constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
-  const int Din = a.D_in, Dout = a.D_out;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const double* __restrict__ zs = a.Zs;
-  double* xs = smem + L.xs;
-  double* actb = smem + L.act;
-  double* redx = smem + L.red;                            // [NW][chunk][16]
-  const double* ils = a.hyp + HYP_ILS;
-  const int64_t r0 = (int64_t)blockIdx.x * 16;
-  const bool act = Own<MPB, NW>::active(wave);
-  const double s2 = a.hyp[HYP_VAR];
-  const int64_t r = r0 + c;
-  const bool rin = r < a.ldA, rvalid = r < a.Rin;
-  d4 av[NQ], acc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int ib = Own<MPB, NW>::ib(wave, q);
-    acc[q] = (d4){0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double v = (act && rin) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] : 0.0;
-      av[q][t] = v;
-      if (!CS && act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
-    }
-  }
-  double gsum = 0.0;
-  if constexpr (CS) {
-    // cbar_d = 2 vbar_d c_d staged into LDS ([k][16 rows], B-operand order), abar += q_sqrt_d cbar_d: out block ib sums kb <= ib.
-    // Mp <= 256: two staging buffers (the loads of output d+1 fly during the products of d, one barrier per output);
-    // Mp >= 512: LDS holds one buffer (two barriers per output, loads still prefetched).
-    using OC = OwnCS<MPB, NW>;
-    constexpr bool DBUF = (MPB <= 16);
-    constexpr int NLT = OC::NLOAD * 64;             // staging threads
-    constexpr int NS = Mp * 16 / (NLT * 2);         // staged element PAIRS per staging thread (16-byte loads / LDS stores)
-    double* buf1 = DBUF ? smem + L.red : actb;
-    const bool stager = tid < NLT;
-    const int e0 = 2 * tid;                         // pair i of this thread: elements e0 + i * 2 NLT (+1) of the tile; rows scc, scc + 1
-    const int scc = e0 & 15;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 tmp[NS];
-    auto stage_load = [&](int d) {
-      if (!stager) return;
-      const d2 v2 = 2.0 * *reinterpret_cast<const d2*>(a.VB + (int64_t)d * a.ldA + r0 + scc);
-      const double* __restrict__ Cd = a.Csave + ((int64_t)blockIdx.x * Dout + d) * (Mp * 16) + e0;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) tmp[i] = v2 * *reinterpret_cast<const d2*>(Cd + i * 2 * NLT);
-    };
-    auto stage_store = [&](double* buf) {
-      if (!stager) return;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) *reinterpret_cast<d2*>(buf + e0 + i * 2 * NLT) = tmp[i];
-    };
-    constexpr bool PREF = (NW < 16);            // NW = 16 (1024 threads, 128-VGPR cap): no prefetch across the products (spills)
-    d4 cacc[OC::NQ];
-#pragma unroll
-    for (int q = 0; q < OC::NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
-    const bool cact = OC::active(wave);
-    if (PREF) stage_load(0);
-    if (DBUF) stage_store(actb);
-    for (int d = 0; d < Dout; ++d) {
-      gsum += rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
-      double* cur = (DBUF && (d & 1)) ? buf1 : actb;
-      if (DBUF) {
-        if (d + 1 < Dout) stage_load(d + 1);
-        __syncthreads();
-      } else {
-        __syncthreads();          // the products of output d-1 are done with the buffer
-        if (!PREF) stage_load(d);
-        stage_store(actb);
-        __syncthreads();
-        if (PREF && d + 1 < Dout) stage_load(d + 1);
-      }
-      if (cact) {
-        const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
-        const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
-#pragma unroll
-        for (int q = 0; q < OC::NQ; ++q) {
-          const int ib = OC::ib(wave, q);
-#pragma unroll 4
-          for (int kb = 0; kb <= ib; ++kb) cacc[q] = chain_block<Mp, D4>(Td, TdT, cur, ib, kb, g, c, cacc[q]);
-        }
-      }
-      if (DBUF && d + 1 < Dout) stage_store((d & 1) ? actb : buf1);
-    }
-    // mean part (abar += q_mu mbar) and hand-over of abar through LDS, under the d-loop's ownership
-    if (cact) {
-      for (int sp = 0; sp < a.DP4 / 4; ++sp) {
-        const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
-#pragma unroll
-        for (int q = 0; q < OC::NQ; ++q)
-          cacc[q] = mfma_f64(a.qmu4[(int64_t)(16 * OC::ib(wave, q) + c) * a.DP4 + 4 * sp + g], bv, cacc[q]);
-      }
-    }
-    __syncthreads();   // the last staged operand is consumed -> abar goes into the first buffer
-    if (cact) {
-#pragma unroll
-      for (int q = 0; q < OC::NQ; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) actb[out_slot<D4>(OC::ib(wave, q), g, t) * 16 + c] = cacc[q][t];
-    }
-    __syncthreads();
-    if (WHITE) {       // a1bar = abar - 2 gsum a1, applied by the waves that hold those rows of a1 (standard ownership)
-      if (act) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) actb[out_slot<D4>(Own<MPB, NW>::ib(wave, q), g, t) * 16 + c] -= 2.0 * gsum * av[q][t];
-      }
-      __syncthreads();
-    }
-  } else {
-  __syncthreads();
-  for (int d = 0; d < Dout; ++d) {
-    const double vd = rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
-    gsum += vd;
-    const double vd2 = 2.0 * vd;
-    if (act) {
-      const double* __restrict__ Sd = a.Sd + (int64_t)d * Mp * Mp;
-      if constexpr (ILV) {
-        // y_d = S_d a for this wave's row blocks (the NQ chains interleaved), then abar += 2 vbar_d(column) * y_d
-        d4 y[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] = (d4){0, 0, 0, 0};
-#pragma unroll 4
-        for (int kb = 0; kb < MPB; ++kb) {
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) y[q] = chain_block<Mp, D4>(Sd, Sd, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, y[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[q][t] = fma(vd2, y[q][t], acc[q][t]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-          const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
-#pragma unroll 4
-          for (int kb = 0; kb < MPB; ++kb) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c] * vd2, acc[q]);
-          }
-        }
-      }
-    }
-  }
-  }
-  if constexpr (!CS) {
-  if (act) {
-    for (int sp = 0; sp < a.DP4 / 4; ++sp) {
-      const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-        acc[q] = mfma_f64(a.qmu4[(int64_t)(16 * ib + c) * a.DP4 + 4 * sp + g], bv, acc[q]);
-      }
-    }
-  }
-  __syncthreads();   // "a" fully consumed from LDS -> overwrite with abar in place
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (WHITE) acc[q][t] -= 2.0 * gsum * av[q][t];
-        actb[out_slot<D4>(ib, g, t) * 16 + c] = acc[q][t];
-      }
-    }
-  }
-  __syncthreads();
-  }
-  // b = Ku^{-1} abar (dense)   |   white: kbar = Lu^{-T} a1bar (k-blocks >= own block)
-  d4 bb[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) bb[q] = (d4){0, 0, 0, 0};
-  if (act) {
-    if (WHITE || !ILV) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll 4
-        for (int kb = (WHITE ? ib : 0); kb < MPB; ++kb)
-          bb[q] = WHITE ? chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, bb[q])
-                        : chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, ib, kb, g, c, bb[q]);
-      }
-    } else {
-#pragma unroll 4
-      for (int kb = 0; kb < MPB; ++kb) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) bb[q] = chain_block<Mp, D4>(a.Kinv, a.Kinv, actb, Own<MPB, NW>::ib(wave, q), kb, g, c, bb[q]);
-      }
-    }
-  }
-  // E, kbar; recompute the Kuf tile for GW = kbar * dk/dr2
-  d4 r2[WIDE ? NQ : 1];
-  if constexpr (WIDE) {
-    sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
-  } else {
-    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
-      const int rr = idx / Din, j = idx % Din;
-      int64_t row = r0 + rr;
-      if (row > a.Rin - 1) row = a.Rin - 1;
-      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
-    }
-    __syncthreads();
-  }
-  double svar = 0.0;
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int m = 16 * ib + g + 4 * t;
-        const double e = WHITE ? bb[q][t] : bb[q][t] - gsum * av[q][t];
-        const double kbar = WHITE ? e : e - gsum * av[q][t];
-        double r2v;
-        if constexpr (WIDE) {
-          r2v = r2[q][t];
-        } else {
-          r2v = 0.0;
-          for (int j = 0; j < Din; ++j) {
-            const double df = zs[(int64_t)m * Din + j] - xs[c * (Din + 1) + j];
-            r2v = fma(df, df, r2v);
-          }
-        }
-        double k, dk;
-        kern_val_grad<KIND>(r2v, s2, k, dk);
-        const bool ok = rvalid && (m < a.M);
-        svar += ok ? kbar * k : 0.0;
-        const double w = ok ? kbar * dk : 0.0;
-        bb[q][t] = w;
-        if (rin) {
-          if (a.E) a.E[(int64_t)m * a.ldA + r] = e;     // NULL: d loss / d Ku is assembled from the P_d (model.hip, alg_g)
-          a.GW[(int64_t)m * a.ldA + r] = w;
-        }
-      }
-    }
-  }
-  svar = sum_wave(svar);
-  const double gk = sum_wave((rvalid && g == 0 && wave == 0) ? gsum : 0.0);
-  double* hp = a.hyp_part + ((int64_t)blockIdx.x * NW + wave) * (Din + 2);
-  if (lane == 0) {
-    hp[0] = svar / s2;
-    hp[1] = gk;
-  }
-  // lengthscale partials and d loss / d X, chunked over D_in like the distance computation
-  for (int j0 = 0; j0 < Din; j0 += XCH) {
-    const int jn = (Din - j0 < XCH) ? Din - j0 : XCH;
-    if (WIDE) {   // single-chunk kernels: xs still holds x/l staged above
-      __syncthreads();
-      for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
-        const int rr = idx / jn, j = idx % jn;
-        int64_t row = r0 + rr;
-        if (row > a.Rin - 1) row = a.Rin - 1;
-        xs[rr * (jn + 1) + j] = a.X[row * Din + j0 + j] * ils[j0 + j];
-      }
-      __syncthreads();
-    }
-    for (int j = 0; j < jn; ++j) {
-      double sx = 0.0, sl = 0.0;
-      if (act) {
-        const double xv = xs[c * (jn + 1) + j];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const double df = xv - zs[(int64_t)(16 * ib + g + 4 * t) * Din + j0 + j];
-            const double wdf = bb[q][t] * df;
-            sx += wdf;
-            sl = fma(wdf, df, sl);
-          }
-        }
-      }
-      if (a.dX || a.MBp) {
-        sx = sum_groups(sx);
-        if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
-      }
-      sl = sum_wave(sl);
-      if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
-    }
-    if (a.dX || a.MBp) {
-      __syncthreads();
-      for (int idx = tid; idx < 16 * jn; idx += NW * 64) {
-        // dX is row-major (j fastest); the fused transposed adjoints are M-major (row fastest): keep the stores coalesced
-        const int j = a.MBp ? idx / 16 : idx % jn, cc = a.MBp ? idx % 16 : idx / jn;
-        const int64_t row = r0 + cc;
-        if (row < a.Rin) {
-          double sx = 0.0;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) sx += redx[(w * jn + j) * 16 + cc];
-          double dx = 2.0 * ils[j0 + j] * sx;
-          if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
-            dx += a.MB[(int64_t)(j0 + j) * a.ldA + row];
-          } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-            for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[(int64_t)(j0 + j) * Dout + d], a.MB[(int64_t)d * a.ldA + row], dx);
-          }
-          if (a.MBp) {
-            const int d = j0 + j - a.prop;
-            if (d >= 0) {
-              const double zv = a.zp[(row / a.n_inner) * a.zp_s + (row % a.n_inner) * a.zp_n + d * a.zp_d];
-              a.MBp[(int64_t)d * a.ldA + row] = dx;
-              a.VBp[(int64_t)d * a.ldA + row] = dx * zv * 0.5 * rsqrt(a.varp[row * a.Dp + d] + a.jitter);
-            }
-          } else {
-            a.dX[row * Din + j0 + j] = dx;
-          }
-        } else if (a.MBp && row < a.ldA && j0 + j >= a.prop) {
-          a.MBp[(int64_t)(j0 + j - a.prop) * a.ldA + row] = 0.0;
-          a.VBp[(int64_t)(j0 + j - a.prop) * a.ldA + row] = 0.0;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// dispatch
-// ------------------------------------------------------------------------------------------------------
 int sm_chain_enabled() {
   static const int on = getenv("DSDGP_CHAIN_SM") ? atoi(getenv("DSDGP_CHAIN_SM")) : 1;
   return on;
@@ -743,110 +19,32 @@ int sm_chain_enabled() {
 // waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
 // one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
 #define SM_SMALL_BLOCKS 160
-static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd, bool cs = false) {
+static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
   static const int on = getenv("DSDGP_SM_SMALL") ? atoi(getenv("DSDGP_SM_SMALL")) : 1;
-  static const int cs_nw4 = getenv("DSDGP_CS_NW4") ? atoi(getenv("DSDGP_CS_NW4")) : 0;
-  // Csave backward at M = 128: 8 waves own ONE row block each, so the triangular q_sqrt_d products are unbalanced (1..8 blocks);
-  // 4 waves own a balanced pair (w, 7 - w)
-  if (cs && cs_nw4 && Mp == 128 && nblk > SM_SMALL_BLOCKS) return false;
   // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
   // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
   // (the 4-wave forward instance has the early-mean specialisation)
   const int64_t lim = (Mp == 256 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
   return on && (Mp == 128 || Mp == 256) && nblk <= lim && D_in <= XCH;
 }
+// waves per row block of the instance that a launch of this shape takes
 static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {
-  return Mp >= 1024 ? 16 : (Mp >= 512 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
+  return Mp > 512 ? 16 : (Mp > 256 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
 }
-// upper bound over both variants (rows of hyp_part are written per wave: unused rows stay zero)
+// rows of hyp_part the backward chain writes (one per wave)
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in, true) * ceil_div(ld, 16); }
-
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
-  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE);
-  const size_t lds = (size_t)L.total * sizeof(double);
-  if (lds > 160 * 1024) {
-    dsdgp_set_error("layer_fwd(sm): needs %zu B LDS (> 160 KiB): D_out too large for this M", lds);
-    return DSDGP_ERR_UNSUPPORTED;
-  }
-  if (lds > 64 * 1024)
-    {
-      static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
-      if ((int)lds > lds_set) {
-        DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = (int)lds;
-      }
-    }
-  ProfScope ps(ctx, "layer_fwd");
-  const int nrow = ceil_div(a.Rin, 16);
-  int ds = a.d_split > 0 ? a.d_split : 1;
-  if (ds > a.D_out) ds = a.D_out;
-  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
-  DS_HIP(hipGetLastError());
-  return DSDGP_OK;
-}
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
-static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
-  const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE, (CS && MPB <= 16) ? 2 : 1);
-  const size_t lds = (size_t)L.total * sizeof(double);
-  if (lds > 160 * 1024) {
-    dsdgp_set_error("layer_bwd(sm): needs %zu B LDS (> 160 KiB)", lds);
-    return DSDGP_ERR_UNSUPPORTED;
-  }
-  if (lds > 64 * 1024)
-    {
-      static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
-      if ((int)lds > lds_set) {
-        DS_HIP(hipFuncSetAttribute((const void*)k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = (int)lds;
-      }
-    }
-  ProfScope ps(ctx, "layer_bwd");
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
-  DS_HIP(hipGetLastError());
-  return DSDGP_OK;
-}
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-static int bwd_sm_go(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
-  return a.Csave ? bwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, true>(ctx, a) : bwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, false>(ctx, a);
-}
-
-#define SM_CASE2(FN, MPB, NW, KIND, ARGS)                                                              \
-  if (wide) return white ? FN<MPB, NW, KIND, true, true> ARGS : FN<MPB, NW, KIND, false, true> ARGS;      \
-  return white ? FN<MPB, NW, KIND, true, false> ARGS : FN<MPB, NW, KIND, false, false> ARGS;
-#define SM_CASE(FN, MPB, NW, ARGS)                                           \
-  case MPB * 16:                                                             \
-    if (kern_kind == DSDGP_KERN_RBF) { SM_CASE2(FN, MPB, NW, DSDGP_KERN_RBF, ARGS) }   \
-    SM_CASE2(FN, MPB, NW, DSDGP_KERN_MATERN52, ARGS)
-#define SM_DISPATCH(FN, ARGS)                                                          \
-  switch (Mp) {                                                                        \
-    SM_CASE(FN, 2, 4, ARGS) SM_CASE(FN, 4, 4, ARGS) SM_CASE(FN, 8, 4, ARGS)            \
-    SM_CASE(FN, 16, 4, ARGS) SM_CASE(FN, 32, 8, ARGS) SM_CASE(FN, 64, 16, ARGS)        \
-    default:                                                                           \
-      dsdgp_set_error("layer chain: padded inducing count %d not built (32..1024)", Mp); \
-      return DSDGP_ERR_UNSUPPORTED;                                                    \
-  }
-
-#define SM_SMALL_CASE(FN, MPB, ARGS)                                                                       \
-  if (Mp == MPB * 16) {                                                                                    \
-    if (kern_kind == DSDGP_KERN_RBF)                                                                       \
-      return white ? FN<MPB, 8, DSDGP_KERN_RBF, true, false> ARGS : FN<MPB, 8, DSDGP_KERN_RBF, false, false> ARGS; \
-    return white ? FN<MPB, 8, DSDGP_KERN_MATERN52, true, false> ARGS : FN<MPB, 8, DSDGP_KERN_MATERN52, false, false> ARGS; \
-  }
+// padded inducing counts whose backward chain has a Csave instance (layer_sm_impl.hpp: sm_cs_inst)
+int sm_cs_built(int Mp) { return Mp > 256 || Mp == 32 || Mp == 64 || Mp == 128 || Mp == 256; }
 
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white) {
-  const bool wide = a.D_in > XCH;
-  if (sm_small(Mp, ceil_div(a.Rin, 16), a.D_in, false)) {
-    SM_SMALL_CASE(fwd_sm_go, 8, (ctx, a))
-    SM_SMALL_CASE(fwd_sm_go, 16, (ctx, a))
-  }
-  SM_DISPATCH(fwd_sm_go, (ctx, a))
+  const int small = sm_small(Mp, ceil_div(a.Rin, 16), a.D_in, false);
+  if (Mp < 128) return layer_fwd_sm_a(ctx, a, Mp, kern_kind, white, small);
+  if (Mp <= 256) return layer_fwd_sm_b(ctx, a, Mp, kern_kind, white, small);
+  return layer_fwd_sm_c(ctx, a, Mp, kern_kind, white, small);
 }
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white) {
-  const bool wide = a.D_in > XCH;
-  if (sm_small(Mp, ceil_div(a.ldA, 16), a.D_in, true, a.Csave != nullptr)) {
-    SM_SMALL_CASE(bwd_sm_go, 8, (ctx, a))
-    SM_SMALL_CASE(bwd_sm_go, 16, (ctx, a))
-  }
-  SM_DISPATCH(bwd_sm_go, (ctx, a))
+  const int small = sm_small(Mp, ceil_div(a.ldA, 16), a.D_in, true);
+  if (Mp < 128) return layer_bwd_sm_a(ctx, a, Mp, kern_kind, white, small);
+  if (Mp <= 256) return layer_bwd_sm_b(ctx, a, Mp, kern_kind, white, small);
+  return layer_bwd_sm_c(ctx, a, Mp, kern_kind, white, small);
 }

@@ -47,8 +47,11 @@ struct RedJob {
   int64_t count;
   int32_t nsplit, blk_start;
   int32_t wide;        // wide: few outputs, many splits -> one workgroup per output element (fixed-order tree)
-  int32_t sym_n;       // > 0: (sym_n x sym_n) symmetric result whose 64x64 tiles above the diagonal were not computed
+  int32_t sym_n;       // > 0: symmetric result whose tiles above the diagonal were not computed (mirrored here)
   int32_t sym_tile;
+  int64_t pstride;     // elements between consecutive splits of `part`
+  int32_t in_ld, out_ld;   // > 0: 2-D result, `part` rows have leading dimension in_ld (the weight-gradient products run on
+                           // whole 64-row tiles: Mw = round_up(Mp, 64)), `out` rows out_ld; 0: linear
 };
 
 struct LayerState {
@@ -156,11 +159,12 @@ static int cs_min_blocks() { return getenv("DSDGP_CS_MIN_BLOCKS") ? atoi(getenv(
 // Policy (measured, profiles/r02_csave_notes.md): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %: the per-output products are
 // long enough to hide the staging latency); at Mp = 128 / 256 the d-loop turns from MFMA-throughput-bound into latency-bound and
 // the chain gets no faster (cfg 2) or slower (cfg 3, register pressure halves the occupancy), so those sizes keep the S_d form.
-//   DSDGP_SAVE_C = 0: never, 1 (default): Mp >= 512, 2: every size (parity tests force the small instances)
+//   DSDGP_SAVE_C = 0: never, 1 (default): Mp > 256 (the 8- / 16-wave row-oriented instances), 2: every size that has an
+//   instance (parity tests force the small ones)
 static int save_c_mode() { return getenv("DSDGP_SAVE_C") ? atoi(getenv("DSDGP_SAVE_C")) : 1; }
 static bool save_c_enabled(int Mp = 1 << 30) {
   const int mode = save_c_mode();
-  return sm_chain_enabled() && (mode >= 2 || (mode == 1 && Mp >= 512));
+  return sm_chain_enabled() && (mode >= 2 || (mode == 1 && Mp > 256));
 }
 static int big_mp(bool uniform) {
   static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
@@ -182,8 +186,8 @@ static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks)
 
 static void wgrad_shapes(int Mp, int& NI, int& ti) {
   static const int ni_env = getenv("DSDGP_WGRAD_NI") ? atoi(getenv("DSDGP_WGRAD_NI")) : 0;   // tuning knob: 2 -> 32x32 tiles
-  NI = (Mp % 64 == 0 && ni_env != 2) ? 4 : 2;
-  ti = Mp / (16 * NI);
+  NI = (ni_env != 2) ? 4 : 2;
+  ti = pad_Mw(Mp) / (16 * NI);        // the products run on Mw = round_up(Mp, 64) rows (zero rows beyond Mp)
 }
 
 static void layout(dsdgp_model* m, char* base, size_t* total) {
@@ -262,7 +266,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
       const int alg_env = getenv("DSDGP_ALG_G") ? atoi(getenv("DSDGP_ALG_G")) : -1;   // -1: heuristic, 0: never, 1: always (read per model)
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
       v.alg_g = (!D.white && sm_chain_enabled() && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
-      v.need_tpt = (v.Mp >= 512 || save_c_enabled(v.Mp)) ? 1 : 0;
+      v.need_tpt = (v.Mp > 256 || save_c_enabled(v.Mp)) ? 1 : 0;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }
@@ -276,7 +280,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.R_max = (int64_t)m->s_max * m->n_max;
     const int64_t Rin_max = (l == 0) ? m->n_max : S.R_max;
     S.ld_max = round_up(Rin_max, 16);
-    S.A = b.take<double>(Mp * S.ld_max); S.E = b.take<double>(Mp * S.ld_max); S.GW = b.take<double>(Mp * S.ld_max);
+    const size_t Mw = pad_Mw(v.Mp);      // rows Mp..Mw-1 stay zero (never written): whole tiles for the weight-gradient products
+    S.A = b.take<double>(Mw * S.ld_max); S.E = b.take<double>(Mw * S.ld_max); S.GW = b.take<double>(Mw * S.ld_max);
     S.C = save_c_enabled((int)Mp) ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
     S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
     S.XT1 = b.take<double>((size_t)round_up(v.DinP16, 64) * S.ld_max);   // rows >= DinP16 stay zero: whole 64-row tiles for the mean-gradient product
@@ -287,12 +292,12 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.Xcat = S.prop ? b.take<double>(S.R_max * (d.D_out + S.prop)) : nullptr;
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
-    const int tj_big = v.Mp / (16 * NI);
+    const int tj_big = ti;
     S.nsplit_big_max = choose_nsplit((v.alg_g ? 0 : ti * tj_big) + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
                                      S.ld_max / 16, 1024);
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
-    S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * MM);
-    S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mp * (v.DP16 + v.DinP16));
+    S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * Mw * Mw);
+    S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
     S.wj = b.take<WgradJob>(d.D_out + 4);
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
   if (J.wide) {
     const int64_t i = blockIdx.x - J.blk_start;     // one workgroup per output element
     double s = 0.0;
-    for (int sp = threadIdx.x; sp < J.nsplit; sp += 256) s += J.part[(int64_t)sp * J.count + i];
+    for (int sp = threadIdx.x; sp < J.nsplit; sp += 256) s += J.part[(int64_t)sp * J.pstride + i];
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) J.out[i] = s;
     return;
@@ -685,24 +690,27 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
   const int64_t i0 = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
   if (i0 >= J.count) return;
   int64_t i = i0, o = i0;
-  if (J.sym_n > 0) {
-    // tiles above the diagonal were not computed: the thread that would own element (lr, lc) of upper tile (ti, tj) sums the
-    // SAME local element of the lower tile (tj, ti) — coalesced partial reads — and stores it at the transposed position
-    const int64_t r = i0 / J.sym_n, cc = i0 % J.sym_n;
-    const int64_t ti = r / J.sym_tile, tj = cc / J.sym_tile;
-    if (tj > ti) {
-      const int64_t lr = r % J.sym_tile, lc = cc % J.sym_tile;
-      i = (tj * J.sym_tile + lr) * J.sym_n + ti * J.sym_tile + lc;
-      o = (ti * J.sym_tile + lc) * J.sym_n + tj * J.sym_tile + lr;
+  if (J.out_ld > 0) {
+    const int64_t r = i0 / J.out_ld, cc = i0 % J.out_ld;
+    i = r * J.in_ld + cc;
+    if (J.sym_n > 0) {
+      // tiles above the diagonal were not computed: the thread that would own element (lr, lc) of upper tile (ti, tj) sums the
+      // SAME local element of the lower tile (tj, ti) — coalesced partial reads — and stores it at the transposed position
+      const int64_t ti = r / J.sym_tile, tj = cc / J.sym_tile;
+      if (tj > ti) {
+        const int64_t lr = r % J.sym_tile, lc = cc % J.sym_tile;
+        i = (tj * J.sym_tile + lr) * J.in_ld + ti * J.sym_tile + lc;
+        o = (ti * J.sym_tile + lc) * J.out_ld + tj * J.sym_tile + lr;
+      }
     }
   }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
   for (; sp + 8 <= J.nsplit; sp += 8) {     // eight independent loads in flight; fixed order -> deterministic
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.count + i];
+    for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.pstride + i];
   }
-  for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.count + i];
+  for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.pstride + i];
   J.out[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
@@ -1061,7 +1069,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     gf.push_back(P);
     // S_d = q_sqrt_d q_sqrt_d^T feeds the dense backward chain and KS_d; layers whose backward chain always takes the Csave
     // form (Mp >= 512) and that do not assemble dl/dKu algebraically never read it
-    if (!(sm_chain_enabled() && Mp >= 512 && save_c_enabled(Mp)) || v.alg_g) {
+    if (!(sm_chain_enabled() && Mp > 256 && save_c_enabled(Mp)) || v.alg_g) {
       fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
       P.lower_only = 1; P.tri = 2 | 4 | 16;                                                              //   lower x lower^T, symmetric
       gf.push_back(P);
@@ -1352,7 +1360,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     // c_d is kept for the backward chain where that pays: enough row blocks to hide the extra latency per output (the N-row first
     // layer is a latency-bound launch) and enough outputs for the halved d-loop to matter
     // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
-    St.c_used = save && St.C && (v.Mp >= 512 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
+    St.c_used = save && St.C && sm_cs_built(v.Mp) && (v.Mp > 256 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
     a.Csave = St.c_used ? St.C : nullptr;
     a.flags = dbg_flags();
     a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
@@ -1402,6 +1410,8 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     const int64_t MM = (int64_t)v.Mp * v.Mp;
+    const int Mw = pad_Mw(v.Mp);
+    const int64_t MMw = (int64_t)Mw * Mw;
     std::vector<WgradJob> jobs;
     // G is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
     // of the K splits, so every task carries about the same number of MFMAs.  alg_g layers have no G job (k_asm_kbar
@@ -1418,19 +1428,19 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.P = (j == 0) ? St.E : St.A;
       J.Q = St.A;
       J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
-      J.out = St.part_big + (int64_t)j * ns * MM;
-      J.ti = ti; J.tj = ti; J.ldo = v.Mp; J.task_start = start;
-      J.sym = (j >= 1) ? 1 : 0; J.qrows16 = v.Mp / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
+      J.out = St.part_big + (int64_t)j * ns * MMw;
+      J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = start;
+      J.sym = (j >= 1) ? 1 : 0; J.qrows16 = Mw / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
       J.ns_diag = ns_diag; J.pad = 0;
       start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
       jobs.push_back(J);
-      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16});   // mirror at 16-block granularity
+      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
     }
     // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
     const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI), nt = ns;
     St.ns_thin = nt;
     double* const out_q = St.part_thin;
-    double* const out_z = St.part_thin + (int64_t)nt * v.Mp * v.DP16;
+    double* const out_z = St.part_thin + (int64_t)nt * Mw * v.DP16;
     jobs.push_back(WgradJob{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, start, 0, v.DP16 / 16, 0, 0});
     start += nt * ti * tjq;
     jobs.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, start, 0, v.DinP16 / 16, 0, 0});
@@ -1440,17 +1450,17 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       const int tim = ceil_div(v.DinP16 / 16, NI), tjm = ceil_div(v.DP16 / 16, NI);
       jobs.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, start, 0, v.DP16 / 16, 0, 0});
       start += nt * tim * tjm;
-      red.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, nt, 0, 0, 0, 0});
+      red.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, nt, 0, 0, 0, 0, (int64_t)16 * NI * tim * v.DP16, 0, 0});
     }
     const int njobs_l = (int)jobs.size();
     St.njobs = njobs_l;
     St.tot_big = start;
     St.tot_thin = 0;
-    red.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0});
-    red.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0});
+    red.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0, (int64_t)Mw * v.DP16, 0, 0});
+    red.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
+    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
-    DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MM * sizeof(double), ctx->stream));
+    DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }

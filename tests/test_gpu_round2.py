@@ -316,3 +316,84 @@ def test_gemm_large_tile_kernel(ctx, tA, tB, m, n, k):
     ctx.sync()
     ref = 0.75 * (A.T if tA else A) @ (B.T if tB else B) - 1.25 * Cc
     assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
+
+
+# ---------------------------------------------------------------- full per-GPU shards of the 8-GPU configs (BASELINE configs[3], [4])
+def _shard_properties(model, X, Y, zs, S, n_layers, check_grad_perm=True):
+    """Size-independent properties of one full shard (the oracle would need minutes at these sizes):
+    bitwise determinism, row-permutation invariance of value AND gradient, estimator linearity over samples, linear data scale."""
+    rng = np.random.RandomState(0)
+    N = X.shape[0]
+    e1 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    g1 = model.engine().grad.cpu().numpy().copy()
+    e2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    g2 = model.engine().grad.cpu().numpy().copy()
+    assert np.isfinite(e1) and np.all(np.isfinite(g1))
+    assert e1 == e2 and np.array_equal(g1, g2)                          # fixed-order reductions only: bitwise deterministic
+    perm = rng.permutation(N)
+    zp = [z[:, perm, :] if z.shape[1] == N else z for z in zs]
+    e3 = model._build_likelihood(X[perm], Y[perm], zs=zp, with_grad=check_grad_perm)
+    assert_allclose(e3, e1, rtol=1e-10)
+    if check_grad_perm:                                                 # same rows in another order: the same gradient up to summation order
+        g3 = model.engine().grad.cpu().numpy()
+        assert np.max(np.abs(g3 - g1)) <= 1e-8 * np.max(np.abs(g1))
+    eng = model.engine()
+    o1 = eng.elbo(X, Y, S, zs=zs, data_scale=1.0, kl_weight=1.0)
+    o3 = eng.elbo(X, Y, S, zs=zs, data_scale=3.0, kl_weight=0.5)
+    assert_allclose(o3[1], 3.0 * o1[1], rtol=1e-13)                     # dgp.py:96-98: linear data scale
+    assert_allclose(o3[2], 0.5 * o1[2], rtol=1e-13)
+    assert_allclose(o3[0], o3[1] - o3[2], rtol=1e-12)
+    # mean over S of the single-sample data terms == the S-sample data term (rows are independent through all layers)
+    acc = [eng.elbo(X, Y, 1, zs=[z[s_:s_ + 1] if z.shape[0] == S else z for z in zs], data_scale=1.0, kl_weight=0.0)[1]
+           for s_ in range(S)]
+    assert_allclose(np.mean(acc), o1[1], rtol=1e-10)
+    return e1, g1
+
+
+def test_full_shard_cfg4_properties():
+    """configs[3]: MNIST-shaped 784 -> 30 -> 30 -> 10, M = 512, MultiClass(10), S = 10, minibatch 4096 over 8 GPUs = 512 rows
+    per GPU (the shard tools/bench_configs.py times: wide-input first layer at 512 rows, 8-wave M = 512 chains at 5120 rows)."""
+    rng = np.random.RandomState(60)
+    Ndata, N, S, M, K = 1200, 512, 10, 512, 10
+    Xall = rng.uniform(size=(Ndata, 784)) * (rng.uniform(size=(Ndata, 784)) < 0.19)
+    Yall = rng.randint(0, K, size=(Ndata, 1)).astype(np.float64)
+    Z = Xall[rng.permutation(Ndata)[:M]] + 0.01 * rng.randn(M, 784)
+    specs = [kern_spec("rbf", 784, 2.0, 2.0), kern_spec("rbf", 30, 2.0, 2.0), kern_spec("rbf", 30, 2.0, 2.0)]
+    spec, state, model = make_case(Xall, Yall, Z, specs, S=S, num_data=60000, num_classes=K, randomize=False)
+    X, Y = Xall[:N], Yall[:N]
+    zs = [rng.randn(S, N, 30), rng.randn(S, N, 30), rng.randn(S, N, K)]
+    _shard_properties(model, X, Y, zs, S, 3)
+    # the gradient is an ascent direction of the bound on this shard: one small sign-step of Adam (first step = lr * sign(g))
+    # raises it, by about lr * |g|_1
+    e0 = model.compute_log_likelihood(X, Y, zs=zs)
+    g1n = float(np.sum(np.abs(model.engine().grad.cpu().numpy())))
+    model.train_step(1e-6, X=X, Y=Y, zs=zs)
+    e1 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert e1 > e0 and (e1 - e0) < 2.0e-6 * g1n
+
+
+def test_full_shard_cfg5_properties_and_natgrad():
+    """configs[4]: 8 -> 8 -> 8 -> 1, M = 1024, S = 50, minibatch 1000 over 8 GPUs = 125 rows per GPU (16-wave M = 1024 chains at
+    6250 rows, multi-workgroup Cholesky, large-tile GEMMs) + a natural-gradient step on the last layer."""
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(61)
+    N, D, M, S = 125, 8, 1024, 50
+    Xall, Yall = rng.randn(2000, D), rng.randn(2000, 1)
+    Z = Xall[rng.permutation(2000)[:M]] + 0.05 * rng.randn(M, D)
+    spec, state, model = make_case(Xall, Yall, Z, [kern_spec("rbf", D)] * 3, S=S, num_data=7372, q_sqrt_scale=1e-5, lik_var=1.0)
+    X, Y = Xall[:N], Yall[:N]
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), np.zeros((1, 1, 1))]
+    e1, g1 = _shard_properties(model, X, Y, zs, S, 3)
+    # natural-gradient step with gamma = 1 on the (Gaussian-likelihood) last layer maximises the bound over its q(u):
+    # no other q(u) for that layer gives a higher value (tests/test_collapsed.py:57-104 is the 1-layer instance of this)
+    last = model.layers[-1]
+    NatGradOptimizer(1.0).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    e_opt = model.compute_log_likelihood(X, Y, zs=zs)
+    assert e_opt > e1
+    q_mu, q_sqrt = last.q_mu.read_value(), last.q_sqrt.read_value()
+    for _ in range(3):
+        last.q_mu = q_mu + 1e-3 * rng.randn(*q_mu.shape)
+        assert model.compute_log_likelihood(X, Y, zs=zs) < e_opt
+    last.q_mu = q_mu
+    last.q_sqrt = q_sqrt * (1.0 + 1e-3)
+    assert model.compute_log_likelihood(X, Y, zs=zs) < e_opt
