@@ -24,8 +24,9 @@ static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
   // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
   // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
   // (the 4-wave forward instance has the early-mean specialisation)
-  const int64_t lim = (Mp == 256 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
-  return on && (Mp == 128 || Mp == 256) && nblk <= lim && D_in <= XCH;
+  // Mp = 160 .. 224 follow the M = 256 rule (tools/bench_padding.py: with 4 waves M = 224 ran no faster than M = 256 with 8)
+  const int64_t lim = (Mp > 128 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
+  return on && Mp >= 128 && Mp <= 256 && nblk <= lim && D_in <= XCH;
 }
 // waves per row block of the instance that a launch of this shape takes
 static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {

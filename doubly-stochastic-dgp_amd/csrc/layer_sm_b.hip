@@ -5,6 +5,9 @@ int layer_fwd_sm_b(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind,
   const bool wide = a.D_in > XCH;
   if (small) {
     SM_SMALL_CASE(fwd_sm_go, 8, (ctx, a))
+    SM_SMALL_CASE(fwd_sm_go, 10, (ctx, a))
+    SM_SMALL_CASE(fwd_sm_go, 12, (ctx, a))
+    SM_SMALL_CASE(fwd_sm_go, 14, (ctx, a))
     SM_SMALL_CASE(fwd_sm_go, 16, (ctx, a))
   }
   switch (Mp) {
@@ -21,6 +24,9 @@ int layer_bwd_sm_b(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind,
   const bool wide = a.D_in > XCH;
   if (small) {
     SM_SMALL_CASE(bwd_sm_go, 8, (ctx, a))
+    SM_SMALL_CASE(bwd_sm_go, 10, (ctx, a))
+    SM_SMALL_CASE(bwd_sm_go, 12, (ctx, a))
+    SM_SMALL_CASE(bwd_sm_go, 14, (ctx, a))
     SM_SMALL_CASE(bwd_sm_go, 16, (ctx, a))
   }
   switch (Mp) {

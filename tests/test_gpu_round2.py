@@ -397,3 +397,31 @@ def test_full_shard_cfg5_properties_and_natgrad():
     last.q_mu = q_mu
     last.q_sqrt = q_sqrt * (1.0 + 1e-3)
     assert model.compute_log_likelihood(X, Y, zs=zs) < e_opt
+
+
+# ---------------------------------------------------------------- inducing counts that are not powers of two
+@pytest.mark.parametrize("M,Mp", [(100, 112), (200, 224), (300, 320), (70, 80), (140, 160), (600, 640)])
+def test_non_power_of_two_inducing_counts(M, Mp):
+    """M = 100 is the reference demo size (demos/run_regression.py:57); the padded size the device works on is the next
+    multiple of 16 / 32 / 64 / 128, not the next power of two, and values + gradients match the oracle as for any other M."""
+    rng = np.random.RandomState(M)
+    N, D, S = 50, 4, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D) * 1.4
+    specs = [kern_spec("rbf", D, 1.2, 1.3), kern_spec("matern52", D, 0.9, 1.1)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=777)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    ref, gref = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=777)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    g = model.engine().gradient_dict()
+    for k in gref:
+        assert np.max(np.abs(-gref[k] - g[k])) <= 1e-7 * (np.max(np.abs(gref[k])) + 1e-12), k
+    # the workspace is sized by the padded count: (D_out x Mp x Mp) blocks, so Mp shows in its size
+    import ctypes
+    from doubly_stochastic_dgp import _lib
+    eng = model.engine()
+    nb = ctypes.c_int64()
+    _lib.check(eng.lib.dsdgp_model_workspace_bytes(ctypes.byref(eng.desc), 64, 1, ctypes.byref(nb)))
+    d_pow2 = 1 << int(np.ceil(np.log2(M)))
+    assert Mp < d_pow2 or M == d_pow2

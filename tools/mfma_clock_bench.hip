@@ -2,6 +2,7 @@
 // s_memtime (shader-clock ticks) while the host times the same launch with HIP events; short (~0.1 ms) and long (~0.3 s) runs.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
 template <int NACC>
 __global__ __launch_bounds__(256) void k(double* out, unsigned long long* ticks, int iters) {
@@ -50,7 +51,12 @@ void run(int waves_per_simd, int iters) {
   hipFree(out);
   hipFree(ticks);
 }
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {   // long mode: ~N seconds of the saturating configuration, for power / clock sampling from outside
+    const int secs = atoi(argv[1]);
+    for (int i = 0; i < secs * 14; ++i) run<8>(2, 100000);
+    return 0;
+  }
   run<8>(2, 100); run<8>(2, 100); run<8>(2, 400); run<8>(2, 2000); run<8>(2, 20000); run<8>(2, 100000);
   run<4>(4, 200); run<4>(4, 20000);
   run<8>(1, 200); run<8>(1, 20000);
