@@ -195,11 +195,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # test rig only (validating the N > 1 code path on a 1-GPU box): DSDGP_BENCH_BACKEND=gloo + DSDGP_BENCH_ONE_DEVICE=1 put
+    # every rank on cuda:0 and stage the all-reduce through the host; the driver's runs use RCCL, one GPU per rank
+    backend = os.environ.get("DSDGP_BENCH_BACKEND", "nccl")
+    if os.environ.get("DSDGP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = dict(CFG)
     if args.scaling == "strong" and world > 1:
@@ -287,7 +295,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo = model.train_step(0.01, sync=True)
