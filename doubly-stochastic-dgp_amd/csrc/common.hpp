@@ -131,6 +131,40 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- [UPSTREAM] Bernoulli likelihood, probit link (/root/reference/tests/test_dgp.py:48-54 builds it; its variational
+// expectations are the base Likelihood's 20-point Gauss-Hermite rule, its predictions the probit closed form)
+// probit(x) = Phi(x) (1 - 2e-3) + 1e-3
+__device__ __forceinline__ double bern_probit(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)) * (1.0 - 2e-3) + 1e-3; }
+// log Bernoulli(y | p): y == 1 selects p, every other target 1 - p
+__device__ __forceinline__ double bern_logp(double p, double y) { return log(y == 1.0 ? p : 1.0 - p); }
+// variational expectation int log p(y | f) N(f | mu, v) df with np.polynomial.hermite.hermgauss(20) (weights / sqrt(pi));
+// dmu / dv = its derivatives.  No clamp on v: a negative variance gives NaN, as upstream's sqrt does.
+__device__ __forceinline__ double bern_var_exp(double mu, double v, double y, double* dmu, double* dv) {
+  constexpr double GX[10] = {0.24534070830090124, 0.7374737285453944, 1.234076215395323, 1.7385377121165861, 2.2549740020892757,
+                             2.7888060584281305, 3.3478545673832163, 3.944764040115625, 4.603682449550744, 5.387480890011233};
+  constexpr double GW[10] = {0.2607930634495549, 0.16173933398399998, 0.0615063720639769, 0.013997837447101022,
+                             0.00183010313108049, 0.00012882627996192928, 4.402121090230851e-06, 6.127490259982928e-08,
+                             2.4820623623151755e-10, 1.2578006724379234e-13};
+  const double sd = sqrt(2.0 * v);
+  const double sgn = (y == 1.0) ? 1.0 : -1.0;
+  double ve = 0.0, gm = 0.0, gv = 0.0;
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    const double x = (k < 10) ? -GX[9 - k] : GX[k - 10];
+    const double w = (k < 10) ? GW[9 - k] : GW[k - 10];
+    const double f = mu + sd * x;
+    const double p = bern_probit(f);
+    const double q = (y == 1.0) ? p : 1.0 - p;
+    ve += w * log(q);
+    const double dl = sgn * (1.0 - 2e-3) * 0.39894228040143267794 * exp(-0.5 * f * f) / q;      // d log q / d f
+    gm += w * dl;
+    gv += w * dl * x;
+  }
+  *dmu = gm;
+  *dv = gv / sd;
+  return ve;
+}
+
 // sum over the four 16-lane groups (same c): afterwards every lane holds the total for its column c.
 __device__ __forceinline__ double sum_groups(double x) {
   x += __shfl_xor(x, 16, 64);

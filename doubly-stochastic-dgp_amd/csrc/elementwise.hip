@@ -91,6 +91,61 @@ extern "C" int dsdgp_gauss_predict_density(dsdgp_ctx* ctx, const double* mean, c
   return gauss_over_samples(ctx, mean, var, Y, n, S, DY, lik_var, 1, nullptr, out);
 }
 
+// ---- Bernoulli (probit) through BroadcastingLikelihood: mode 0 mean_s variational expectation, mode 1 logmeanexp_s density
+__global__ void k_bern_over_samples(const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ Y,
+                                    int64_t n, int S, int DY, int mode, const double* __restrict__ sw, double* __restrict__ out) {
+  const int64_t total = n * DY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const double y = Y[i];
+    if (mode == 0) {
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        double dm, dv;
+        const double ve = bern_var_exp(mean[(int64_t)s * total + i], var[(int64_t)s * total + i], y, &dm, &dv);
+        acc += sw ? sw[s] * ve : ve;
+      }
+      out[i] = sw ? acc : acc / S;
+    } else {
+      double mx = -1.0 / 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double l = bern_logp(bern_probit(mean[(int64_t)s * total + i] / sqrt(1.0 + var[(int64_t)s * total + i])), y);
+        mx = l > mx ? l : mx;
+      }
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double l = bern_logp(bern_probit(mean[(int64_t)s * total + i] / sqrt(1.0 + var[(int64_t)s * total + i])), y);
+        acc += exp(l - mx);
+      }
+      out[i] = mx + log(acc) - log((double)S);
+    }
+  }
+}
+extern "C" int dsdgp_bernoulli_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n,
+                                       int32_t S, int32_t DY, int mode, const double* sample_w, double* out) {
+  DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && (mode == 0 || mode == 1));
+  DS_CHECK_ARG(mode == 0 || !sample_w);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
+  hipLaunchKernelGGL(k_bern_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, mode, sample_w, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+__global__ void k_bern_predict(const double* __restrict__ mean, const double* __restrict__ var, int64_t count,
+                               double* __restrict__ om, double* __restrict__ ov) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const double p = bern_probit(mean[i] / sqrt(1.0 + var[i]));
+    om[i] = p;
+    ov[i] = p - p * p;
+  }
+}
+extern "C" int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t count, double* out_mean,
+                                       double* out_var) {
+  DS_CHECK_ARG(ctx && mean && var && out_mean && out_var && count > 0);
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
+  hipLaunchKernelGGL(k_bern_predict, dim3(nb), dim3(256), 0, ctx->stream, mean, var, count, out_mean, out_var);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
 __global__ void k_add_scalar(const double* __restrict__ in, double v, int64_t count, double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = in[i] + v;

@@ -519,6 +519,43 @@ __global__ __launch_bounds__(256) void k_lik_gauss(const double* __restrict__ me
   }
 }
 
+// [UPSTREAM] Bernoulli (probit) variational expectations and their adjoints w.r.t. the last layer's mean / var; same outputs as
+// k_lik_gauss (the likelihood has no parameter: the second partial is zero)
+__global__ __launch_bounds__(256) void k_lik_bern(const double* __restrict__ mean, const double* __restrict__ var,
+                                                  const double* __restrict__ Y, int64_t n, int S, int DY, double w,
+                                                  const double* __restrict__ sw, double* __restrict__ part,
+                                                  double* __restrict__ dmean, double* __restrict__ dvar,
+                                                  double* __restrict__ MBt, double* __restrict__ VBt, int64_t ldt) {
+  __shared__ double sh[4];
+  const int64_t total = (int64_t)S * n * DY;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double ve = 0.0;
+  if (idx < total) {
+    const int64_t row = idx / DY;
+    const int dd = (int)(idx % DY);
+    const double y = Y[(row % n) * DY + dd];
+    const double f = sw ? sw[row / n] * S : 1.0;
+    double dm, dv;
+    ve = f * bern_var_exp(mean[idx], var[idx], y, &dm, &dv);
+    if (dmean) {
+      dmean[idx] = -w * f * dm;
+      dvar[idx] = -w * f * dv;
+    }
+    if (MBt) {
+      MBt[(int64_t)dd * ldt + row] = -w * f * dm;
+      VBt[(int64_t)dd * ldt + row] = -w * f * dv;
+    }
+  } else if (MBt && idx < ldt * DY) {      // rows of the 16-row padding
+    MBt[(idx % DY) * ldt + idx / DY] = 0.0;
+    VBt[(idx % DY) * ldt + idx / DY] = 0.0;
+  }
+  const double a = block_sum_256(ve, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
 // per-sample quadrature weights applied to per-row values (R = S*n rows) and the (R x K) adjoints (MultiClass + DGP_Quad)
 __global__ void k_scale_by_sample(const double* __restrict__ sw, int64_t n, int S, int K, int64_t R, double* __restrict__ ve,
                                   double* __restrict__ dmean, double* __restrict__ dvar) {
@@ -978,7 +1015,7 @@ __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ gr
 // ------------------------------------------------------------------------------------------------------
 static int validate_desc(const dsdgp_model_desc* d) {
   DS_CHECK_ARG(d && d->L >= 1 && d->L <= DSDGP_MAX_LAYERS && d->n_theta > 0);
-  DS_CHECK_ARG(d->lik_kind == DSDGP_LIK_GAUSSIAN || d->lik_kind == DSDGP_LIK_MULTICLASS);
+  DS_CHECK_ARG(d->lik_kind == DSDGP_LIK_GAUSSIAN || d->lik_kind == DSDGP_LIK_MULTICLASS || d->lik_kind == DSDGP_LIK_BERNOULLI);
   for (int l = 0; l < d->L; ++l) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
@@ -1604,14 +1641,21 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   const double w = data_scale / (double)S;
   // the last layer of a deep model has one output row per input row: its transposed adjoints come straight from the
   // likelihood kernel (no k_adj_prep launch on the critical path)
-  m->fused_last = with_grad && L > 1 && sm_chain_enabled() && m->desc.lik_kind == DSDGP_LIK_GAUSSIAN;
-  if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN) {
+  const bool elementwise = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN || m->desc.lik_kind == DSDGP_LIK_BERNOULLI;
+  m->fused_last = with_grad && L > 1 && sm_chain_enabled() && elementwise;
+  if (elementwise) {
     const int64_t ldt = round_up((int64_t)S * n, 16);
     if (m->fused_last) nblocks = ceil_div(ldt * DY, 256);
-    hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
-                       w, m->sample_w, m->lik_part, (with_grad && !m->fused_last) ? m->lik_dmean : nullptr,
-                       (with_grad && !m->fused_last) ? m->lik_dvar : nullptr, m->fused_last ? last.MB : nullptr,
-                       m->fused_last ? last.VB : nullptr, ldt);
+    double* dm = (with_grad && !m->fused_last) ? m->lik_dmean : nullptr;
+    double* dv = (with_grad && !m->fused_last) ? m->lik_dvar : nullptr;
+    double* mbt = m->fused_last ? last.MB : nullptr;
+    double* vbt = m->fused_last ? last.VB : nullptr;
+    if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN)
+      hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
+                         w, m->sample_w, m->lik_part, dm, dv, mbt, vbt, ldt);
+    else
+      hipLaunchKernelGGL(k_lik_bern, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, w, m->sample_w,
+                         m->lik_part, dm, dv, mbt, vbt, ldt);
   } else {
     // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
     DS_CHECK_ARG(DY == m->desc.num_classes);

@@ -10,7 +10,7 @@ _LIB_PATH = os.environ.get("DSDGP_LIB_PATH") or os.path.join(os.path.dirname(_HE
 DSDGP_MAX_LAYERS = 16
 KERN_RBF, KERN_MATERN52 = 0, 1
 MEAN_ZERO, MEAN_IDENTITY, MEAN_LINEAR = 0, 1, 2
-LIK_GAUSSIAN, LIK_MULTICLASS = 0, 1
+LIK_GAUSSIAN, LIK_MULTICLASS, LIK_BERNOULLI = 0, 1, 2
 ERR_NOT_SPD = -2
 ERR_RCCL = -6
 
@@ -100,6 +100,9 @@ _PROTOS = {
     "dsdgp_multiclass_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int, C.c_void_p, C.c_void_p]),
     "dsdgp_multiclass_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dsdgp_bernoulli_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int, C.c_void_p, C.c_void_p]),
+    "dsdgp_bernoulli_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dsdgp_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
 }
 

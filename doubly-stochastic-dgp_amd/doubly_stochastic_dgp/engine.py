@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, settings
-from .gpflow_compat import (Gaussian, MultiClass, Parameter, positive_backward, positive_forward, split_kernel)
+from .gpflow_compat import (Bernoulli, Gaussian, MultiClass, Parameter, positive_backward, positive_forward, split_kernel)
 
 _KIND = {"rbf": _lib.KERN_RBF, "matern52": _lib.KERN_MATERN52}
 _MEAN = {"zero": _lib.MEAN_ZERO, "identity": _lib.MEAN_IDENTITY, "linear": _lib.MEAN_LINEAR}
@@ -166,6 +166,9 @@ class Engine:
         elif isinstance(self.likelihood, MultiClass):
             d.lik_kind = _lib.LIK_MULTICLASS
             d.num_classes = self.likelihood.num_classes
+            d.off_lik_var = -1
+        elif isinstance(self.likelihood, Bernoulli):
+            d.lik_kind = _lib.LIK_BERNOULLI
             d.off_lik_var = -1
         else:
             raise NotImplementedError(type(self.likelihood).__name__)

@@ -232,6 +232,16 @@ class MultiClass(Likelihood):
         self.epsilon = 1e-3
 
 
+class Bernoulli(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.Bernoulli() with the probit link (/root/reference/tests/test_dgp.py:48-54): targets 1 select
+    p = probit(f), every other value (the test draws -1 / 1) 1 - p; no parameters."""
+    kind = "bernoulli"
+
+    def __init__(self, invlink=None):
+        if invlink is not None:
+            raise NotImplementedError("only the default probit link is on the built path")
+
+
 class InducingPoints(Parameterized):
     """[UPSTREAM] gpflow.features.InducingPoints — holder of Z (layers.py:153)."""
 

@@ -49,11 +49,12 @@ class BroadcastingLikelihood:
 
     def __init__(self, likelihood):
         self.likelihood = likelihood
-        from .gpflow_compat import Gaussian, MultiClass
+        from .gpflow_compat import Bernoulli, Gaussian, MultiClass
         self.needs_broadcasting = not isinstance(likelihood, Gaussian)
-        if not isinstance(likelihood, (Gaussian, MultiClass)):
+        self.bernoulli = isinstance(likelihood, Bernoulli)
+        if not isinstance(likelihood, (Gaussian, MultiClass, Bernoulli)):
             raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
-                                      "(Gaussian, MultiClass are)")
+                                      "(Gaussian, MultiClass, Bernoulli are)")
 
     def check_targets(self, Y):
         """MultiClass: Y must hold integer class labels in [0, num_classes) — the device kernel indexes its per-class
@@ -61,6 +62,11 @@ class BroadcastingLikelihood:
         if not self.needs_broadcasting:
             return
         Y = np.asarray(Y, dtype=np.float64)
+        if self.bernoulli:
+            # [UPSTREAM] tf.where(tf.equal(Y, 1), p, 1 - p): any finite target is accepted (the reference test draws -1 / 1)
+            if Y.ndim != 2 or not np.all(np.isfinite(Y)):
+                raise ValueError(f"Bernoulli targets must be a finite (N, D) array, got shape {Y.shape}")
+            return
         K = self.likelihood.num_classes
         if Y.ndim != 2 or Y.shape[1] != 1:
             raise ValueError(f"MultiClass targets must have shape (N, 1) with labels in [0, {K}), got {Y.shape}")
@@ -88,6 +94,9 @@ class BroadcastingLikelihood:
                 _lib.check(ctx.lib.dsdgp_gauss_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, lv, wp, ptr(out)))
             else:
                 _lib.check(ctx.lib.dsdgp_gauss_predict_density(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, lv, ptr(out)))
+        elif self.bernoulli:
+            out = ctx.empty(N, D)
+            _lib.check(ctx.lib.dsdgp_bernoulli_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
         else:
             out = ctx.empty(N, 1)
             _lib.check(ctx.lib.dsdgp_multiclass_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
@@ -118,6 +127,10 @@ class BroadcastingLikelihood:
         S, N, K = Fmu.shape
         m = ctx.to_device(Fmu)
         om, ov = ctx.empty(S, N, K), ctx.empty(S, N, K)
+        if self.bernoulli:
+            _lib.check(ctx.lib.dsdgp_bernoulli_predict(ctx.handle, ptr(m), ptr(v), S * N * K, ptr(om), ptr(ov)))
+            ctx.sync()
+            return om.cpu().numpy(), ov.cpu().numpy()
         _lib.check(ctx.lib.dsdgp_multiclass_predict(ctx.handle, ptr(m), ptr(v), S * N, K, ptr(om), ptr(ov)))
         ctx.sync()
         return om.cpu().numpy(), ov.cpu().numpy()

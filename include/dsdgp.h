@@ -41,7 +41,8 @@ typedef enum {
 
 enum { DSDGP_KERN_RBF = 0, DSDGP_KERN_MATERN52 = 1 };            /* [UPSTREAM] gpflow.kernels */
 enum { DSDGP_MEAN_ZERO = 0, DSDGP_MEAN_IDENTITY = 1, DSDGP_MEAN_LINEAR = 2 }; /* layer_initializations.py:30-42,51 */
-enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1 };       /* dgp.py:57, utils.py:54-93 */
+enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1, DSDGP_LIK_BERNOULLI = 2 };   /* dgp.py:57, utils.py:54-93,
+                                                                                       * tests/test_dgp.py:48-54 */
 
 #define DSDGP_MAX_LAYERS 16
 
@@ -231,6 +232,16 @@ int dsdgp_multiclass_var_exp(dsdgp_ctx* ctx, const double* mean, const double* v
 /* MultiClass.predict_mean_and_var: out_mean[r,k] = predictive class probability, out_var = p - p^2; R rows. */
 int dsdgp_multiclass_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t R, int32_t K, double* out_mean,
                              double* out_var);
+
+/* [UPSTREAM] Bernoulli() (probit link, 20-point Gauss-Hermite variational expectations) through BroadcastingLikelihood
+ * (utils.py:76-86; exercised by /root/reference/tests/test_dgp.py:48-54).  Targets: 1 selects p, anything else 1 - p.
+ * mode 0: out[i,d] = mean_s (or sum_s sample_w[s]) variational expectation ; mode 1: out[i,d] = logsumexp_s log density - log S.
+ * mean/var: (S x n x DY); Y, out: (n x DY). */
+int dsdgp_bernoulli_var_exp(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int32_t S,
+                            int32_t DY, int mode, const double* sample_w, double* out);
+/* Bernoulli.predict_mean_and_var (probit closed form): out_mean = probit(mean / sqrt(1 + var)), out_var = p - p^2. */
+int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t count, double* out_mean,
+                            double* out_var);
 
 /* out = in + value (Gaussian.predict_mean_and_var adds the noise variance, dgp.py:116-119). */
 int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out);

@@ -367,6 +367,50 @@ class MultiClass:
         return ps, ps - ps ** 2
 
 
+class Bernoulli:
+    """[UPSTREAM] gpflow 1.1.1 Bernoulli() as /root/reference/tests/test_dgp.py:48-54 builds it: probit link
+    p(f) = Phi(f) (1 - 2e-3) + 1e-3, log-density log(p if y == 1 else 1 - p); variational expectations by the base
+    Likelihood's 20-point Gauss-Hermite rule (X = mu + sqrt(2 var) x, weights / sqrt(pi)); predict_mean_and_var in the
+    probit closed form p = probit(mu / sqrt(1 + var)), var = p - p^2; predict_density = log-density at that p.
+    BroadcastingLikelihood (utils.py:76-86) flattens to (S*N, D) with Y tiled — elementwise, so shapes are kept here."""
+    kind = "bernoulli"
+
+    def __init__(self, num_gauss_hermite_points=20):
+        self.H = num_gauss_hermite_points
+
+    @staticmethod
+    def _probit(xp, x):
+        return 0.5 * (1.0 + xp.erf(x / math.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+
+    @staticmethod
+    def _one(xp, Y, like):
+        """1.0 where the target equals 1 ([UPSTREAM] tf.equal(Y, 1)), broadcast over the leading sample axis of `like`"""
+        y = np.asarray(Y.detach().numpy() if hasattr(Y, "detach") else Y, dtype=np.float64)
+        return xp.asarray(np.broadcast_to((y == 1.0).astype(np.float64), tuple(like.shape)).copy())
+
+    @staticmethod
+    def _logp(xp, p, one):
+        return xp.log(one * p + (1.0 - one) * (1.0 - p))
+
+    def variational_expectations(self, xp, Fmu, Fvar, Y):
+        gh_x, gh_w = np.polynomial.hermite.hermgauss(self.H)
+        gh_w = gh_w / math.sqrt(math.pi)
+        one = self._one(xp, Y, Fmu)
+        out = 0.0
+        for x, w in zip(gh_x, gh_w):
+            F = Fmu + xp.sqrt(2.0 * Fvar) * float(x)
+            out = out + float(w) * self._logp(xp, self._probit(xp, F), one)
+        return out
+
+    def predict_mean_and_var(self, xp, Fmu, Fvar):
+        p = self._probit(xp, Fmu / xp.sqrt(1.0 + Fvar))
+        return p, p - p ** 2
+
+    def predict_density(self, xp, Fmu, Fvar, Y):
+        p = self.predict_mean_and_var(xp, Fmu, Fvar)[0]
+        return self._logp(xp, p, self._one(xp, Y, p))
+
+
 # --------------------------------------------------------------------------------------------------
 # dgp.py:42-126  DGP_Base
 # --------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 A model is described by a plain ``spec`` dict and a ``state`` dict of *unconstrained* numpy arrays (the
 free variables GPflow would optimise):
 
-spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass", "num_classes": K,
+spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass"|"bernoulli", "num_classes": K,
          "layers": [{"kind": "rbf"|"matern52", "input_dim": D_in, "ARD": bool, "has_white": bool,
                      "mean": "zero"|"identity"|"linear", "mean_A": ndarray|None}, ...]}
 state = {"l{i}.Z": (M,D_in), "l{i}.q_mu": (M,D_out), "l{i}.q_sqrt": (D_out,M,M)  [tril part is the free var],
@@ -68,6 +68,8 @@ def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
                                   input_prop_dim=ls.get("input_prop_dim")))
     if spec["likelihood"] == "gaussian":
         lik = O.Gaussian(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
+    elif spec["likelihood"] == "bernoulli":
+        lik = O.Bernoulli()
     else:
         lik = O.MultiClass(spec["num_classes"])
     return O.DGPOracle(layers, lik, num_samples=num_samples, num_data=num_data, sample_weights=sample_weights)

@@ -425,3 +425,76 @@ def test_non_power_of_two_inducing_counts(M, Mp):
     _lib.check(eng.lib.dsdgp_model_workspace_bytes(ctypes.byref(eng.desc), 64, 1, ctypes.byref(nb)))
     d_pow2 = 1 << int(np.ceil(np.log2(M)))
     assert Mp < d_pow2 or M == d_pow2
+
+
+# ---------------------------------------------------------------- Bernoulli likelihood (reference tests/test_dgp.py:48-54)
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("white", [True, False])
+def test_bernoulli_elbo_gradients_and_predictions(L, white):
+    """Shapes of the reference's test_bernoulli (Y in {-1, 1}, L = 1 and 2, white=True there; white=False added): ELBO and every
+    gradient block vs the oracle's torch autograd, E_log_p_Y, predict_density, predict_y."""
+    from tests.test_gpu_parity import _grad_check
+    rng = np.random.RandomState(48 + L)
+    N, D, M, S, DY = 50, 2, 19, 3, 2
+    X = rng.uniform(size=(N, D))
+    Y = rng.choice([-1.0, 1.0], N * DY).reshape(N, DY)
+    Z = X[:M].copy()
+    specs = [kern_spec("matern52", D, 1.0, 0.5, white_variance=0.01) for _ in range(L)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=200, bernoulli=True)
+    widths = [D] * (L - 1) + [DY]
+    zs = [rng.randn(S, N, w) for w in widths]
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=200)
+    om = OM.build(O.NP, spec, state, S, 200)
+    assert_allclose(model.E_log_p_Y(X, Y, zs=zs), om.E_log_p_Y(O.NP, X, Y, zs), rtol=1e-10, atol=1e-12)
+    _, Fm, Fv = om.propagate(O.NP, X, zs, S=S)
+    m, v = model._build_predict(X, S=S, zs=zs)
+    assert_allclose(model.likelihood.predict_density_logmeanexp(m, v, Y), om.predict_density(O.NP, X, Y, zs, S), rtol=1e-10,
+                    atol=1e-12)
+    pm, pv = model.likelihood.predict_mean_and_var(m, v)
+    rm, rv = om.likelihood.predict_mean_and_var(O.NP, Fm[-1], Fv[-1])
+    assert_allclose(pm, rm, rtol=1e-12, atol=1e-14)
+    assert_allclose(pv, rv, rtol=1e-10, atol=1e-14)
+    assert np.all(pm > 1e-3 - 1e-12) and np.all(pm < 1 - 1e-3 + 1e-12)       # probit's 1e-3 floor / ceiling
+
+
+def test_bernoulli_var_exp_primitive_and_edge_targets():
+    """dsdgp_bernoulli_var_exp vs the oracle: targets 1 select p, every other value (0, -1, 2.5) 1 - p; quadrature weights
+    replace the mean over S; a negative variance gives NaN as upstream's sqrt does."""
+    from doubly_stochastic_dgp.gpflow_compat import Bernoulli
+    from doubly_stochastic_dgp.utils import BroadcastingLikelihood
+    rng = np.random.RandomState(3)
+    S, N, D = 4, 37, 3
+    mu, var = 2.0 * rng.randn(S, N, D), rng.uniform(1e-6, 4.0, size=(S, N, D))
+    Y = rng.choice([1.0, 0.0, -1.0, 2.5], N * D).reshape(N, D)
+    lik, ol = BroadcastingLikelihood(Bernoulli()), O.Bernoulli()
+    ve = ol.variational_expectations(O.NP, mu, var, Y)
+    assert_allclose(lik.variational_expectations_mean(mu, var, Y), ve.mean(0), rtol=1e-12, atol=1e-14)
+    w = rng.uniform(size=S)
+    assert_allclose(lik.variational_expectations_mean(mu, var, Y, weights=w), (ve * w[:, None, None]).sum(0), rtol=1e-12, atol=1e-14)
+    from scipy.special import logsumexp
+    assert_allclose(lik.predict_density_logmeanexp(mu, var, Y), logsumexp(ol.predict_density(O.NP, mu, var, Y), axis=0) - np.log(S),
+                    rtol=1e-12, atol=1e-14)
+    bad = var.copy()
+    bad[1, 5, 2] = -0.1
+    out = lik.variational_expectations_mean(mu, bad, Y)
+    assert np.isnan(out[5, 2]) and np.isfinite(np.delete(out.ravel(), 5 * D + 2)).all()
+
+
+def test_bernoulli_training_decreases_loss_and_classifies():
+    """Two-layer Bernoulli DGP on a separable toy problem: 200 Adam steps raise the ELBO and the predictive mean separates the
+    classes (an end-to-end run of the path the reference exercises only through compare_to_single_layer)."""
+    from doubly_stochastic_dgp.dgp import DGP
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Bernoulli
+    rng = np.random.RandomState(0)
+    N = 200
+    X = rng.uniform(-2, 2, size=(N, 2))
+    Y = np.where(X[:, :1] * X[:, 1:] > 0, 1.0, -1.0)
+    model = DGP(X, Y, X[:20].copy(), [RBF(2, lengthscales=1.0), RBF(2, lengthscales=1.0)], Bernoulli(), num_samples=5)
+    e0 = np.mean([model.compute_log_likelihood() for _ in range(5)])
+    for _ in range(300):
+        model.train_step(0.02)
+    e1 = np.mean([model.compute_log_likelihood() for _ in range(5)])
+    assert e1 > e0 + 10.0
+    p, _ = model.predict_y(X, 20)
+    acc = np.mean((p.mean(0) > 0.5) == (Y == 1.0))
+    assert acc > 0.9

@@ -171,3 +171,16 @@ def test_multiclass_targets_are_validated():
         with pytest.raises(ValueError):
             lik.check_targets(bad)
     BroadcastingLikelihood(Gaussian()).check_targets(np.array([[0.3, -7.0]]))   # real-valued targets: nothing to check
+
+
+def test_bernoulli_is_a_built_likelihood():
+    """Bernoulli() (tests/test_dgp.py:48-54 of the reference) is accepted; its targets only need to be finite (N, D)."""
+    from doubly_stochastic_dgp.gpflow_compat import Bernoulli
+    from doubly_stochastic_dgp.utils import BroadcastingLikelihood
+    lik = BroadcastingLikelihood(Bernoulli())
+    assert lik.needs_broadcasting and lik.bernoulli
+    lik.check_targets(np.array([[-1.0], [1.0], [0.0]]))
+    with pytest.raises(ValueError):
+        lik.check_targets(np.array([[np.nan]]))
+    with pytest.raises(NotImplementedError):
+        Bernoulli(invlink="logit")

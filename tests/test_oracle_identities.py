@@ -396,3 +396,72 @@ def test_trainable_linear_mean_restatement():
         sp[k], sm[k] = state[k] + e, state[k] - e
         fd = (OM.elbo(spec, sp, X, Y, zs, S) - OM.elbo(spec, sm, X, Y, zs, S)) / 2e-6
         assert abs(fd - g[k][idx]) <= 1e-6 * max(1.0, abs(fd)), (k, fd, g[k][idx])
+
+
+def test_T12_bernoulli_probit_restatement():
+    """Oracle Bernoulli (gpflow 1.1.1 Bernoulli() of /root/reference/tests/test_dgp.py:48-54): (a) the 20-point Gauss-Hermite
+    variational expectation written the way upstream does — (R x H) log-densities times the (H x 1) weights — equals the oracle's
+    loop; (b) it agrees with adaptive quadrature of log p(y|f) N(f|mu, var) to the rule's accuracy; (c) predict_mean_and_var is
+    the probit closed form, whose mean agrees with adaptive quadrature of probit(f) N(f|mu, var)."""
+    from scipy import integrate, special
+    rng = np.random.RandomState(12)
+    S, N, D = 2, 7, 2
+    mu, var = rng.randn(S, N, D), rng.uniform(0.05, 1.5, size=(S, N, D))
+    Y = rng.choice([-1.0, 1.0], N * D).reshape(N, D)
+    lik = O.Bernoulli()
+    ve = lik.variational_expectations(O.NP, mu, var, Y)
+    assert ve.shape == (S, N, D)
+    # (a) upstream's matmul form
+    gx, gw = np.polynomial.hermite.hermgauss(20)
+    Xq = gx[None, :] * np.sqrt(2.0 * var.reshape(-1, 1)) + mu.reshape(-1, 1)
+    p = 0.5 * (1.0 + special.erf(Xq / np.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+    Yt = np.tile(np.broadcast_to(Y, (S, N, D)).reshape(-1, 1), (1, 20))
+    logp = np.log(np.where(Yt == 1, p, 1 - p))
+    assert_allclose(ve.reshape(-1, 1), logp @ (gw.reshape(-1, 1) / np.sqrt(np.pi)), rtol=1e-13)
+
+    # (b), (c) adaptive quadrature on a few entries
+    def probit(f):
+        return 0.5 * (1.0 + special.erf(f / np.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+    pm, pv = lik.predict_mean_and_var(O.NP, mu, var)
+    assert_allclose(pv, pm - pm ** 2, rtol=1e-14)
+    for idx in [(0, 0, 0), (1, 3, 1), (0, 6, 1)]:
+        m0, v0, y0 = mu[idx], var[idx], Y[idx[1], idx[2]]
+        pdf = lambda f: np.exp(-0.5 * (f - m0) ** 2 / v0) / np.sqrt(2 * np.pi * v0)
+        q = integrate.quad(lambda f: np.log(probit(f) if y0 == 1 else 1 - probit(f)) * pdf(f), m0 - 12 * np.sqrt(v0),
+                           m0 + 12 * np.sqrt(v0), epsabs=1e-12)[0]
+        assert abs(ve[idx] - q) < 1e-6
+        qm = integrate.quad(lambda f: probit(f) * pdf(f), m0 - 12 * np.sqrt(v0), m0 + 12 * np.sqrt(v0), epsabs=1e-12)[0]
+        assert abs(pm[idx] - qm) < 1e-9        # E[Phi(f)] = Phi(mu / sqrt(1 + var)) exactly; the 1e-3 mixing is linear
+    # predict_density: log-density at the predictive mean, targets other than 1 select 1 - p
+    pd = lik.predict_density(O.NP, mu, var, Y)
+    assert_allclose(pd, np.log(np.where(np.broadcast_to(Y, pm.shape) == 1, pm, 1 - pm)), rtol=1e-14)
+
+
+def test_bernoulli_single_layer_elbo_and_torch_gradient():
+    """One-layer DGP with the Bernoulli likelihood (the L = 1 case of tests/test_dgp.py:48-54): numpy and torch backends agree
+    and the torch gradient of the ELBO w.r.t. q_mu matches a central difference."""
+    import torch
+    from tests.helpers import kern_spec
+    rng = np.random.RandomState(5)
+    N, D, M, S = 20, 2, 7, 3
+    X = rng.uniform(size=(N, D))
+    Y = rng.choice([-1.0, 1.0], N).reshape(N, 1)
+    lds = O.init_layers_linear(X, Y, X[:M].copy(), [kern_spec("rbf", D, 1.0, 0.7)], white=True)
+    lds[0]["q_mu"] = 0.3 * rng.randn(*lds[0]["q_mu"].shape)
+    sl, state = OM.state_from_layers(lds, likelihood="bernoulli")
+    spec = dict(jitter=1e-6, white=True, likelihood="bernoulli", layers=sl, num_classes=None)
+    zs = [rng.randn(S, N, 1)]
+    e = OM.elbo(spec, state, X, Y, zs, S, num_data=50)
+    assert np.isfinite(e)
+    st = {k: torch.tensor(v, dtype=torch.float64, requires_grad=(k == "l0.q_mu")) for k, v in state.items()}
+    et = OM.build(O.TH, spec, st, S, 50).build_likelihood(O.TH, torch.tensor(X), torch.tensor(Y), [torch.tensor(z) for z in zs])
+    assert abs(float(et) - e) < 1e-10 * max(1.0, abs(e))
+    et.backward()
+    g = st["l0.q_mu"].grad.numpy()
+    h = 1e-6
+    for i in (0, 3):
+        sp, sm = dict(state), dict(state)
+        sp["l0.q_mu"] = state["l0.q_mu"].copy(); sp["l0.q_mu"][i, 0] += h
+        sm["l0.q_mu"] = state["l0.q_mu"].copy(); sm["l0.q_mu"][i, 0] -= h
+        fd = (OM.elbo(spec, sp, X, Y, zs, S, num_data=50) - OM.elbo(spec, sm, X, Y, zs, S, num_data=50)) / (2 * h)
+        assert abs(fd - g[i, 0]) < 1e-6 * max(1.0, abs(fd))
