@@ -28,6 +28,9 @@ CASES = {
     # MultiClass(3) / RobustMax likelihood, three layers (demo_mnist.ipynb:99-104 in miniature)
     "multiclass": dict(N=24, D=2, DY=1, M=10, S=2, L=3, kind="rbf", ls=1.1, var=2.0, white=False, lik=None, jitter=1e-6,
                        seed=6, num_data=100, zx=False, classes=3),
+    # Bernoulli() likelihood, targets in {-1, 1}, two whitened layers: tests/test_dgp.py:48-54 (N=19, D_X=2, D_Y=3, Z=X)
+    "bernoulli": dict(N=19, D=2, DY=3, M=19, S=2, L=2, kind="matern52", ls=0.5, var=1.0, white=True, lik=None, jitter=1e-6,
+                      seed=7, num_data=None, zx=True, bernoulli=True),
 }
 
 
@@ -40,6 +43,8 @@ def inputs(name):
     Z = X.copy() if c["zx"] else rng.randn(M, D) * 1.2
     if c.get("classes"):
         Y = rng.randint(0, c["classes"], size=(N, 1)).astype(np.float64)
+    if c.get("bernoulli"):
+        Y = rng.choice([-1.0, 1.0], N * c["DY"]).reshape(N, c["DY"])
     kdims = c.get("dims") or [D] * L                       # kernel input dims per layer (step-down cases)
     specs = []
     for d in kdims:
@@ -58,5 +63,5 @@ def build(name):
     c, X, Y, Z, specs, zs = inputs(name)
     spec, state, model = make_case(X, Y, Z, specs, white=c["white"], jitter=c["jitter"], lik_var=c["lik"] or 1.0, S=c["S"],
                                    num_data=c["num_data"], seed=c["seed"], q_sqrt_scale=c.get("demo_scale"),
-                                   num_classes=c.get("classes"))
+                                   num_classes=c.get("classes"), bernoulli=bool(c.get("bernoulli")))
     return spec, state, model, X, Y, zs, c

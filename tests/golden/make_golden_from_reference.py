@@ -84,6 +84,8 @@ def reference_outputs(name, gpflow, tf, ref_dgp):
             kerns.append(k)
         if c.get("classes"):
             lik = gpflow.likelihoods.MultiClass(c["classes"])
+        elif c.get("bernoulli"):
+            lik = gpflow.likelihoods.Bernoulli()
         else:
             lik = gpflow.likelihoods.Gaussian()
             lik.variance = float(O.positive_forward(O.NP, state["lik_variance_raw"]))
