@@ -582,13 +582,19 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           if (Own<MPB, NW>::skip(ib)) continue;
+          // y_d = S_d a, then abar += 2 vbar_d y_d (four FMAs per output).  The earlier form scaled the B operand instead
+          // (one v_mul_f64 per MFMA): fp64 VALU work competes with the fp64 MFMAs — that multiply alone cost 16 % of the
+          // loop (tools/chain_loop_bench.hip: 113 -> 95 us at the D_out = 8 launch of config 2).
           const double* __restrict__ W = Sd + 16 * ib + c + (int64_t)g * Mp;
+          d4 y = (d4){0, 0, 0, 0};
 #pragma unroll 4
           for (int kb = 0; kb < MPB; ++kb) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              acc[q] = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c] * vd2, acc[q]);
+              y = mfma_f64(W[(int64_t)(16 * kb + 4 * s) * Mp], actb[(16 * kb + 4 * s + g) * 16 + c], y);
           }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[q][t] = fma(vd2, y[t], acc[q][t]);
         }
       }
     }

@@ -167,6 +167,72 @@ __global__ __launch_bounds__(512, 4) void k_fast(const double* __restrict__ S, d
   out[(size_t)blockIdx.x * 512 + tid] = racc[0] + racc[1] + racc[2] + racc[3];
 }
 
+
+// ---- variants of the committed form (what is the 30 % between the full loop and the MFMAs alone made of?)
+//   VAR 1: no per-product v_mul_f64 (y_d accumulated, abar += vd2 * y_d once per output)
+//   VAR 2: VAR 1 + two accumulators (even / odd k-steps)
+//   VAR 3: VAR 1 + explicit register prefetch: the 16 weights of the NEXT four k-blocks are loaded before the 16 MFMAs of these
+//   VAR 4: VAR 3 + the 16 activation values of the next four k-blocks prefetched too
+template <int VAR>
+__global__ __launch_bounds__(512) void k_var(const double* __restrict__ S, double* out, int Dout) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  for (int i = tid; i < Mp * 16; i += 512) smem[i] = 1e-3 * (i % 97);
+  __syncthreads();
+  d4 acc = (d4){0, 0, 0, 0};
+  const double* __restrict__ act = smem + g * 16 + c;
+  if (VAR <= 2) {
+    for (int d = 0; d < Dout; ++d) {
+      const double* __restrict__ W = S + (int64_t)d * Mp * Mp + 16 * wave + c + (int64_t)g * Mp;
+      d4 y0 = (d4){0, 0, 0, 0}, y1 = (d4){0, 0, 0, 0};
+#pragma unroll 4
+      for (int kb = 0; kb < MPB; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double w = W[(int64_t)(16 * kb + 4 * s) * Mp];
+          const double b = act[(16 * kb + 4 * s) * 16];
+          if (VAR == 2 && (s & 1)) y1 = mfma_f64(w, b, y1); else y0 = mfma_f64(w, b, y0);
+        }
+      acc += (1.0 + d) * (y0 + y1);
+    }
+  } else {
+    double wn[16], bn[16];
+    {
+      const double* __restrict__ W = S + 16 * wave + c + (int64_t)g * Mp;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wn[j] = W[(int64_t)(4 * j) * Mp];
+      if (VAR == 4)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bn[j] = act[(4 * j) * 16];
+    }
+    const int nh = 2 * Dout;                 // half-outputs: four k-blocks each
+    d4 y = (d4){0, 0, 0, 0};
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      double wc[16], bc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { wc[j] = wn[j]; bc[j] = bn[j]; }
+      const int hn = h + 1 < nh ? h + 1 : h;
+      const double* __restrict__ W = S + (int64_t)(hn >> 1) * Mp * Mp + (int64_t)(64 * (hn & 1)) * Mp + 16 * wave + c + (int64_t)g * Mp;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wn[j] = W[(int64_t)(4 * j) * Mp];
+      if (VAR == 4) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bn[j] = act[(64 * (hn & 1) + 4 * j) * 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double b = (VAR == 4) ? bc[j] : act[(64 * (h & 1) + 4 * j) * 16];
+        y = mfma_f64(wc[j], b, y);
+      }
+      if (h & 1) { acc += (1.0 + (h >> 1)) * y; y = (d4){0, 0, 0, 0}; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  out[(size_t)blockIdx.x * 512 + tid] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
 template <typename F>
 void timeit(const char* name, F launch, double flops) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -195,5 +261,8 @@ int main() {
   // 32 data rows per workgroup (two activation tiles per weight fragment): half the weight stream per flop
   timeit("16x16x4  32 rows per workgroup, global=true lds=true", [&] { k_big<true, true, 2><<<blocks / 2, 512, lds2>>>(S, out, Dout); }, fl);
   timeit("16x16x4  32 rows per workgroup, global=false lds=true", [&] { k_big<false, true, 2><<<blocks / 2, 512, lds2>>>(S, out, Dout); }, fl);
+#define VARI(V, TXT) timeit("16x16x4  " TXT, [&] { k_var<V><<<blocks, 512, lds>>>(S, out, Dout); }, fl)
+  VARI(1, "no v_mul (y_d accumulated)"); VARI(2, "no v_mul, two accumulators"); VARI(3, "no v_mul, weights prefetched one group ahead");
+  VARI(4, "no v_mul, weights and activations prefetched");
   return 0;
 }
