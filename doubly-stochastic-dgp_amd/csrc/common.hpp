@@ -165,19 +165,40 @@ __device__ __forceinline__ double bern_var_exp(double mu, double v, double y, do
   return ve;
 }
 
+// Cross-lane sums WITHOUT the LDS: __shfl_xor compiles to ds_bpermute_b32 pairs (an LDS round trip of 100-200 cycles per step when
+// 32 waves share the CU); the per-input-dimension reductions at the end of the backward chain were six such dependent steps per
+// dimension and took 23 K of the 61 K clocks of a D_out = 1 workgroup (DSDGP_BWD_TIMING, profiles/r02_bwd_phases.txt).
+// gfx950 has v_permlane16_swap / v_permlane32_swap (exchange odd/even 16-lane rows, upper/lower 32 lanes) and the gfx9 DPP row
+// shifts / row broadcasts, all plain VALU instructions.
+//
 // sum over the four 16-lane groups (same c): afterwards every lane holds the total for its column c.
 __device__ __forceinline__ double sum_groups(double x) {
-  x += __shfl_xor(x, 16, 64);
-  x += __shfl_xor(x, 32, 64);
-  return x;
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);     // {this row | its neighbour row} in either order
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  const unsigned lo2 = __double2loint(y), hi2 = __double2hiint(y);
+  const auto c = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+  const auto d = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+  return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
-// full 64-lane sum
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_or_zero(double x) {      // the DPP-moved value; lanes without a source (or masked off) read 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// full 64-lane sum, returned in every lane (inclusive scan by row_shr 1/2/4/8, row_bcast 15/31, then lane 63 read back)
 __device__ __forceinline__ double sum_wave(double x) {
-  x += __shfl_xor(x, 1, 64);
-  x += __shfl_xor(x, 2, 64);
-  x += __shfl_xor(x, 4, 64);
-  x += __shfl_xor(x, 8, 64);
-  return sum_groups(x);
+  x += dpp_or_zero<0x111, 0xf>(x);
+  x += dpp_or_zero<0x112, 0xf>(x);
+  x += dpp_or_zero<0x114, 0xf>(x);
+  x += dpp_or_zero<0x118, 0xf>(x);
+  x += dpp_or_zero<0x142, 0xa>(x);
+  x += dpp_or_zero<0x143, 0xc>(x);
+  const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(x), 63);
+  const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(x), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // broadcast of lane `L` (compile-time constant) of a double through two v_readlane_b32 (far cheaper than the

@@ -71,6 +71,7 @@ struct LayerBwdArgs {
   int32_t Dp, prop;     // previous layer's D_out, input_prop_dim
   double jitter;
   int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
+  unsigned long long* phase_clk;   // debug aid (DSDGP_BWD_TIMING): [workgroup][8] shader-clock stamps of the backward chain's phases, or NULL
 };
 
 // out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]

@@ -285,19 +285,8 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
   }
-  // acc holds this wave's rows of "a": save for the backward pass, and the partial mean a . q_mu (layers.py:190)
-  if (act && a.Asave && blockIdx.y == 0) {
-    const int64_t r = r0 + c;
-    if (r < a.ldA) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-        if (Own<MPB, NW>::skip(ib)) continue;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = (r < a.Rin) ? acc[q][t] : 0.0;
-      }
-    }
-  }
+  // acc holds this wave's rows of "a" (saved for the backward pass at the END of the kernel, see there); the partial mean
+  // a . q_mu (layers.py:190)
   if constexpr (MU_EARLY) {
     for (int d = 0; d < Dout; ++d) {
       double mu = 0.0;
@@ -419,14 +408,35 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
   }
+  // "a" for the backward pass.  Stored LAST: vmcnt retires in order on gfx9, so a store issued before the per-output loop made that
+  // loop's first weight loads wait for the store's write acknowledgement.  The tile is re-read from the activation buffer (this
+  // thread's own slots, intact since the second chain) — no register stays live for it.
+  if (act && a.Asave && blockIdx.y == 0) {
+    const int64_t r = r0 + c;
+    if (r < a.ldA) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        if (Own<MPB, NW>::skip(ib)) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = (r < a.Rin) ? actb[out_slot<D4>(ib, g, t) * 16 + c] : 0.0;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * NW + wave).
 // ------------------------------------------------------------------------------------------------------
 // CS: abar's variance part from the saved c_d (triangular q_sqrt_d products, staged through LDS) instead of dense S_d a
+#define BWD_STAMP(i) do { if (a.phase_clk && tid == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// occupancy the 8-wave instances are held to: 80 VGPRs = three workgroups per CU at Mp <= 128, 128 VGPRs = two at Mp <= 256 (the
+// allocator lands one to three registers above those steps otherwise, which halves the resident workgroups)
+template <int MPB, int NW, bool WIDE, bool CS>
+constexpr int bwd_min_waves() { return (NW == 8 && !WIDE && !CS) ? (MPB <= 8 ? 6 : 4) : 1; }
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
-__global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
+__global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   constexpr bool D4 = (MPB > 16);
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
   const double s2 = a.hyp[HYP_VAR];
   const int64_t r = r0 + c;
   const bool rin = r < a.ldA, rvalid = r < a.Rin;
+  BWD_STAMP(0);
   d4 av[NQ], acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -457,7 +468,21 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
       if (!CS && act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
     }
   }
+  // x / l of this row block (needed for the kernel recompute after the chains): requested now so that its latency hides behind them.
+  // xs is not touched by anything in between and every path below passes a barrier before reading it.
+  if constexpr (!WIDE) {
+    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
+      const int rr = idx / Din, j = idx % Din;
+      int64_t row = r0 + rr;
+      if (row > a.Rin - 1) row = a.Rin - 1;
+      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
+    }
+  }
+  // the first two k-steps of the mean part's upstream adjoints, for the same reason
+  const double bv0 = (act && rin) ? a.MB[(int64_t)g * a.ldA + r] : 0.0;
+  const double bv1 = (act && rin && a.DP4 > 4) ? a.MB[(int64_t)(4 + g) * a.ldA + r] : 0.0;
   double gsum = 0.0;
+  BWD_STAMP(1);      // A tile loaded
   if constexpr (CS) {
     // cbar_d = 2 vbar_d c_d staged into LDS ([k][16 rows], B-operand order), abar += q_sqrt_d cbar_d: out block ib sums kb <= ib.
     // Mp <= 256: two staging buffers (the loads of output d+1 fly during the products of d, one barrier per output);
@@ -520,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     // mean part (abar += q_mu mbar) and hand-over of abar through LDS, under the d-loop's ownership
     if (cact) {
       for (int sp = 0; sp < a.DP4 / 4; ++sp) {
-        const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
+        const double bv = sp == 0 ? bv0 : (sp == 1 ? bv1 : (rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0));
 #pragma unroll
         for (int q = 0; q < OC::NQ; ++q) {
           const int ib = OC::ib(wave, q);
@@ -600,10 +625,11 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
     }
   }
   }
+  BWD_STAMP(2);      // d-loop done
   if constexpr (!CS) {
   if (act) {
     for (int sp = 0; sp < a.DP4 / 4; ++sp) {
-      const double bv = rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0;
+      const double bv = sp == 0 ? bv0 : (sp == 1 ? bv1 : (rin ? a.MB[(int64_t)(4 * sp + g) * a.ldA + r] : 0.0));
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
@@ -627,6 +653,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
   }
   __syncthreads();
   }
+  BWD_STAMP(3);      // mean part, abar in LDS
   // b = Ku^{-1} abar (dense)   |   white: kbar = Lu^{-T} a1bar (k-blocks >= own block)
   d4 bb[NQ];
 #pragma unroll
@@ -653,19 +680,11 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
       }
     }
   }
+  BWD_STAMP(4);      // Ku^-1 product
   // E, kbar; recompute the Kuf tile for GW = kbar * dk/dr2
   d4 r2[WIDE ? NQ : 1];
-  if constexpr (WIDE) {
-    sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
-  } else {
-    for (int idx = tid; idx < 16 * Din; idx += NW * 64) {
-      const int rr = idx / Din, j = idx % Din;
-      int64_t row = r0 + rr;
-      if (row > a.Rin - 1) row = a.Rin - 1;
-      xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
-    }
-    __syncthreads();
-  }
+  if constexpr (WIDE) sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
+  BWD_STAMP(5);      // (wide inputs: distances chunked through LDS)
   double svar = 0.0;
   if (act) {
 #pragma unroll
@@ -693,13 +712,13 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
         svar += ok ? kbar * k : 0.0;
         const double w = ok ? kbar * dk : 0.0;
         bb[q][t] = w;
-        if (rin) {
-          if (a.E) a.E[(int64_t)m * a.ldA + r] = e;     // NULL: d loss / d Ku is assembled from the P_d (model.hip, alg_g)
-          a.GW[(int64_t)m * a.ldA + r] = w;
-        }
+        // NULL: d loss / d Ku is assembled from the P_d (model.hip, alg_g).  GW is stored at the end of the kernel: a store issued here
+        // makes the Z loads of the reductions below wait for its write acknowledgement (vmcnt retires in order).
+        if (rin && a.E) a.E[(int64_t)m * a.ldA + r] = e;
       }
     }
   }
+  BWD_STAMP(6);      // kernel recompute, E / GW stores issued
   svar = sum_wave(svar);
   const double gk = sum_wave((rvalid && g == 0 && wave == 0) ? gsum : 0.0);
   double* hp = a.hyp_part + ((int64_t)blockIdx.x * NW + wave) * (Din + 2);
@@ -720,29 +739,64 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
       }
       __syncthreads();
     }
-    for (int j = 0; j < jn; ++j) {
-      double sx = 0.0, sl = 0.0;
+    // epilogue operands of this thread's item (one item per thread when 16 jn <= threads): requested now, they arrive during the
+    // reductions below instead of after the barrier
+    const bool single = 16 * jn <= NW * 64;
+    double pre_mb = 0.0, pre_z = 0.0, pre_var = 1.0;
+    if ((a.dX || a.MBp) && single && tid < 16 * jn) {
+      const int j = a.MBp ? tid / 16 : tid % jn, cc = a.MBp ? tid % 16 : tid / jn;
+      const int64_t row = r0 + cc;
+      if (row < a.Rin) {
+        if (a.mean_kind == DSDGP_MEAN_IDENTITY) pre_mb = a.MB[(int64_t)(j0 + j) * a.ldA + row];
+        const int d = j0 + j - a.prop;
+        if (a.MBp && d >= 0) {
+          pre_z = a.zp[(row / a.n_inner) * a.zp_s + (row % a.n_inner) * a.zp_n + d * a.zp_d];
+          pre_var = a.varp[row * a.Dp + d];
+        }
+      }
+    }
+    // four input dimensions at a time: their 16 Z loads are in flight together (one dimension per pass exposed an L1 / L2 round
+    // trip per dimension: 20 K of the 59 K clocks of a D_out = 1 workgroup at config 2, profiles/r02_bwd_phases.txt)
+    constexpr int JG = (NQ <= 2) ? 2 : 1;       // more in flight costs registers: JG = 4 took the M = 128 instance from 3 to 2 workgroups per CU
+    for (int jg = 0; jg < jn; jg += JG) {
+      double sxv[JG], slv[JG];
+#pragma unroll
+      for (int u = 0; u < JG; ++u) sxv[u] = slv[u] = 0.0;
       if (act) {
-        const double xv = xs[c * (jn + 1) + j];
+        double xv[JG];
+#pragma unroll
+        for (int u = 0; u < JG; ++u) xv[u] = xs[c * (jn + 1) + (jg + u < jn ? jg + u : jn - 1)];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           if (Own<MPB, NW>::skip(ib)) continue;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const double df = xv - zs[(int64_t)(16 * ib + g + 4 * t) * Din + j0 + j];
-            const double wdf = bb[q][t] * df;
-            sx += wdf;
-            sl = fma(wdf, df, sl);
+            const double* __restrict__ zr = zs + (int64_t)(16 * ib + g + 4 * t) * Din + j0;
+            double zv[JG];
+#pragma unroll
+            for (int u = 0; u < JG; ++u) zv[u] = zr[jg + u < jn ? jg + u : jn - 1];
+#pragma unroll
+            for (int u = 0; u < JG; ++u) {
+              const double df = xv[u] - zv[u];
+              const double wdf = bb[q][t] * df;
+              sxv[u] += wdf;
+              slv[u] = fma(wdf, df, slv[u]);
+            }
           }
         }
       }
-      if (a.dX || a.MBp) {
-        sx = sum_groups(sx);
-        if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
+#pragma unroll
+      for (int u = 0; u < JG; ++u) {
+        const int j = jg + u;
+        if (j >= jn) break;
+        if (a.dX || a.MBp) {
+          const double sx = sum_groups(sxv[u]);
+          if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
+        }
+        const double sl = sum_wave(slv[u]);
+        if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
       }
-      sl = sum_wave(sl);
-      if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
     }
     if (a.dX || a.MBp) {
       __syncthreads();
@@ -756,16 +810,17 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
           for (int w = 0; w < NW; ++w) sx += redx[(w * jn + j) * 16 + cc];
           double dx = 2.0 * ils[j0 + j] * sx;
           if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
-            dx += a.MB[(int64_t)(j0 + j) * a.ldA + row];
+            dx += single ? pre_mb : a.MB[(int64_t)(j0 + j) * a.ldA + row];
           } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
             for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[(int64_t)(j0 + j) * Dout + d], a.MB[(int64_t)d * a.ldA + row], dx);
           }
           if (a.MBp) {
             const int d = j0 + j - a.prop;
             if (d >= 0) {
-              const double zv = a.zp[(row / a.n_inner) * a.zp_s + (row % a.n_inner) * a.zp_n + d * a.zp_d];
+              const double zv = single ? pre_z : a.zp[(row / a.n_inner) * a.zp_s + (row % a.n_inner) * a.zp_n + d * a.zp_d];
+              const double vv = single ? pre_var : a.varp[row * a.Dp + d];
               a.MBp[(int64_t)d * a.ldA + row] = dx;
-              a.VBp[(int64_t)d * a.ldA + row] = dx * zv * 0.5 * rsqrt(a.varp[row * a.Dp + d] + a.jitter);
+              a.VBp[(int64_t)d * a.ldA + row] = dx * zv * 0.5 * rsqrt(vv + a.jitter);
             }
           } else {
             a.dX[row * Din + j0 + j] = dx;
@@ -777,6 +832,16 @@ __global__ __launch_bounds__(NW * 64) void k_layer_bwd_sm(const LayerBwdArgs a, 
       }
     }
   }
+  if (act && rin) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ib = Own<MPB, NW>::ib(wave, q);
+      if (Own<MPB, NW>::skip(ib)) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a.GW[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] = bb[q][t];
+    }
+  }
+  BWD_STAMP(7);      // hyper-parameter partials, dX / transposed adjoints, GW
 }
 
 
@@ -805,6 +870,32 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
+// DSDGP_BWD_TIMING=1 (debug aid, synchronous): per-phase shader clocks of every backward-chain launch, averaged over its workgroups
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
+static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds& L, size_t lds) {
+  const int nwg = (int)ceil_div(a0.ldA, 16);
+  unsigned long long* clk = nullptr;
+  DS_HIP(hipMalloc(&clk, (size_t)nwg * 8 * sizeof(unsigned long long)));
+  LayerBwdArgs a = a0;
+  a.phase_clk = clk;
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(nwg), dim3(NW * 64), lds, ctx->stream, a, L);
+  DS_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<unsigned long long> h((size_t)nwg * 8);
+  DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  hipFree(clk);
+  double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long first = ~0ull, last = 0;
+  for (int w = 0; w < nwg; ++w) {
+    for (int i = 0; i < 7; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
+    first = std::min(first, h[(size_t)w * 8]);
+    last = std::max(last, h[(size_t)w * 8 + 7]);
+  }
+  fprintf(stderr, "[bwd phases] Mp=%d NW=%d D_out=%d wgs=%d  clocks/wg: A-tile %.0f | d-loop %.0f | mean+abar %.0f | Kinv %.0f | x-stage %.0f | "
+          "kernel+E/GW %.0f | hyp+dX %.0f | sum %.0f   launch span %.0f\n", MPB * 16, NW, a.D_out, nwg, ph[0] / nwg, ph[1] / nwg,
+          ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg, ph[6] / nwg,
+          (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) / nwg, (double)(last - first));
+  return DSDGP_OK;
+}
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
 static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
   const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE, (CS && MPB <= 16) ? 2 : 1);
@@ -822,6 +913,8 @@ static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
       }
     }
   ProfScope ps(ctx, "layer_bwd");
+  static const bool timing = getenv("DSDGP_BWD_TIMING") != nullptr;
+  if (timing) return bwd_phase_timing<MPB, NW, KIND, WHITE, WIDE, CS>(ctx, a, L, lds);
   hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
