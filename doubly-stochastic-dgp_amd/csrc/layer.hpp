@@ -33,6 +33,7 @@ struct LayerFwdArgs {
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
   double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
   int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
+  unsigned long long* phase_clk;   // debug aid (DSDGP_FWD_TIMING): [workgroup][8] shader-clock stamps of the forward chain's phases, or NULL
 };
 
 struct LayerBwdArgs {

@@ -153,6 +153,7 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
   }
 }
 
+#define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const bool act = Own<MPB, NW>::active(wave);
   const double s2 = a.hyp[HYP_VAR];
+  FWD_STAMP(0);
 
   // [X^T ; 1] of this block for the Z-gradient product of the backward pass (coalesced 128-byte runs along the rows)
   if (a.XT1 && blockIdx.y == 0) {
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
     }
   }
   __syncthreads();
+  FWD_STAMP(1);      // Kuf tile in LDS
 
   d4 acc[NQ];
   // --- a1 = Lu^{-1} k (layers.py:186): out block ib sums k-blocks kb <= ib ; weights LinvT[k][i]
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
     }
   }
   __syncthreads();
+  FWD_STAMP(2);      // a1, |a1|^2
   // --- a = Lu^{-T} a1 (layers.py:188): out block ib sums kb >= ib ; weights Linv[k][i]   (white: a = a1)
   if (!WHITE) {
 #pragma unroll
@@ -287,7 +291,9 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   }
   // acc holds this wave's rows of "a" (saved for the backward pass at the END of the kernel, see there); the partial mean
   // a . q_mu (layers.py:190)
+  FWD_STAMP(3);      // a
   if constexpr (MU_EARLY) {
+    // (four / two outputs per pass with their q_mu loads in flight together were tried: 143 / 95 VGPRs instead of 79 and no gain)
     for (int d = 0; d < Dout; ++d) {
       double mu = 0.0;
       if (act) {
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
     }
   }
   __syncthreads();
+  FWD_STAMP(4);      // mean partials
 
   const double kdiag = a.hyp[HYP_KDIAG];
   // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
   }
+  FWD_STAMP(5);      // per-output products and epilogue
   // "a" for the backward pass.  Stored LAST: vmcnt retires in order on gfx9, so a store issued before the per-output loop made that
   // loop's first weight loads wait for the store's write acknowledgement.  The tile is re-read from the activation buffer (this
   // thread's own slots, intact since the second chain) — no register stays live for it.
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
   }
+  FWD_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -866,6 +875,25 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   const int nrow = ceil_div(a.Rin, 16);
   int ds = a.d_split > 0 ? a.d_split : 1;
   if (ds > a.D_out) ds = a.D_out;
+  static const bool timing = getenv("DSDGP_FWD_TIMING") != nullptr;
+  if (timing) {      // debug aid, synchronous: per-phase shader clocks averaged over the workgroups of this launch
+    unsigned long long* clk = nullptr;
+    DS_HIP(hipMalloc(&clk, (size_t)nrow * 8 * sizeof(unsigned long long)));
+    LayerFwdArgs b = a;
+    b.phase_clk = clk;
+    hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, b, L);
+    DS_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h((size_t)nrow * 8);
+    DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    hipFree(clk);
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < nrow; ++w)
+      for (int i = 0; i < 6; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
+    fprintf(stderr, "[fwd phases] Mp=%d NW=%d D_out=%d wgs=%dx%d  clocks/wg: Kuf tile %.0f | a1 %.0f | a %.0f | mean partials %.0f | per-output + epilogue %.0f | "
+            "Asave %.0f | sum %.0f\n", MPB * 16, NW, a.D_out, nrow, ds, ph[0] / nrow, ph[1] / nrow, ph[2] / nrow, ph[3] / nrow, ph[4] / nrow,
+            ph[5] / nrow, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / nrow);
+    return DSDGP_OK;
+  }
   hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;

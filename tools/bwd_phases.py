@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""Per-phase shader clocks of the backward chain launches of one config shape (DSDGP_BWD_TIMING=1: synchronous debug aid in
+"""Per-phase shader clocks of the forward and backward chain launches of one config shape (DSDGP_FWD_TIMING=1 / DSDGP_BWD_TIMING=1: synchronous debug aids in
 csrc/layer_sm_impl.hpp).  usage: python tools/bwd_phases.py 2 [3 ...]"""
 import os
 import sys
 
 os.environ["DSDGP_BWD_TIMING"] = "1"
+os.environ["DSDGP_FWD_TIMING"] = "1"
 os.environ["DSDGP_NO_OVERLAP"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "doubly-stochastic-dgp_amd"))
