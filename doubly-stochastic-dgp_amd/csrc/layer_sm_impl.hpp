@@ -116,13 +116,23 @@ static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide, int n
   return L;
 }
 
-// scaled squared distances of this wave's inducing rows to the block's 16 data rows, D layout, chunked over D_in
+// scaled squared distances of this wave's inducing rows to the block's 16 data rows, D layout, chunked over D_in (wide inputs).
+// r2[m][c] = |z_m|^2 + |x_c|^2 - 2 z_m . x_c on the MFMA pipe: lane (g, c) feeds A = Zs[16 ib + c][k], B = xs[c][k] with
+// k = 16-dimension group + 4 g + s in k-step s (any bijection of k works as long as A and B agree), so the product lands in the
+// D layout (row g + 4 t of block ib, column c) the chains want; |z_m|^2 is summed per lane for row 16 ib + c, folded over g and
+// turned from that A-operand order into the D layout through 16 doubles of LDS per row block (`scratch`, wave-private: same wave
+// writes and reads, LDS operations of a wave execute in order); |x_c|^2 from a per-lane sum folded over g.  The element-by-element form (one L2 load and one FMA per (m, c, dimension) and lane)
+// took 1.37 M of the 3.25 M clocks of the 784-dimensional first layer of config 4 (profiles/r02_fwd_phases.txt) and as much again
+// in the backward chain.  Absolute error ~ 1e-16 (|z|^2 + |x|^2); the result is clamped at 0.
 template <int NQ, int MPB, int NW>
 __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const double* __restrict__ X,
                                           const double* __restrict__ ils, double* xs, int Din, int64_t r0, int64_t Rin,
-                                          int tid, int wave, int g, int c, bool act, d4 (&r2)[NQ]) {
+                                          int tid, int wave, int g, int c, bool act, double* scratch, d4 (&r2)[NQ]) {
+  d4 zx[NQ];
+  double zsq[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) r2[q] = (d4){0, 0, 0, 0};
+  for (int q = 0; q < NQ; ++q) { zx[q] = (d4){0, 0, 0, 0}; zsq[q] = 0.0; }
+  double xx = 0.0;
   for (int j0 = 0; j0 < Din; j0 += XCH) {
     const int jn = (Din - j0 < XCH) ? Din - j0 : XCH;
     if (j0 > 0) __syncthreads();
@@ -134,23 +144,81 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
     }
     __syncthreads();
     if (act) {
+      if ((jn & 15) == 0 && (Din & 3) == 0) {
+        // whole groups of 16 dimensions: one 32-byte load per lane and row block, all groups of the chunk unrolled so that their
+        // loads are in flight together (the wide instances run one workgroup per CU: registers are plentiful)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-        if (Own<MPB, NW>::skip(ib)) continue;
+        for (int u = 0; u < XCH / 16; ++u) {
+          const int kk = 16 * u;
+          if (kk >= jn) break;
+          double b[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double* __restrict__ zr = zs + (int64_t)(16 * ib + g + 4 * t) * Din + j0;
-          double acc = r2[q][t];
-          for (int j = 0; j < jn; ++j) {
-            const double df = zr[j] - xs[c * (jn + 1) + j];
-            acc = fma(df, df, acc);
+          for (int s = 0; s < 4; ++s) {
+            b[s] = xs[c * (jn + 1) + kk + 4 * g + s];
+            xx = fma(b[s], b[s], xx);
           }
-          r2[q][t] = acc;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ib = Own<MPB, NW>::ib(wave, q);
+            if (Own<MPB, NW>::skip(ib)) continue;
+            const d4 av = *reinterpret_cast<const d4*>(zs + (int64_t)(16 * ib + c) * Din + j0 + kk + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              zx[q] = mfma_f64(av[s], b[s], zx[q]);
+              zsq[q] = fma(av[s], av[s], zsq[q]);
+            }
+          }
+        }
+      } else {
+        for (int kk = 0; kk < jn; kk += 16) {
+          double b[4];
+          int jc[4];
+          bool in[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int j = kk + 4 * g + s;
+            in[s] = j < jn;
+            jc[s] = in[s] ? j : jn - 1;                      // unconditional (clamped) loads, masked afterwards
+            const double v = xs[c * (jn + 1) + jc[s]];
+            b[s] = in[s] ? v : 0.0;
+            xx = fma(b[s], b[s], xx);
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ib = Own<MPB, NW>::ib(wave, q);
+            if (Own<MPB, NW>::skip(ib)) continue;
+            const double* __restrict__ zr = zs + (int64_t)(16 * ib + c) * Din + j0;
+            double av[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double v = zr[jc[s]];
+              av[s] = in[s] ? v : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              zx[q] = mfma_f64(av[s], b[s], zx[q]);
+              zsq[q] = fma(av[s], av[s], zsq[q]);
+            }
+          }
         }
       }
     }
   }
+  xx = sum_groups(xx);          // lane (g, c) covered the dimensions 4 g .. 4 g + 3 of every group of 16
+  double* zrow = scratch + wave * NQ * 16;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double zq = sum_groups(zsq[q]);          // |z|^2 of row 16 ib + c
+    if (g == 0) zrow[q * 16 + c] = zq;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double v = zrow[q * 16 + g + 4 * t] + xx - 2.0 * zx[q][t];
+      r2[q][t] = v > 0.0 ? v : 0.0;
+    }
 }
 
 #define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -214,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
     }
   } else {
     d4 r2[NQ];
-    sm_sqdist<NQ, MPB, NW>(a.Zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
+    sm_sqdist<NQ, MPB, NW>(a.Zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, red_s1, r2);
     if (act) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -692,7 +760,7 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   BWD_STAMP(4);      // Ku^-1 product
   // E, kbar; recompute the Kuf tile for GW = kbar * dk/dr2
   d4 r2[WIDE ? NQ : 1];
-  if constexpr (WIDE) sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, r2);
+  if constexpr (WIDE) sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, redx, r2);
   BWD_STAMP(5);      // (wide inputs: distances chunked through LDS)
   double svar = 0.0;
   if (act) {
