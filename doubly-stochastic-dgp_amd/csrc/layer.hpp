@@ -73,6 +73,13 @@ struct LayerBwdArgs {
   double jitter;
   int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
   unsigned long long* phase_clk;   // debug aid (DSDGP_BWD_TIMING): [workgroup][8] shader-clock stamps of the backward chain's phases, or NULL
+  // split-M kernels, small launches: gridDim.y = d_split workgroups share a row block, each takes D_out / d_split outputs of the d-loop
+  // and leaves its partial abar tile (+ its share of sum_d vbar_d) in `part` ([row block][d_split][Mp * 16 + 16]); the workgroup that
+  // arrives last (ticket from part_cnt[row block], reset by it) adds the partials in split order — a fixed order, whoever is
+  // last — and runs the rest of the chain
+  int32_t d_split;
+  double* part;
+  int* part_cnt;
 };
 
 // out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]

@@ -559,6 +559,49 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   const double bv0 = (act && rin) ? a.MB[(int64_t)g * a.ldA + r] : 0.0;
   const double bv1 = (act && rin && a.DP4 > 4) ? a.MB[(int64_t)(4 + g) * a.ldA + r] : 0.0;
   double gsum = 0.0;
+  // d-split (LayerBwdArgs::d_split): this workgroup's outputs of the d-loop, and the hand-over of the partial tiles
+  const int n_split = (int)gridDim.y;
+  const int dchunk = (Dout + n_split - 1) / n_split;
+  const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
+  __shared__ int s_ticket;
+  // T: this wave's accumulator tiles, row block of tile q = ib_of(q) (negative: none).  Returns false in the workgroups that are done.
+  auto merge_split = [&](auto& T, auto ib_of) -> bool {
+    if (n_split == 1) return true;
+    constexpr int NT = sizeof(T) / sizeof(T[0]);
+    const int64_t pstride = (int64_t)Mp * 16 + 16;
+    double* mine = a.part + ((int64_t)blockIdx.x * n_split + blockIdx.y) * pstride;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int ib = ib_of(q);
+      if (ib < 0) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mine[(16 * ib + g + 4 * t) * 16 + c] = T[q][t];
+    }
+    if (wave == 0 && g == 0) mine[Mp * 16 + c] = gsum;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(a.part_cnt + blockIdx.x, 1);
+    __syncthreads();
+    if (s_ticket != n_split - 1) return false;
+    if (tid == 0) a.part_cnt[blockIdx.x] = 0;          // every split has arrived: ready for the next launch
+    __threadfence();
+    const double* base = a.part + (int64_t)blockIdx.x * n_split * pstride;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) T[q] = (d4){0, 0, 0, 0};
+    gsum = 0.0;
+    for (int y = 0; y < n_split; ++y) {
+      const double* __restrict__ p = base + y * pstride;
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const int ib = ib_of(q);
+        if (ib < 0) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) T[q][t] += p[(16 * ib + g + 4 * t) * 16 + c];
+      }
+      gsum += p[Mp * 16 + c];
+    }
+    return true;
+  };
   BWD_STAMP(1);      // A tile loaded
   if constexpr (CS) {
     // cbar_d = 2 vbar_d c_d staged into LDS ([k][16 rows], B-operand order), abar += q_sqrt_d cbar_d: out block ib sums kb <= ib.
@@ -591,20 +634,21 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
 #pragma unroll
     for (int q = 0; q < OC::NQ; ++q) cacc[q] = (d4){0, 0, 0, 0};
     const bool cact = OC::active(wave);
-    if (PREF) stage_load(0);
-    if (DBUF) stage_store(actb);
-    for (int d = 0; d < Dout; ++d) {
+    if (PREF && d_lo < d_hi) stage_load(d_lo);
+    if (DBUF && d_lo < d_hi) stage_store(actb);
+    for (int d = d_lo; d < d_hi; ++d) {
       gsum += rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
-      double* cur = (DBUF && (d & 1)) ? buf1 : actb;
+      const int dpar = (d - d_lo) & 1;
+      double* cur = (DBUF && dpar) ? buf1 : actb;
       if (DBUF) {
-        if (d + 1 < Dout) stage_load(d + 1);
+        if (d + 1 < d_hi) stage_load(d + 1);
         __syncthreads();
       } else {
         __syncthreads();          // the products of output d-1 are done with the buffer
         if (!PREF) stage_load(d);
         stage_store(actb);
         __syncthreads();
-        if (PREF && d + 1 < Dout) stage_load(d + 1);
+        if (PREF && d + 1 < d_hi) stage_load(d + 1);
       }
       if (cact) {
         const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
@@ -617,8 +661,9 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
           for (int kb = 0; kb <= ib; ++kb) cacc[q] = chain_block<Mp, D4>(Td, TdT, cur, ib, kb, g, c, cacc[q]);
         }
       }
-      if (DBUF && d + 1 < Dout) stage_store((d & 1) ? actb : buf1);
+      if (DBUF && d + 1 < d_hi) stage_store(dpar ? actb : buf1);
     }
+    if (!merge_split(cacc, [&](int q) { const int ib = OC::ib(wave, q); return (cact && (OC::CUSTOM || !Own<MPB, NW>::skip(ib))) ? ib : -1; })) return;
     // mean part (abar += q_mu mbar) and hand-over of abar through LDS, under the d-loop's ownership
     if (cact) {
       for (int sp = 0; sp < a.DP4 / 4; ++sp) {
@@ -656,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
     }
   } else {
   __syncthreads();
-  for (int d = 0; d < Dout; ++d) {
+  for (int d = d_lo; d < d_hi; ++d) {
     const double vd = rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
     gsum += vd;
     const double vd2 = 2.0 * vd;
@@ -701,8 +746,9 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
       }
     }
   }
+  if (!merge_split(acc, [&](int q) { const int ib = Own<MPB, NW>::ib(wave, q); return (act && !Own<MPB, NW>::skip(ib)) ? ib : -1; })) return;
   }
-  BWD_STAMP(2);      // d-loop done
+  BWD_STAMP(2);      // d-loop done (and, with a d-split, the partial tiles merged)
   if constexpr (!CS) {
   if (act) {
     for (int sp = 0; sp < a.DP4 / 4; ++sp) {
@@ -974,7 +1020,7 @@ static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds&
   DS_HIP(hipMalloc(&clk, (size_t)nwg * 8 * sizeof(unsigned long long)));
   LayerBwdArgs a = a0;
   a.phase_clk = clk;
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(nwg), dim3(NW * 64), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(nwg, a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<unsigned long long> h((size_t)nwg * 8);
   DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1011,7 +1057,8 @@ static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
   ProfScope ps(ctx, "layer_bwd");
   static const bool timing = getenv("DSDGP_BWD_TIMING") != nullptr;
   if (timing) return bwd_phase_timing<MPB, NW, KIND, WHITE, WIDE, CS>(ctx, a, L, lds);
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16)), dim3(NW * 64), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds,
+                     ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

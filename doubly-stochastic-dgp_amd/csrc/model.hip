@@ -69,6 +69,8 @@ struct LayerState {
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
+  double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
+  int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
   BigChol big_k, big_ngA, big_ngS, big_ngT;
   GemmProblem* ng_gp;  // device: 5 natural-gradient GEMM problems (H, Sinv | Y | X | Splus)
@@ -300,6 +302,9 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
+    // d-split of the backward chain on small launches (at most 512 workgroups): partial abar tiles + arrival counters
+    S.bpart = sm_chain_enabled() ? b.take<double>((size_t)512 * (Mp * 16 + 16)) : nullptr;
+    S.bcnt = sm_chain_enabled() ? b.take<int>(512) : nullptr;
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -1565,6 +1570,17 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     }
     b.mean_kind = St.d.mean_kind; b.mean_A = St.meanA;
     b.hyp_part = St.hyp_part;
+    {   // few row blocks (the N-row first layer, small shards): spread the d-loop over up to four workgroups per row block.
+        // Only from Mp = 512 (DSDGP_BWD_SPLIT = 2 forces it everywhere, 0 disables): the hand-over needs two device-scope fences
+        // per workgroup, which on this multi-XCD part write back / invalidate a whole L2 — measured +57 us on the 63-row-block
+        // first layer of config 2 (M = 128) against -0.9 ms on the 32-row-block, 30-output first layer of config 4 (M = 512)
+      static const int bsplit_on = getenv("DSDGP_BWD_SPLIT") ? atoi(getenv("DSDGP_BWD_SPLIT")) : 1;
+      const int64_t nblk = ld / 16;
+      const bool want = bsplit_on >= 2 || (bsplit_on == 1 && v.Mp > 256);
+      int ds = (want && St.bpart && nblk < 256) ? (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk)) : 1;
+      if (ds > v.D_out) ds = v.D_out;
+      b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
+    }
     if (sm_chain_enabled())
       DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     else

@@ -498,3 +498,26 @@ def test_bernoulli_training_decreases_loss_and_classifies():
     p, _ = model.predict_y(X, 20)
     acc = np.mean((p.mean(0) > 0.5) == (Y == 1.0))
     assert acc > 0.9
+
+
+def test_backward_d_split_forced_on_small_shapes(monkeypatch):
+    """The d-split of the backward chain (several workgroups per row block share the per-output loop and hand their partial
+    tiles over through global memory) is used from Mp = 512 by default; DSDGP_BWD_SPLIT=2 forces it onto small shapes: dense
+    S_d form (M = 32, 100), Csave form (DSDGP_SAVE_C=2), white and non-white, D_out not divisible by the split."""
+    from tests.test_gpu_parity import _grad_check
+    monkeypatch.setenv("DSDGP_BWD_SPLIT", "2")
+    rng = np.random.RandomState(77)
+    for M, white, save_c in ((32, False, "1"), (100, True, "1"), (64, False, "2")):
+        monkeypatch.setenv("DSDGP_SAVE_C", save_c)
+        N, D, S, DY = 70, 3, 3, 5
+        X, Y = rng.randn(N, D), rng.randn(N, DY)
+        Z = X[rng.permutation(N)[:min(M, N)]] if M <= N else np.vstack([X, rng.randn(M - N, D)])
+        Z = Z + 0.01 * rng.randn(*Z.shape)
+        specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2)]
+        spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=300)
+        zs = [rng.randn(S, N, D), rng.randn(S, N, DY)]
+        _grad_check(X, Y, spec, state, model, zs, S, num_data=300)
+        # a second evaluation on the same model: the arrival counters were reset by the last workgroups
+        e1 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+        e2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+        assert e1 == e2
