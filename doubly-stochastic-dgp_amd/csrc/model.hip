@@ -168,6 +168,17 @@ static bool save_c_enabled(int Mp = 1 << 30) {
   const int mode = save_c_mode();
   return sm_chain_enabled() && (mode >= 2 || (mode == 1 && Mp > 256));
 }
+// workgroups per row block of a chain launch with few row blocks (the d-split).  < 256 row blocks (first layers, small shards): up to
+// four, ~512 workgroups.  256..511 row blocks (the per-GPU shards of configs 4 / 5: two rounds on 256 CUs, the second a quarter to a
+// half full): two or three pack better, but every workgroup repeats the prologue (Kuf tile and the two triangular chains), so only
+// when each keeps at least five outputs (measured: config 4, D_out = 30, -6.6 % per step; config 5, D_out = 8, +6.7 % without the rule)
+static int chain_d_split(int64_t nblk, int D_out) {
+  int ds = 1;
+  if (nblk < 256) ds = (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk));
+  else if (nblk < 512) ds = (int)std::min<int64_t>(1024 / nblk, D_out / 5);
+  if (ds > D_out) ds = D_out;
+  return ds < 1 ? 1 : ds;
+}
 static int big_mp(bool uniform) {
   static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
   return uniform ? v : 512;
@@ -302,8 +313,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
-    // d-split of the backward chain on small launches (at most 512 workgroups): partial abar tiles + arrival counters
-    S.bpart = sm_chain_enabled() ? b.take<double>((size_t)512 * (Mp * 16 + 16)) : nullptr;
+    // d-split of the backward chain on small launches (at most 1024 workgroups): partial abar tiles + arrival counters
+    S.bpart = sm_chain_enabled() ? b.take<double>((size_t)1024 * (Mp * 16 + 16)) : nullptr;
     S.bcnt = sm_chain_enabled() ? b.take<int>(512) : nullptr;
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
@@ -1408,7 +1419,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
-      a.d_split = (nblk < 256) ? (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk)) : 1;
+      a.d_split = chain_d_split(nblk, v.D_out);
     }
     if (sm_chain_enabled())
       DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
@@ -1577,8 +1588,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       static const int bsplit_on = getenv("DSDGP_BWD_SPLIT") ? atoi(getenv("DSDGP_BWD_SPLIT")) : 1;
       const int64_t nblk = ld / 16;
       const bool want = bsplit_on >= 2 || (bsplit_on == 1 && v.Mp > 256);
-      int ds = (want && St.bpart && nblk < 256) ? (int)std::min<int64_t>(4, std::max<int64_t>(1, 512 / nblk)) : 1;
-      if (ds > v.D_out) ds = v.D_out;
+      const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
     if (sm_chain_enabled())
