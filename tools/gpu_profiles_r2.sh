@@ -66,6 +66,12 @@ tail = open("$O/mfma_long.txt").read().strip().splitlines()[-3:]
 print("last lines of the loop's own report:")
 for t in tail: print(t)
 PY
+# 7b. microbenchmarks of the fp64 MFMA forms and of the chain loop's ingredients; per-phase clocks of the chain kernels
+for t in mfma_f64_variants mfma_4x4_probe mfma_emul_test mfma_clock_probe chain_loop_bench; do
+  timeout 120 tools/bin/$t > $P/r02_$t.txt 2>&1
+done
+timeout 300 python tools/bwd_phases.py 2 3 4 5 2> $O/phases.txt > /dev/null
+( echo "# DSDGP_FWD_TIMING=1 DSDGP_BWD_TIMING=1 DSDGP_NO_OVERLAP=1 python tools/bwd_phases.py 2 3 4 5  (third step of each config;"; echo "# shader clocks per workgroup averaged over the launch)"; grep -E "^== cfg|phases\]" $O/phases.txt | awk '/^== cfg/{c=$0; n=0; print; next} {print}' | sed 's/   launch span.*//' ) > $P/r02_chain_phases.txt
 # 8. headline bench line (full, with cpu_baseline)
 timeout 900 python bench.py > $P/r02_bench.json 2> $O/bench.err
 find $O -name "*.db" -size +20M -delete
