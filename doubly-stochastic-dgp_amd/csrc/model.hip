@@ -108,6 +108,8 @@ struct dsdgp_model {
   int n_pt = 0, t_pt = 0;
   hipEvent_t ev_fork, ev_prep_side, ev_z;
   bool prepared_grad = false;  // the last prepare also produced U_d, n, U_d U_d^T
+  bool track_theta = false;    // dsdgp_model_track_theta: the caller reports its writes to theta
+  bool kuu_valid = false;      // Lu / Lu^-1 / Ku^-1 belong to the Z and kernel hyper-parameters currently in theta
   bool side_pending = false;   // parameter-only work (Ku^-1, S_d, KL, U, UU) still running on the side stream
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
   const double* sample_w = nullptr;   // DGP_Quad quadrature weights (borrowed), NULL = Monte-Carlo mean
@@ -424,11 +426,11 @@ __device__ void kuu_body(const LayerDev& v, const double* __restrict__ theta, do
 // ONE launch for the parameter transforms / padding (first PREP_BLOCKS block columns) and Ku (the rest), grid (x, L)
 __global__ __launch_bounds__(256) void k_prep_kuu(const double* __restrict__ theta, const LayerDev* __restrict__ layers,
                                                   double* __restrict__ lik_const, int64_t off_lik, int lik_gauss, double jitter,
-                                                  int nprep) {
+                                                  int nprep, int keep_kuu) {
   const LayerDev v = layers[blockIdx.y];
   if ((int)blockIdx.x < nprep)
     prep_body(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x, nprep);
-  else
+  else if (!keep_kuu)                 // keep_kuu: the factor of the unchanged Ku stays in place (dsdgp_model_track_theta)
     kuu_body(v, theta, jitter, blockIdx.x - nprep, gridDim.x - nprep);
 }
 
@@ -1296,13 +1298,17 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
-  hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
+  static const int reuse_on = getenv("DSDGP_KUU_REUSE") ? atoi(getenv("DSDGP_KUU_REUSE")) : 1;
+  const bool keep_kuu = reuse_on && m->track_theta && m->kuu_valid;
+  hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
                      m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
-                     m->prep_blocks);
+                     m->prep_blocks, keep_kuu ? 1 : 0);
   DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
-  if (m->uniform_big) {
+  if (keep_kuu) {
+    // Z and the kernel hyper-parameters are those of the previous evaluation: Lu, Lu^-1, log det stay
+  } else if (m->uniform_big) {
     DS_TRY(bigchol_run(ctx, m->big_all));
   } else if (mp_max >= big_mp(false)) {
     for (int l = 0; l < L; ++l) {
@@ -1333,6 +1339,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   }
   m->prepared = true;
   m->prepared_grad = with_grad;
+  m->kuu_valid = true;
   return DSDGP_OK;
 }
 
@@ -1726,6 +1733,20 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
                      lr_t, beta1, beta2, eps);
   DS_HIP(hipGetLastError());
   m->prepared = false;
+  m->kuu_valid = false;
+  return DSDGP_OK;
+}
+
+extern "C" int dsdgp_model_track_theta(dsdgp_model* m, int enable) {
+  DS_CHECK_ARG(m != nullptr);
+  m->track_theta = enable != 0;
+  m->kuu_valid = false;
+  return DSDGP_OK;
+}
+extern "C" int dsdgp_model_theta_changed(dsdgp_model* m) {
+  DS_CHECK_ARG(m != nullptr);
+  m->prepared = false;
+  m->kuu_valid = false;
   return DSDGP_OK;
 }
 

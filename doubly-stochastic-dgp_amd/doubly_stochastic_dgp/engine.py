@@ -230,6 +230,7 @@ class Engine:
                 tA.copy_(self.ctx.torch.as_tensor(np.ascontiguousarray(mf.A._value, dtype=np.float64)))
             th = self._pack_host()
             self.theta.copy_(self.ctx.torch.as_tensor(th))
+            _lib.check(self.lib.dsdgp_model_theta_changed(self.model))     # our side of dsdgp_model_track_theta
             self._host_dirty = False
             self._dev_dirty = False
             self._needs_prepare = True
@@ -282,6 +283,9 @@ class Engine:
                                                ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
                                                C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
         self.model = h
+        # this engine is the only writer of theta besides the library's own optimiser steps and reports its uploads
+        # (_upload_if_needed): an evaluation after a natural-gradient step alone keeps the factorisation of Ku
+        _lib.check(self.lib.dsdgp_model_track_theta(self.model, 1))
         self.n_max, self.s_max = n_max, s_max
         if getattr(self, "_sample_w", None) is not None:       # DGP_Quad weights survive a model re-creation
             self.set_sample_weights(self._sample_w)

@@ -175,6 +175,15 @@ int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2,
  * info (host, may be NULL): non-zero if the updated covariance is not SPD. */
 int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info);
 
+/* Optional contract for callers that alternate optimisers (demo_regression_UCI.ipynb:360-366: one Adam step on the hyper-parameters,
+ * one natural-gradient step on the last layer).  theta is caller-owned, so every evaluation normally rebuilds Ku, its Cholesky
+ * factor and the inverses (layers.py:167-175 build_cholesky_if_needed).  With tracking enabled the caller promises to report its
+ * own writes to theta through dsdgp_model_theta_changed; an evaluation whose only change since the previous one came from
+ * dsdgp_model_natgrad_step — which leaves Z and the kernel hyper-parameters untouched — then keeps Lu, Lu^-1 and Ku^-1 and only
+ * rebuilds what depends on (q_mu, q_sqrt).  dsdgp_model_adam_step always invalidates. */
+int dsdgp_model_track_theta(dsdgp_model* m, int enable);
+int dsdgp_model_theta_changed(dsdgp_model* m);
+
 /* SVGP_Layer.KL (layers.py:221-246) of layer l after dsdgp_model_prepare; out: device scalar. */
 int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out);
 

@@ -521,3 +521,38 @@ def test_backward_d_split_forced_on_small_shapes(monkeypatch):
         e1 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
         e2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
         assert e1 == e2
+
+
+def test_factorisation_kept_after_natgrad_step_is_bitwise_neutral():
+    """dsdgp_model_track_theta: an evaluation that follows a natural-gradient step alone keeps Lu / Lu^-1 / Ku^-1 (Z and the kernel
+    hyper-parameters did not move).  Same alternating Adam / NatGrad schedule on two identical models, one of which reports a
+    (fictitious) write to theta before every evaluation and therefore refactorises every time: identical ELBOs and parameters."""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(8)
+    N, D, M, S = 120, 3, 40, 4
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2)]
+    _, _, a = make_case(X, Y, Z, specs, S=S, num_data=500)
+    _, _, b = make_case(X, Y, Z, specs, S=S, num_data=500)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    vals = []
+    for model, refactor in ((a, False), (b, True)):
+        eng = model.engine()
+        out = []
+        for it in range(3):
+            if refactor:
+                eng._upload_if_needed()
+                _lib.check(eng.lib.dsdgp_model_theta_changed(eng.model))
+            model.train_step(0.01, X=X, Y=Y, zs=zs)                       # Adam: invalidates everything
+            if refactor:
+                _lib.check(eng.lib.dsdgp_model_theta_changed(eng.model))
+            model._build_likelihood(X, Y, zs=zs, with_grad=True)          # gradient for the natural-gradient step
+            eng.natgrad_step(len(model.layers) - 1, 0.1)
+            if refactor:
+                _lib.check(eng.lib.dsdgp_model_theta_changed(eng.model))
+            out.append(model._build_likelihood(X, Y, zs=zs, with_grad=True))   # follows the natgrad step alone: Ku side reused
+        vals.append((out, eng.theta.cpu().numpy().copy(), eng.grad.cpu().numpy().copy()))
+    assert vals[0][0] == vals[1][0]
+    assert np.array_equal(vals[0][1], vals[1][1])
+    assert np.array_equal(vals[0][2], vals[1][2])
