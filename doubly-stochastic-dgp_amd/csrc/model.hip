@@ -76,6 +76,10 @@ struct LayerState {
   GemmProblem* ng_gp;  // device: 5 natural-gradient GEMM problems (H, Sinv | Y | X | Splus)
   PotrfItem* ng_items; // device: 2 * D_out factorisation items (A_d, then Splus_d)
   int ng_t1, ng_t2, ng_t3, ng_t4;
+  // the products of THIS layer that depend on (q_mu, q_sqrt) only, as launches of their own (prepare after a natural-gradient
+  // step on this layer alone: the other layers' S_d / U_d / ... are still those of the previous evaluation)
+  GemmProblem* lq = nullptr;
+  int lq_nf = 0, lq_tf = 0, lq_n1 = 0, lq_t1 = 0, lq_n2 = 0, lq_t2 = 0, lq_np = 0, lq_tp = 0;   // forward / U, n, KS / U U^T / P_d T_d, GS_d
   WgradJob* wj;        // device: (1 + D_out) big jobs followed by 2 thin jobs, rebuilt when (n, S) changes
   int ns_big, ns_thin, tot_big, tot_thin;
   // z actually used by the last forward (for the backward pass)
@@ -110,6 +114,8 @@ struct dsdgp_model {
   bool prepared_grad = false;  // the last prepare also produced U_d, n, U_d U_d^T
   bool track_theta = false;    // dsdgp_model_track_theta: the caller reports its writes to theta
   bool kuu_valid = false;      // Lu / Lu^-1 / Ku^-1 belong to the Z and kernel hyper-parameters currently in theta
+  int grad_first = 0;          // dsdgp_model_set_grad_first_layer: reverse mode stops below this layer
+  int q_dirty = -2;            // with kuu_valid: -1 nothing changed, l >= 0 only layer l's (q_mu, q_sqrt) changed, -2 unknown / several
   bool side_pending = false;   // parameter-only work (Ku^-1, S_d, KL, U, UU) still running on the side stream
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
   const double* sample_w = nullptr;   // DGP_Quad quadrature weights (borrowed), NULL = Monte-Carlo mean
@@ -318,6 +324,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     // d-split of the backward chain on small launches (at most 1024 workgroups): partial abar tiles + arrival counters
     S.bpart = sm_chain_enabled() ? b.take<double>((size_t)1024 * (Mp * 16 + 16)) : nullptr;
     S.bcnt = sm_chain_enabled() ? b.take<int>(512) : nullptr;
+    S.lq = b.take<GemmProblem>(12);
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -1113,6 +1120,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     const int Mp = v.Mp;
     const int64_t MM = (int64_t)Mp * Mp;
     GemmProblem P;
+    const size_t gf0 = gf.size() + 1, g10 = g1.size(), g20 = g2.size(), gp0 = gpt.size();   // this layer's q-dependent problems (Ku^-1 excluded)
     fill_gemm(P, v.LinvT, v.Linv, v.Kinv, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, 1, 0, 0, 0, 0);              // Ku^-1
     P.lower_only = 1; P.tri = 8 | 1 | 16;                                                              //   upper x lower, symmetric
     gf.push_back(P);
@@ -1149,6 +1157,23 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     if (v.D_in > WIDE_DIN) {
       fill_gemm(P, v.wm, v.Zp1, v.WZ, Mp, v.DinP16, Mp, Mp, v.DinP16, v.DinP16, 0, 0, 1, 0, 0, 0, 0);  // wm [Z | 1]
       wz.push_back(P);
+    }
+    {
+      LayerState& Sq = m->L[l];
+      std::vector<GemmProblem> lq(gf.begin() + gf0, gf.end());
+      Sq.lq_nf = (int)lq.size();
+      Sq.lq_tf = gemm_plan(lq.data(), Sq.lq_nf);
+      std::vector<GemmProblem> q1(g1.begin() + g10, g1.end()), q2(g2.begin() + g20, g2.end());
+      Sq.lq_n1 = (int)q1.size(); Sq.lq_t1 = gemm_plan(q1.data(), Sq.lq_n1);
+      Sq.lq_n2 = (int)q2.size(); Sq.lq_t2 = gemm_plan(q2.data(), Sq.lq_n2);
+      std::vector<GemmProblem> qp(gpt.begin() + gp0, gpt.end());
+      Sq.lq_np = (int)qp.size(); Sq.lq_tp = gemm_plan(qp.data(), Sq.lq_np);
+      lq.insert(lq.end(), q1.begin(), q1.end());
+      lq.insert(lq.end(), q2.begin(), q2.end());
+      lq.insert(lq.end(), qp.begin(), qp.end());
+      DS_CHECK_ARG(lq.size() <= 12);
+      DS_HIP(hipMemcpyAsync(Sq.lq, lq.data(), lq.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
+      DS_HIP(hipStreamSynchronize(st));
     }
     m->kuu_blocks = std::max(m->kuu_blocks, std::min(1024, (Mp / 16) * (Mp / 16)));
     asm_elems = std::max<int64_t>(asm_elems, (int64_t)v.D_out * v.M * v.M);
@@ -1324,22 +1349,44 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     st = m->side;
   }
-  DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
   const int klb = mp_max >= 512 ? 512 : NPART;    // M = 512 / 1024: V alone is 8..64 MB per layer — 32 workgroups were latency-bound
-  hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
+  // only layer lq's (q_mu, q_sqrt) moved since an evaluation that produced everything this one needs: its products alone
+  const int gfirst = (with_grad && !m->desc.white) ? m->grad_first : 0;
+  const int lq = (keep_kuu && m->q_dirty >= 0 && (m->prepared_grad || !with_grad)) ? m->q_dirty : -1;
+  if (lq >= 0) {
+    LayerState& Sq = m->L[lq];
+    DS_TRY(gemm_launch(ctx, Sq.lq, Sq.lq_nf, Sq.lq_tf, st));
+    hipLaunchKernelGGL(k_kl_part, dim3(klb, 1), dim3(256), 0, st, m->layers_dev + lq);
+  } else {
+    DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
+    hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
+  }
   hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, st, m->layers_dev, L, klb);
   DS_HIP(hipGetLastError());
   if (with_grad && !m->desc.white) {
-    DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1, st));
-    DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2, st));
+    if (lq >= 0) {
+      LayerState& Sq = m->L[lq];
+      DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf, Sq.lq_n1, Sq.lq_t1, st));
+      DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf + Sq.lq_n1, Sq.lq_n2, Sq.lq_t2, st));
+    } else if (gfirst > 0) {
+      for (int l = gfirst; l < L; ++l) {
+        LayerState& Sq = m->L[l];
+        DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf, Sq.lq_n1, Sq.lq_t1, st));
+        DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf + Sq.lq_n1, Sq.lq_n2, Sq.lq_t2, st));
+      }
+    } else {
+      DS_TRY(gemm_launch(ctx, m->gp_bwd1, m->n_bwd1, m->t_bwd1, st));
+      DS_TRY(gemm_launch(ctx, m->gp_bwd2, m->n_bwd2, m->t_bwd2, st));
+    }
   }
   if (side) {
     DS_HIP(hipEventRecord(m->ev_prep_side, m->side));
     m->side_pending = true;
   }
   m->prepared = true;
-  m->prepared_grad = with_grad;
+  m->prepared_grad = with_grad && gfirst == 0;     // (a partial prepare with_grad required the previous one to have had it)
   m->kuu_valid = true;
+  m->q_dirty = -1;
   return DSDGP_OK;
 }
 
@@ -1557,7 +1604,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   DS_TRY(ensure_plan(m, n, S));
   const bool overlap = overlap_on(m, n, S);
   DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
-  for (int l = L - 1; l >= 0; --l) {
+  const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
+  for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
     const bool last = (l == L - 1);
@@ -1578,8 +1626,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
     b.flags = dbg_flags(); b.Asave = St.A; b.Csave = St.c_used ? St.C : nullptr; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
-    b.dX = (l > 0) ? m->L[l - 1].dF : nullptr;
-    if (sm && l >= 2) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
+    b.dX = (l > gfirst) ? m->L[l - 1].dF : nullptr;
+    if (sm && l >= 2 && l > gfirst) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
       LayerState& Pv = m->L[l - 1];
       b.dX = nullptr;
       b.MBp = Pv.MB; b.VBp = Pv.VB;
@@ -1628,13 +1676,21 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     hipLaunchKernelGGL(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
     DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
     DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
+  } else if (gfirst > 0) {
+    for (int l = gfirst; l < L; ++l) {
+      LayerState& Sq = m->L[l];
+      DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf + Sq.lq_n1 + Sq.lq_n2, Sq.lq_np, Sq.lq_tp));
+    }
   } else {
     DS_TRY(gemm_launch(ctx, m->gp_pt, m->n_pt, m->t_pt));
   }
-  hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, L), dim3(256), 0, ctx->stream, m->layers_dev, kl_weight);
-  if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
-  if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, L), dim3(256), 0, ctx->stream, m->layers_dev);
-  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, L), dim3(256), 0, ctx->stream, m->layers_dev, m->grad, kl_weight);
+  // the assembly of the layers that took part (their gradient entries; those of the layers below gfirst keep their old content)
+  const LayerDev* lay = m->layers_dev + gfirst;
+  const int La = L - gfirst;
+  hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, La), dim3(256), 0, ctx->stream, lay, kl_weight);
+  if (m->n_wz && gfirst == 0) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
+  if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, La), dim3(256), 0, ctx->stream, lay);
+  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, La), dim3(256), 0, ctx->stream, lay, m->grad, kl_weight);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -1734,19 +1790,27 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
   DS_HIP(hipGetLastError());
   m->prepared = false;
   m->kuu_valid = false;
+  m->q_dirty = -2;
   return DSDGP_OK;
 }
 
+extern "C" int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first) {
+  DS_CHECK_ARG(m && first >= 0 && first < m->desc.L);
+  m->grad_first = first;
+  return DSDGP_OK;
+}
 extern "C" int dsdgp_model_track_theta(dsdgp_model* m, int enable) {
   DS_CHECK_ARG(m != nullptr);
   m->track_theta = enable != 0;
   m->kuu_valid = false;
+  m->q_dirty = -2;
   return DSDGP_OK;
 }
 extern "C" int dsdgp_model_theta_changed(dsdgp_model* m) {
   DS_CHECK_ARG(m != nullptr);
   m->prepared = false;
   m->kuu_valid = false;
+  m->q_dirty = -2;
   return DSDGP_OK;
 }
 
@@ -1902,6 +1966,7 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   hipLaunchKernelGGL(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
   m->prepared = false;
+  m->q_dirty = (m->q_dirty == -1 || m->q_dirty == l) ? l : -2;     // Z and the kernel hyper-parameters are untouched: kuu_valid stays
   if (info) {
     std::vector<double> sc(4 * v.D_out);
     DS_HIP(hipMemcpyAsync(sc.data(), v.ngScal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

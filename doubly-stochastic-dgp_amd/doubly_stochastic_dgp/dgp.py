@@ -168,7 +168,7 @@ class DGP_Base(Parameterized):
         return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64))
 
     # dgp.py:92-98
-    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False):
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0):
         eng = self.engine()
         if X is None:
             X, Y = self.next_minibatch()
@@ -178,7 +178,7 @@ class DGP_Base(Parameterized):
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)                 # dgp.py:96-97
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
-                       kl_weight=klw, with_grad=with_grad, sync=allreduce is None)
+                       kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer)
         if allreduce is not None:
             out = allreduce(eng, with_grad)
         return float(out[0])
@@ -267,8 +267,8 @@ class DGP_Quad(DGP_Base):
         Fmean, Fvar = self._build_predict(X, full_cov=False, S=self.num_samples, zs=self.gh_x)
         return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64), weights=self.gh_w)
 
-    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False):
-        return DGP_Base._build_likelihood(self, X, Y, zs=self.gh_x, with_grad=with_grad)
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0):
+        return DGP_Base._build_likelihood(self, X, Y, zs=self.gh_x, with_grad=with_grad, grad_from_layer=grad_from_layer)
 
     def train_step(self, *args, **kwargs):
         kwargs["zs"] = self.gh_x

@@ -283,6 +283,7 @@ class Engine:
                                                ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
                                                C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
         self.model = h
+        self._grad_first = 0
         # this engine is the only writer of theta besides the library's own optimiser steps and reports its uploads
         # (_upload_if_needed): an evaluation after a natural-gradient step alone keeps the factorisation of Ku
         _lib.check(self.lib.dsdgp_model_track_theta(self.model, 1))
@@ -348,13 +349,19 @@ class Engine:
                                                   arrs["mean"], arrs["var"]))
         return outs["F"], outs["mean"], outs["var"]
 
-    def elbo(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, with_grad=False, sync=True):
+    def elbo(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, with_grad=False, sync=True, grad_from_layer=0):
+        """grad_from_layer = l > 0: the reverse pass stops below layer l, as tf.gradients(loss, var_list) does for a var_list of
+        upper-layer (q_mu, q_sqrt) pairs (NatGradOptimizer); the gradient entries of the lower layers are then NOT updated."""
         Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
         Yd = Y if hasattr(Y, "data_ptr") else self.ctx.to_device(Y)
         n = Xd.shape[0]
         self._ensure(n, S)
         self._upload_if_needed()
         zp, zst, keep = self._zs_args(zs, S, n)
+        gfl = int(grad_from_layer) if with_grad else 0
+        if gfl != getattr(self, "_grad_first", 0):
+            _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, gfl))
+            self._grad_first = gfl
         _lib.check(self.lib.dsdgp_model_elbo(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed),
                                              float(data_scale), float(kl_weight), int(with_grad), ptr(self.out4)))
         if not sync:

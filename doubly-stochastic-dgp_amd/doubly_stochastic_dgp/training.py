@@ -35,7 +35,8 @@ class NatGradOptimizer:
         layers = self._layer_indices(model, var_list)
         eng = model.engine()
         for _ in range(int(maxiter)):
-            model._build_likelihood(X, Y, zs=zs, with_grad=True)
+            # tf.gradients w.r.t. var_list only: the reverse pass stops below the lowest layer in it
+            model._build_likelihood(X, Y, zs=zs, with_grad=True, grad_from_layer=min(layers))
             for l in layers:
                 eng.natgrad_step(l, self.gamma)
         eng.ctx.sync()

@@ -175,6 +175,13 @@ int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2,
  * info (host, may be NULL): non-zero if the updated covariance is not SPD. */
 int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info);
 
+/* [UPSTREAM] tf.gradients(loss, var_list) with var_list = the (q_mu, q_sqrt) of the upper layer(s), as
+ * NatGradOptimizer.minimize(var_list=[[last.q_mu, last.q_sqrt]]) builds it: TensorFlow prunes the reverse pass below the
+ * lowest layer in var_list.  After this call dsdgp_model_elbo(with_grad=1) runs the reverse pass for layers >= first only;
+ * the gradient entries of the layers below keep their previous content (do NOT follow with dsdgp_model_adam_step).
+ * first = 0 restores the full gradient.  Ignored (full gradient) for white=True models. */
+int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first);
+
 /* Optional contract for callers that alternate optimisers (demo_regression_UCI.ipynb:360-366: one Adam step on the hyper-parameters,
  * one natural-gradient step on the last layer).  theta is caller-owned, so every evaluation normally rebuilds Ku, its Cholesky
  * factor and the inverses (layers.py:167-175 build_cholesky_if_needed).  With tracking enabled the caller promises to report its

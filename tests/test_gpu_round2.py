@@ -556,3 +556,35 @@ def test_factorisation_kept_after_natgrad_step_is_bitwise_neutral():
     assert vals[0][0] == vals[1][0]
     assert np.array_equal(vals[0][1], vals[1][1])
     assert np.array_equal(vals[0][2], vals[1][2])
+
+
+def test_natgrad_with_pruned_reverse_pass_matches_full_gradient():
+    """NatGradOptimizer.minimize evaluates the gradient w.r.t. its var_list only (dsdgp_model_set_grad_first_layer: the reverse
+    pass stops below the lowest layer in it, as tf.gradients does).  The natural-gradient step from the pruned pass must be the
+    one from the full gradient, bit for bit, and a following full-gradient evaluation must be unaffected."""
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(18)
+    N, D, M, S = 90, 3, 30, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.01 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("matern52", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
+    _, _, a = make_case(X, Y, Z, specs, S=S, num_data=400)
+    _, _, b = make_case(X, Y, Z, specs, S=S, num_data=400)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
+    last = len(a.layers) - 1
+    # a: the optimiser's own (pruned) path ; b: full gradient, then the same step
+    NatGradOptimizer(0.05).minimize(a, var_list=[[a.layers[-1].q_mu, a.layers[-1].q_sqrt]], maxiter=2, X=X, Y=Y, zs=zs)
+    for _ in range(2):
+        b._build_likelihood(X, Y, zs=zs, with_grad=True)
+        b.engine().natgrad_step(last, 0.05)
+    assert np.array_equal(a.engine().theta.cpu().numpy(), b.engine().theta.cpu().numpy())
+    ea = a._build_likelihood(X, Y, zs=zs, with_grad=True)
+    eb = b._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert ea == eb
+    assert np.array_equal(a.engine().grad.cpu().numpy(), b.engine().grad.cpu().numpy())
+    # two layers in the var_list: pruned below the lower one
+    NatGradOptimizer(0.02).minimize(a, var_list=[[l.q_mu, l.q_sqrt] for l in a.layers[1:]], X=X, Y=Y, zs=zs)
+    b._build_likelihood(X, Y, zs=zs, with_grad=True)
+    for l in (1, 2):
+        b.engine().natgrad_step(l, 0.02)
+    assert np.array_equal(a.engine().theta.cpu().numpy(), b.engine().theta.cpu().numpy())
