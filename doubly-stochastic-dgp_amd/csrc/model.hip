@@ -1463,14 +1463,15 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     a.mean = (Fmeans && Fmeans[l]) ? Fmeans[l] : St.mean;
     a.var = (Fvars && Fvars[l]) ? Fvars[l] : St.var;
     a.ldA = round_up(Rin, 16);
-    a.Asave = save ? St.A : nullptr;
+    const bool save_l = save && (m->desc.white || l >= m->grad_first);    // layers below the pruned reverse pass keep nothing for it
+    a.Asave = save_l ? St.A : nullptr;
     // c_d is kept for the backward chain where that pays: enough row blocks to hide the extra latency per output (the N-row first
     // layer is a latency-bound launch) and enough outputs for the halved d-loop to matter
     // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
-    St.c_used = save && St.C && sm_cs_built(v.Mp) && (v.Mp > 256 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
+    St.c_used = save_l && St.C && sm_cs_built(v.Mp) && (v.Mp > 256 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
     a.Csave = St.c_used ? St.C : nullptr;
     a.flags = dbg_flags();
-    a.XT1 = (save && sm_chain_enabled()) ? St.XT1 : nullptr;
+    a.XT1 = (save_l && sm_chain_enabled()) ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
       a.d_split = chain_d_split(nblk, v.D_out);
