@@ -30,7 +30,7 @@ static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
 }
 // waves per row block of the instance that a launch of this shape takes
 static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {
-  return Mp > 512 ? 16 : (Mp > 256 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
+  return (Mp > 512 || (Mp == 512 && D_in <= XCH && !bwd)) ? 16 : (Mp > 256 ? 8 : (sm_small(Mp, nblk, D_in, bwd) ? 8 : 4));
 }
 // rows of hyp_part the backward chain writes (one per wave)
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in, true) * ceil_div(ld, 16); }

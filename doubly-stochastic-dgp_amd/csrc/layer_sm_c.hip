@@ -3,6 +3,13 @@
 
 int layer_fwd_sm_c(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white, int small) {
   const bool wide = a.D_in > XCH;
+  if (Mp == 512 && !wide) {      // forward chain only: 16 waves (four per SIMD at one workgroup per CU) measured -8 % there and +2 % on the
+                                 // backward chain (config 4); the wide instance's staging would not fit the LDS with 16 waves
+    switch (Mp) {
+      SM_CASE(fwd_sm_go, 32, 16, (ctx, a))
+      default: break;
+    }
+  }
   switch (Mp) {
     SM_CASE(fwd_sm_go, 20, 8, (ctx, a))
     SM_CASE(fwd_sm_go, 24, 8, (ctx, a))
