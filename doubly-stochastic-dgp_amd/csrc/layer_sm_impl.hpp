@@ -15,6 +15,9 @@
 
 #include "layer.hpp"
 
+#ifndef HYP_MFMA
+#define HYP_MFMA 1
+#endif
 #define XCH 64   // columns of x/l staged per chunk
 
 // Operand order of the chain GEMMs — two variants, chosen per instance (measured, tools/ab_kernels.py):
@@ -878,8 +881,8 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
         }
       }
     }
-    if constexpr (WIDE) {
-      // Wide inputs: the sums over this wave's inducing rows run on the MFMA pipe, 16 input dimensions at a time.
+    if constexpr (WIDE || HYP_MFMA) {
+      // The sums over this wave's inducing rows run on the MFMA pipe, 16 input dimensions at a time.
       //   WZ[j][c] = sum_m z[m][j] w[m][c],  Z2[j][c] = sum_m z[m][j]^2 w[m][c]   (A = Zs^T tile: lane (g, c) loads row 16 ib + g + 4 t,
       //   dimension c of the group — 128-byte runs; B = w, which sits in the accumulator layout = the B layout of k-steps t)
       //   d X partial: sum_m w (x - z) = x W1 - WZ          lengthscale partial: sum_m,c w (x - z)^2 = sum_c (x^2 W1 - 2 x WZ + Z2)
