@@ -15,9 +15,6 @@
 
 #include "layer.hpp"
 
-#ifndef HYP_MFMA
-#define HYP_MFMA 1
-#endif
 #define XCH 64   // columns of x/l staged per chunk
 
 // Operand order of the chain GEMMs — two variants, chosen per instance (measured, tools/ab_kernels.py):
@@ -881,97 +878,52 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
         }
       }
     }
-    if constexpr (WIDE || HYP_MFMA) {
-      // The sums over this wave's inducing rows run on the MFMA pipe, 16 input dimensions at a time.
-      //   WZ[j][c] = sum_m z[m][j] w[m][c],  Z2[j][c] = sum_m z[m][j]^2 w[m][c]   (A = Zs^T tile: lane (g, c) loads row 16 ib + g + 4 t,
-      //   dimension c of the group — 128-byte runs; B = w, which sits in the accumulator layout = the B layout of k-steps t)
-      //   d X partial: sum_m w (x - z) = x W1 - WZ          lengthscale partial: sum_m,c w (x - z)^2 = sum_c (x^2 W1 - 2 x WZ + Z2)
-      // with W1[c] = sum_m w[m][c].  One element-by-element pass per dimension (16 L2 loads, two cross-lane reductions) took
-      // 1.93 M of the 5.2 M clocks of the 784-dimensional first layer of config 4 (profiles/r02_chain_phases.txt).
-      double w1 = 0.0;
+    // The sums over this wave's inducing rows run on the MFMA pipe, 16 input dimensions at a time.
+    //   WZ[j][c] = sum_m z[m][j] w[m][c],  Z2[j][c] = sum_m z[m][j]^2 w[m][c]   (A = Zs^T tile: lane (g, c) loads row 16 ib + g + 4 t,
+    //   dimension c of the group — 128-byte runs; B = w, which sits in the accumulator layout = the B layout of k-steps t)
+    //   d X partial: sum_m w (x - z) = x W1 - WZ          lengthscale partial: sum_m,c w (x - z)^2 = sum_c (x^2 W1 - 2 x WZ + Z2)
+    // with W1[c] = sum_m w[m][c].  One element-by-element pass per dimension (16 L2 loads, two cross-lane reductions) took
+    // 1.93 M of the 5.2 M clocks of the 784-dimensional first layer of config 4 and 22 K of the 59 K clocks of a D_out = 1 workgroup
+    // of config 2 (profiles/r02_chain_phases.txt); this form 0.41 M and 12 K.
+    double w1 = 0.0;
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w1 += bb[q][t];           // rows beyond M and skipped blocks hold 0
+    }
+    w1 = sum_groups(w1);
+    for (int kk = 0; kk < jn; kk += 16) {
+      d4 wz = (d4){0, 0, 0, 0}, z2 = (d4){0, 0, 0, 0};
       if (act) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) w1 += bb[q][t];           // rows beyond M and skipped blocks hold 0
-      }
-      w1 = sum_groups(w1);
-      for (int kk = 0; kk < jn; kk += 16) {
-        d4 wz = (d4){0, 0, 0, 0}, z2 = (d4){0, 0, 0, 0};
-        if (act) {
-          const int jc = (kk + c < jn) ? kk + c : jn - 1;       // clamped (unconditional) loads; dimensions past jn are dropped below
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int ib = Own<MPB, NW>::ib(wave, q);
-            if (Own<MPB, NW>::skip(ib)) continue;
-            double zv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) zv[t] = zs[(int64_t)(16 * ib + g + 4 * t) * Din + j0 + jc];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              wz = mfma_f64(zv[t], bb[q][t], wz);
-              z2 = mfma_f64(zv[t] * zv[t], bb[q][t], z2);
-            }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int j = kk + g + 4 * t;                           // accumulator row = dimension kk + g + 4 t, column c
-          const bool in = j < jn;
-          const double xv = xs[c * (jn + 1) + (in ? j : jn - 1)];
-          if ((a.dX || a.MBp) && in) redx[(wave * jn + j) * 16 + c] = act ? fma(xv, w1, -wz[t]) : 0.0;
-          double sl = act ? fma(xv * xv, w1, fma(-2.0 * xv, wz[t], z2[t])) : 0.0;
-          sl += dpp_or_zero<0x111, 0xf>(sl);                      // sum over the 16 columns of this row of lanes (-> lane c = 15)
-          sl += dpp_or_zero<0x112, 0xf>(sl);
-          sl += dpp_or_zero<0x114, 0xf>(sl);
-          sl += dpp_or_zero<0x118, 0xf>(sl);
-          if (c == 15 && in) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
-        }
-      }
-    } else {
-    // four input dimensions at a time: their 16 Z loads are in flight together (one dimension per pass exposed an L1 / L2 round
-    // trip per dimension: 20 K of the 59 K clocks of a D_out = 1 workgroup at config 2, profiles/r02_bwd_phases.txt)
-    constexpr int JG = (NQ <= 2) ? 2 : 1;       // more in flight costs registers: JG = 4 took the M = 128 instance from 3 to 2 workgroups per CU
-    for (int jg = 0; jg < jn; jg += JG) {
-      double sxv[JG], slv[JG];
-#pragma unroll
-      for (int u = 0; u < JG; ++u) sxv[u] = slv[u] = 0.0;
-      if (act) {
-        double xv[JG];
-#pragma unroll
-        for (int u = 0; u < JG; ++u) xv[u] = xs[c * (jn + 1) + (jg + u < jn ? jg + u : jn - 1)];
+        const int jc = (kk + c < jn) ? kk + c : jn - 1;       // clamped (unconditional) loads; dimensions past jn are dropped below
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           if (Own<MPB, NW>::skip(ib)) continue;
+          double zv[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) zv[t] = zs[(int64_t)(16 * ib + g + 4 * t) * Din + j0 + jc];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const double* __restrict__ zr = zs + (int64_t)(16 * ib + g + 4 * t) * Din + j0;
-            double zv[JG];
-#pragma unroll
-            for (int u = 0; u < JG; ++u) zv[u] = zr[jg + u < jn ? jg + u : jn - 1];
-#pragma unroll
-            for (int u = 0; u < JG; ++u) {
-              const double df = xv[u] - zv[u];
-              const double wdf = bb[q][t] * df;
-              sxv[u] += wdf;
-              slv[u] = fma(wdf, df, slv[u]);
-            }
+            wz = mfma_f64(zv[t], bb[q][t], wz);
+            z2 = mfma_f64(zv[t] * zv[t], bb[q][t], z2);
           }
         }
       }
 #pragma unroll
-      for (int u = 0; u < JG; ++u) {
-        const int j = jg + u;
-        if (j >= jn) break;
-        if (a.dX || a.MBp) {
-          const double sx = sum_groups(sxv[u]);
-          if (g == 0) redx[(wave * jn + j) * 16 + c] = sx;
-        }
-        const double sl = sum_wave(slv[u]);
-        if (lane == 0) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
+      for (int t = 0; t < 4; ++t) {
+        const int j = kk + g + 4 * t;                           // accumulator row = dimension kk + g + 4 t, column c
+        const bool in = j < jn;
+        const double xv = xs[c * (jn + 1) + (in ? j : jn - 1)];
+        if ((a.dX || a.MBp) && in) redx[(wave * jn + j) * 16 + c] = act ? fma(xv, w1, -wz[t]) : 0.0;
+        double sl = act ? fma(xv * xv, w1, fma(-2.0 * xv, wz[t], z2[t])) : 0.0;
+        sl += dpp_or_zero<0x111, 0xf>(sl);                      // sum over the 16 columns of this row of lanes (-> lane c = 15)
+        sl += dpp_or_zero<0x112, 0xf>(sl);
+        sl += dpp_or_zero<0x114, 0xf>(sl);
+        sl += dpp_or_zero<0x118, 0xf>(sl);
+        if (c == 15 && in) hp[2 + j0 + j] = -2.0 * ils[j0 + j] * sl;
       }
-    }
     }
     if (a.dX || a.MBp) {
       __syncthreads();
