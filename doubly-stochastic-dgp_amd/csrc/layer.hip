@@ -497,9 +497,16 @@ __device__ __forceinline__ void wgrad_loop(gcptr Pp, gcptr Qp, gcptr scale, int6
     d4 pa[NI], qb[NJ];
 #pragma unroll
     for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Pp + (int64_t)16 * ii * ld + rb);
+    if constexpr (DIAG) {
+      // diagonal tile of a symmetric product: Q's rows ARE P's rows — no second load (a third less operand traffic per P_d at Mw = 128;
+      // the launch moves ~5.6 TB/s out of L2 / Infinity Cache and did not get faster with deeper prefetch: bandwidth, not latency)
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-      if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Qp + (int64_t)16 * jj * ld + rb);
+      for (int jj = 0; jj < NJ; ++jj) qb[jj] = pa[jj];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Qp + (int64_t)16 * jj * ld + rb);
+    }
     if (scale) {
       const d4 sc = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(scale + rb + 4 * g);
 #pragma unroll
