@@ -164,11 +164,12 @@ def sub_rooflines(ctx):
         ctx.prof_read("potrf")
         reps = 5
         for _ in range(reps):
+            _lib.check(e1.lib.dsdgp_model_theta_changed(e1.model))     # else the unchanged Ku keeps its factor (dsdgp_model_track_theta)
             e1._needs_prepare = True
             e1.prepare()
         ms, cnt = ctx.prof_read("potrf")
         fl = 2.0 * M ** 3 / 3.0
-        tf = fl / (ms / reps * 1e-3) / 1e12
+        tf = fl / (max(ms, 1e-9) / reps * 1e-3) / 1e12
         out["potrf_trtri"].append(dict(n=M, us=round(1e3 * ms / reps, 1), algorithmic_gflop=round(fl / 1e9, 3), bound="mfma",
                                        achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                        frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
