@@ -116,6 +116,76 @@ static inline SmLds sm_lds(int Mp, int D_in, int D_out, int NW, bool wide, int n
   return L;
 }
 
+// One staged chunk (jn columns of x / l in xs, row stride jn + 1; Z columns j0 .. j0 + jn) of the MFMA distance form below, any jn:
+// clamped (unconditional) loads, masked afterwards.
+template <int NQ, int MPB, int NW>
+__device__ __forceinline__ void sqdist_chunk_masked(const double* __restrict__ zs, const double* xs, int Din, int j0, int jn, int wave,
+                                                    int g, int c, d4 (&zx)[NQ], double (&zsq)[NQ], double& xx) {
+  for (int kk = 0; kk < jn; kk += 16) {
+    double b[4];
+    int jc[4];
+    bool in[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int j = kk + 4 * g + s;
+      in[s] = j < jn;
+      jc[s] = in[s] ? j : jn - 1;
+      const double v = xs[c * (jn + 1) + jc[s]];
+      b[s] = in[s] ? v : 0.0;
+      xx = fma(b[s], b[s], xx);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ib = Own<MPB, NW>::ib(wave, q);
+      if (Own<MPB, NW>::skip(ib)) continue;
+      const double* __restrict__ zr = zs + (int64_t)(16 * ib + c) * Din + j0;
+      double av[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double v = zr[jc[s]];
+        av[s] = in[s] ? v : 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        zx[q] = mfma_f64(av[s], b[s], zx[q]);
+        zsq[q] = fma(av[s], av[s], zsq[q]);
+      }
+    }
+  }
+}
+// |z|^2 (per lane for row 16 ib + c) folded over g and turned into the accumulator layout through wave-private LDS; r2 >= 0
+template <int NQ>
+__device__ __forceinline__ void sqdist_finish(const d4 (&zx)[NQ], const double (&zsq)[NQ], double xx, double* scratch, int wave, int g,
+                                              int c, d4 (&r2)[NQ]) {
+  xx = sum_groups(xx);          // lane (g, c) covered the dimensions 4 g .. 4 g + 3 of every group of 16
+  double* zrow = scratch + wave * NQ * 16;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double zq = sum_groups(zsq[q]);          // |z|^2 of row 16 ib + c
+    if (g == 0) zrow[q * 16 + c] = zq;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double v = zrow[q * 16 + g + 4 * t] + xx - 2.0 * zx[q][t];
+      r2[q][t] = v > 0.0 ? v : 0.0;
+    }
+}
+// narrow inputs (D_in <= XCH, x / l already staged in xs by the caller, barrier passed): the same form in one chunk
+template <int NQ, int MPB, int NW>
+__device__ __forceinline__ void sqdist_narrow(const double* __restrict__ zs, const double* xs, int Din, int wave, int g, int c, bool act,
+                                              double* scratch, d4 (&r2)[NQ]) {
+  d4 zx[NQ];
+  double zsq[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { zx[q] = (d4){0, 0, 0, 0}; zsq[q] = 0.0; }
+  double xx = 0.0;
+  if (act) sqdist_chunk_masked<NQ, MPB, NW>(zs, xs, Din, 0, Din, wave, g, c, zx, zsq, xx);
+  sqdist_finish<NQ>(zx, zsq, xx, scratch, wave, g, c, r2);
+}
+
 // scaled squared distances of this wave's inducing rows to the block's 16 data rows, D layout, chunked over D_in (wide inputs).
 // r2[m][c] = |z_m|^2 + |x_c|^2 - 2 z_m . x_c on the MFMA pipe: lane (g, c) feeds A = Zs[16 ib + c][k], B = xs[c][k] with
 // k = 16-dimension group + 4 g + s in k-step s (any bijection of k works as long as A and B agree), so the product lands in the
@@ -170,55 +240,11 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
           }
         }
       } else {
-        for (int kk = 0; kk < jn; kk += 16) {
-          double b[4];
-          int jc[4];
-          bool in[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int j = kk + 4 * g + s;
-            in[s] = j < jn;
-            jc[s] = in[s] ? j : jn - 1;                      // unconditional (clamped) loads, masked afterwards
-            const double v = xs[c * (jn + 1) + jc[s]];
-            b[s] = in[s] ? v : 0.0;
-            xx = fma(b[s], b[s], xx);
-          }
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int ib = Own<MPB, NW>::ib(wave, q);
-            if (Own<MPB, NW>::skip(ib)) continue;
-            const double* __restrict__ zr = zs + (int64_t)(16 * ib + c) * Din + j0;
-            double av[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const double v = zr[jc[s]];
-              av[s] = in[s] ? v : 0.0;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              zx[q] = mfma_f64(av[s], b[s], zx[q]);
-              zsq[q] = fma(av[s], av[s], zsq[q]);
-            }
-          }
-        }
+        sqdist_chunk_masked<NQ, MPB, NW>(zs, xs, Din, j0, jn, wave, g, c, zx, zsq, xx);
       }
     }
   }
-  xx = sum_groups(xx);          // lane (g, c) covered the dimensions 4 g .. 4 g + 3 of every group of 16
-  double* zrow = scratch + wave * NQ * 16;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const double zq = sum_groups(zsq[q]);          // |z|^2 of row 16 ib + c
-    if (g == 0) zrow[q * 16 + c] = zq;
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double v = zrow[q * 16 + g + 4 * t] + xx - 2.0 * zx[q][t];
-      r2[q][t] = v > 0.0 ? v : 0.0;
-    }
+  sqdist_finish<NQ>(zx, zsq, xx, scratch, wave, g, c, r2);
 }
 
 #define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -262,6 +288,10 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       xs[rr * (Din + 1) + j] = a.X[row * Din + j] * ils[j];
     }
     __syncthreads();
+    // distances on the MFMA pipe (|z|^2 + |x|^2 - 2 z.x, see sm_sqdist): the element-by-element form — one L1 / L2 load and one FMA per
+    // (inducing row, data row, dimension) and lane — was 17 K of the 61 K clocks of a D_out = 1 workgroup at config 2
+    d4 r2[NQ];
+    sqdist_narrow<NQ, MPB, NW>(a.Zs, xs, Din, wave, g, c, act, red_s1, r2);
     if (act) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -270,13 +300,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = 16 * ib + g + 4 * t;
-          const double* __restrict__ zr = a.Zs + (int64_t)m * Din;
-          double r2 = 0.0;
-          for (int j = 0; j < Din; ++j) {
-            const double df = zr[j] - xs[c * (Din + 1) + j];
-            r2 = fma(df, df, r2);
-          }
-          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2, s2) : 0.0;
+          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
         }
       }
     }
@@ -361,20 +385,30 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   // a . q_mu (layers.py:190)
   FWD_STAMP(3);      // a
   if constexpr (MU_EARLY) {
-    // (four / two outputs per pass with their q_mu loads in flight together were tried: 143 / 95 VGPRs instead of 79 and no gain)
-    for (int d = 0; d < Dout; ++d) {
-      double mu = 0.0;
+    // mean partials mu[d][c] = sum_m q_mu[m][d] a[m][c] over this wave's rows on the MFMA pipe, 16 outputs at a time: A = q_mu^T
+    // (lane (g, c) loads row 16 ib + g + 4 t, output c), B = a in the accumulator layout.  The per-output scalar form (eight loads,
+    // eight FMAs and a cross-lane fold per output) was 16 K of the 169 K clocks of a D_out = 8 workgroup at config 2.
+    for (int d0 = 0; d0 < Dout; d0 += 16) {
+      d4 mu4 = (d4){0, 0, 0, 0};
       if (act) {
+        const bool din = d0 + c < Dout;
+        const int dc = din ? d0 + c : Dout - 1;                  // clamped (unconditional) loads, masked afterwards
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           if (Own<MPB, NW>::skip(ib)) continue;
+          double qv[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
+          for (int t = 0; t < 4; ++t) qv[t] = a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + dc];       // layers.py:190
+#pragma unroll
+          for (int t = 0; t < 4; ++t) mu4 = mfma_f64(din ? qv[t] : 0.0, acc[q][t], mu4);
         }
       }
-      mu = sum_groups(mu);
-      if (g == 0) red_mu[(wave * Dout + d) * 16 + c] = mu;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int d = d0 + g + 4 * t;
+        if (d < Dout) red_mu[(wave * Dout + d) * 16 + c] = mu4[t];
+      }
     }
   }
   __syncthreads();
@@ -805,8 +839,12 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   }
   BWD_STAMP(4);      // Ku^-1 product
   // E, kbar; recompute the Kuf tile for GW = kbar * dk/dr2
-  d4 r2[WIDE ? NQ : 1];
+  d4 r2[NQ];
   if constexpr (WIDE) sm_sqdist<NQ, MPB, NW>(zs, a.X, ils, xs, Din, r0, a.Rin, tid, wave, g, c, act, redx, r2);
+  else sqdist_narrow<NQ, MPB, NW>(zs, xs, Din, wave, g, c, act, redx, r2);      // x / l staged at kernel start
+  // the wave-private scratch of the distance code lives where the dX partials go: a wave that runs ahead into the reductions below
+  // must not overwrite the scratch of one that is still here (seen as a non-deterministic gradient with the Csave chain)
+  __syncthreads();
   BWD_STAMP(5);      // (wide inputs: distances chunked through LDS)
   double svar = 0.0;
   if (act) {
@@ -819,16 +857,7 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
         const int m = 16 * ib + g + 4 * t;
         const double e = WHITE ? bb[q][t] : bb[q][t] - gsum * av[q][t];
         const double kbar = WHITE ? e : e - gsum * av[q][t];
-        double r2v;
-        if constexpr (WIDE) {
-          r2v = r2[q][t];
-        } else {
-          r2v = 0.0;
-          for (int j = 0; j < Din; ++j) {
-            const double df = zs[(int64_t)m * Din + j] - xs[c * (Din + 1) + j];
-            r2v = fma(df, df, r2v);
-          }
-        }
+        const double r2v = r2[q][t];
         double k, dk;
         kern_val_grad<KIND>(r2v, s2, k, dk);
         const bool ok = rvalid && (m < a.M);
