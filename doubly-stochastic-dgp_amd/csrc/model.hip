@@ -115,6 +115,7 @@ struct dsdgp_model {
   bool track_theta = false;    // dsdgp_model_track_theta: the caller reports its writes to theta
   bool kuu_valid = false;      // Lu / Lu^-1 / Ku^-1 belong to the Z and kernel hyper-parameters currently in theta
   int grad_first = 0;          // dsdgp_model_set_grad_first_layer: reverse mode stops below this layer
+  bool grad_pruned = false;    // the gradient buffer holds a pruned reverse pass (entries of the lower layers are stale)
   int q_dirty = -2;            // with kuu_valid: -1 nothing changed, l >= 0 only layer l's (q_mu, q_sqrt) changed, -2 unknown / several
   bool side_pending = false;   // parameter-only work (Ku^-1, S_d, KL, U, UU) still running on the side stream
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;
@@ -1765,6 +1766,7 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   m->fin.done = false;
   if (with_grad) {
     DS_TRY(backward_layers(m, n, S, kl_weight));
+    m->grad_pruned = !m->desc.white && m->grad_first > 0;
   }
   if (!m->fin.done) {
     DS_TRY(join_prep(m));   // KL values
@@ -1783,6 +1785,10 @@ extern "C" int dsdgp_model_set_sample_weights(dsdgp_model* m, const double* w, i
 
 extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t) {
   DS_CHECK_ARG(m && m->grad && m->adam_m && m->adam_v && t >= 1);
+  if (m->grad_pruned) {
+    dsdgp_set_error("dsdgp_model_adam_step: the last gradient was evaluated for layers >= %d only (dsdgp_model_set_grad_first_layer)", m->grad_first);
+    return DSDGP_ERR_BAD_ARG;
+  }
   const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   const int64_t n = m->desc.n_theta;
   const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));

@@ -178,7 +178,8 @@ int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info)
 /* [UPSTREAM] tf.gradients(loss, var_list) with var_list = the (q_mu, q_sqrt) of the upper layer(s), as
  * NatGradOptimizer.minimize(var_list=[[last.q_mu, last.q_sqrt]]) builds it: TensorFlow prunes the reverse pass below the
  * lowest layer in var_list.  After this call dsdgp_model_elbo(with_grad=1) runs the reverse pass for layers >= first only;
- * the gradient entries of the layers below keep their previous content (do NOT follow with dsdgp_model_adam_step).
+ * the gradient entries of the layers below keep their previous content (dsdgp_model_adam_step then fails with
+ * DSDGP_ERR_BAD_ARG until a full gradient has been evaluated again).
  * first = 0 restores the full gradient.  Ignored (full gradient) for white=True models. */
 int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first);
 

@@ -588,3 +588,19 @@ def test_natgrad_with_pruned_reverse_pass_matches_full_gradient():
     for l in (1, 2):
         b.engine().natgrad_step(l, 0.02)
     assert np.array_equal(a.engine().theta.cpu().numpy(), b.engine().theta.cpu().numpy())
+
+
+def test_adam_step_refused_after_pruned_gradient():
+    """A pruned reverse pass leaves the lower layers' gradient entries stale: dsdgp_model_adam_step refuses to use them."""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(2)
+    N, D, M, S = 40, 2, 16, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    specs = [kern_spec("rbf", D, 1.0, 1.0), kern_spec("rbf", D, 1.0, 1.0)]
+    _, _, model = make_case(X, Y, X[:M].copy(), specs, S=S)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 1)]
+    model._build_likelihood(X, Y, zs=zs, with_grad=True, grad_from_layer=1)
+    with pytest.raises(_lib.DsdgpError):
+        model.engine().adam_step(0.01)
+    model._build_likelihood(X, Y, zs=zs, with_grad=True)          # a full gradient again
+    model.engine().adam_step(0.01)
