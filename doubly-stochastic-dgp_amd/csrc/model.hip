@@ -69,6 +69,7 @@ struct LayerState {
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
+  int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
@@ -737,20 +738,22 @@ __global__ void k_adj_prep(const double* __restrict__ dF, const double* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict__ jobs, int njobs, int blk0) {
+  // blk0: first block of this launch in the numbering of the whole job list (per-layer launches of a sub-range)
   __shared__ double sh[4];
+  const int bx = (int)blockIdx.x + blk0;
   int jb = 0;
-  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_start) ++jb;
+  while (jb + 1 < njobs && bx >= jobs[jb + 1].blk_start) ++jb;
   const RedJob J = jobs[jb];
   if (J.wide) {
-    const int64_t i = blockIdx.x - J.blk_start;     // one workgroup per output element
+    const int64_t i = bx - J.blk_start;     // one workgroup per output element
     double s = 0.0;
     for (int sp = threadIdx.x; sp < J.nsplit; sp += 256) s += J.part[(int64_t)sp * J.pstride + i];
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) J.out[i] = s;
     return;
   }
-  const int64_t i0 = (int64_t)(blockIdx.x - J.blk_start) * 256 + threadIdx.x;
+  const int64_t i0 = (int64_t)(bx - J.blk_start) * 256 + threadIdx.x;
   if (i0 >= J.count) return;
   int64_t i = i0, o = i0;
   if (J.out_ld > 0) {
@@ -1521,6 +1524,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const int64_t MM = (int64_t)v.Mp * v.Mp;
     const int Mw = pad_Mw(v.Mp);
     const int64_t MMw = (int64_t)Mw * Mw;
+    St.red_off = (int)red.size();
     std::vector<WgradJob> jobs;
     // G is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
     // of the K splits, so every task carries about the same number of MFMAs.  alg_g layers have no G job (k_asm_kbar
@@ -1572,11 +1576,18 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
+    St.red_n = (int)red.size() - St.red_off;
   }
   int blocks = 0;
   for (auto& r : red) {
     r.blk_start = blocks;
     blocks += r.wide ? (int)r.count : ceil_div(r.count, 256);
+  }
+  for (int l = 0; l < L; ++l) {
+    LayerState& St = m->L[l];
+    St.red_blk0 = red[St.red_off].blk_start;
+    const int nxt = St.red_off + St.red_n;
+    St.red_blkn = (nxt < (int)red.size() ? red[nxt].blk_start : blocks) - St.red_blk0;
   }
   if ((int)red.size() > m->rjobs_cap) {
     dsdgp_set_error("internal: reduction job list overflow");
@@ -1607,6 +1618,14 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool overlap = overlap_on(m, n, S);
   DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
+  // Pipelined tail (DSDGP_PIPE_TAIL=1, OFF by default): every layer's reduction / M x M products / gradient assembly enqueued right
+  // behind its weight-gradient products instead of once for all layers after the last chain — the per-layer "bucket" a
+  // bucketed all-reduce would hang on.  Measured on one GPU it LOSES: config 2 0.643 -> 0.662 ms per
+  // step, configs 3 / 4 / 5 +0.2 .. 0.9 % — the three-fold launches of small kernels take more from the chains they run under than
+  // the shorter tail gives back (those kernels are latency-bound and as long for one layer as for three).  Parity-tested
+  // (tests/test_gpu_round2.py); kept for multi-GPU runs where a per-layer all-reduce could follow each bucket.
+  static const int pipe_on = getenv("DSDGP_PIPE_TAIL") ? atoi(getenv("DSDGP_PIPE_TAIL")) : 0;
+  const bool pipelined = pipe_on && overlap && !m->desc.white && m->n_wz == 0;
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1655,12 +1674,24 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     int NI, ti;
     wgrad_shapes(v.Mp, NI, ti);
     hipStream_t ws = ctx->stream;
-    if (overlap) {
+    // pipelined tail: the last layer of the reverse pass keeps its weight-gradient products and its assembly on the main stream
+    // (which has nothing else left), the others run theirs on the side stream under the following chains
+    if (overlap && !(pipelined && l == gfirst)) {
       DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
     }
     DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
+    if (pipelined) {
+      // this layer's reduction of the split-K partials, P_d T_d / GS_d products and gradient assembly right behind its products
+      hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, ws, m->rjobs + St.red_off, St.red_n, St.red_blk0);
+      DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, ws));
+      const LayerDev* lay1 = m->layers_dev + l;
+      hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, 1), dim3(256), 0, ws, lay1, kl_weight);
+      if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, 1), dim3(256), 0, ws, lay1);
+      hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, 1), dim3(256), 0, ws, lay1, m->grad, kl_weight);
+      DS_HIP(hipGetLastError());
+    }
   }
   if (overlap) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
@@ -1670,7 +1701,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
   }
-  hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red);
+  if (pipelined) return DSDGP_OK;
+  hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
   DS_HIP(hipGetLastError());
   if (m->desc.white) {
     hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);

@@ -6,6 +6,7 @@ Tolerances are stated per test; the reference's own bar is rtol = atol = 1e-7 (1
 (/root/reference/tests/test_dgp.py:101-106).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -604,3 +605,33 @@ def test_adam_step_refused_after_pruned_gradient():
         model.engine().adam_step(0.01)
     model._build_likelihood(X, Y, zs=zs, with_grad=True)          # a full gradient again
     model.engine().adam_step(0.01)
+
+
+def test_pipelined_tail_is_bitwise_neutral():
+    """DSDGP_PIPE_TAIL=1 (per-layer reduction + assembly behind each layer's weight-gradient products, off by default) must give
+    the gradient of the default schedule bit for bit: run in a subprocess (the switch is read once per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "doubly-stochastic-dgp_amd")
+from tests.helpers import kern_spec, make_case
+rng = np.random.RandomState(4)
+N, D, M, S = 700, 4, 64, 8          # large enough for the two-stream schedule (n S Mp >= 2^20)
+X, Y = rng.randn(N, D), rng.randn(N, 2)
+Z = X[:M] + 0.01 * rng.randn(M, D)
+specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
+_, _, m = make_case(X, Y, Z, specs, S=S, num_data=3000)
+zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
+e = m._build_likelihood(X, Y, zs=zs, with_grad=True)
+g = m.engine().grad.cpu().numpy()
+print(repr(e)); print(g.tobytes().hex()[:64]); print(float(np.abs(g).sum()).hex())
+'''
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, DSDGP_PIPE_TAIL=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-3:])
+    assert outs[0] == outs[1]
