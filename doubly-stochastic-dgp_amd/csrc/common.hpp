@@ -167,7 +167,7 @@ __device__ __forceinline__ double bern_var_exp(double mu, double v, double y, do
 
 // Cross-lane sums WITHOUT the LDS: __shfl_xor compiles to ds_bpermute_b32 pairs (an LDS round trip of 100-200 cycles per step when
 // 32 waves share the CU); the per-input-dimension reductions at the end of the backward chain were six such dependent steps per
-// dimension and took 23 K of the 61 K clocks of a D_out = 1 workgroup (DSDGP_BWD_TIMING, profiles/r02_bwd_phases.txt).
+// dimension and took 23 K of the 61 K clocks of a D_out = 1 workgroup (DSDGP_BWD_TIMING, profiles/r02_chain_phases.txt, before/after in DESIGN.md 5.1).
 // gfx950 has v_permlane16_swap / v_permlane32_swap (exchange odd/even 16-lane rows, upper/lower 32 lanes) and the gfx9 DPP row
 // shifts / row broadcasts, all plain VALU instructions.
 //

@@ -192,7 +192,7 @@ __device__ __forceinline__ void sqdist_narrow(const double* __restrict__ zs, con
 // D layout (row g + 4 t of block ib, column c) the chains want; |z_m|^2 is summed per lane for row 16 ib + c, folded over g and
 // turned from that A-operand order into the D layout through 16 doubles of LDS per row block (`scratch`, wave-private: same wave
 // writes and reads, LDS operations of a wave execute in order); |x_c|^2 from a per-lane sum folded over g.  The element-by-element form (one L2 load and one FMA per (m, c, dimension) and lane)
-// took 1.37 M of the 3.25 M clocks of the 784-dimensional first layer of config 4 (profiles/r02_fwd_phases.txt) and as much again
+// took 1.37 M of the 3.25 M clocks of the 784-dimensional first layer of config 4 (DSDGP_FWD_TIMING; the current clocks are in profiles/r02_chain_phases.txt) and as much again
 // in the backward chain.  Absolute error ~ 1e-16 (|z|^2 + |x|^2); the result is clamped at 0.
 template <int NQ, int MPB, int NW>
 __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const double* __restrict__ X,

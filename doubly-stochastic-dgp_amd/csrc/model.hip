@@ -168,7 +168,7 @@ static int dbg_flags() {
 // read per call (not cached) so that the parity tests can force the Csave chain onto small shapes
 static int cs_min_dout() { return getenv("DSDGP_CS_MIN_DOUT") ? atoi(getenv("DSDGP_CS_MIN_DOUT")) : 3; }
 static int cs_min_blocks() { return getenv("DSDGP_CS_MIN_BLOCKS") ? atoi(getenv("DSDGP_CS_MIN_BLOCKS")) : 160; }
-// Policy (measured, profiles/r02_csave_notes.md): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %: the per-output products are
+// Policy (measured, profiles/r02_fp64_mfma_notes.md, last section): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %: the per-output products are
 // long enough to hide the staging latency); at Mp = 128 / 256 the d-loop turns from MFMA-throughput-bound into latency-bound and
 // the chain gets no faster (cfg 2) or slower (cfg 3, register pressure halves the occupancy), so those sizes keep the S_d form.
 //   DSDGP_SAVE_C = 0: never, 1 (default): Mp > 256 (the 8- / 16-wave row-oriented instances), 2: every size that has an
