@@ -690,6 +690,139 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
       }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 128 x 128 tiles for the symmetric products P_d = A diag(v_d) A^T.  The 64 x 64 form above is bound by operand bandwidth out of
+// L2 / Infinity Cache (every wave streams its own 64 + 64 rows: 256 bytes per MFMA); here ONE workgroup owns a 128 x 128 tile, its
+// four waves the 64 x 64 sub-tiles, and each 16-data-row chunk of the 128 (+128) operand rows is staged ONCE through LDS
+// (double-buffered, one barrier per chunk): 64 bytes per MFMA on a diagonal tile, 128 off the diagonal.  LDS layout [row][16 + 2]:
+// the MFMA fragments (lane (g, c): row 16 ii + c, data row 4 t + g of k-step t — any bijection of k works) are conflict-free
+// 8-byte reads, the staging stores 16-byte writes.  The sub-tile above the diagonal of a diagonal tile is not computed
+// (k_reduce_grouped mirrors at 16-block granularity, as for the 64 x 64 form); all K splits of a job cover every tile.
+// MEASURED SLOWER and therefore OFF by default (DSDGP_WGRAD_T128=1 enables it; gradients parity-tested): weight-gradient time per
+// step 0.129 -> 0.169 ms at config 2, 2.49 -> 3.03 ms at config 3.  A third to a half of the operand traffic does not pay for one
+// barrier and one LDS round trip per 16-row chunk with 64 MFMAs per wave in between (two workgroups per CU: 74 KB of LDS each).
+#define T128_LD 18
+int wgrad_t128_lds_bytes() { return (4 * 128 * T128_LD + 2 * 16) * (int)sizeof(double); }
+__global__ __launch_bounds__(256) void k_wgrad_t128(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld, int64_t Rp) {
+  extern __shared__ __attribute__((aligned(16))) double tsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  int jb = 0;
+  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].task_start) ++jb;
+  const WgradJob J = jobs[jb];
+  int local = (int)blockIdx.x - J.task_start;
+  const int T = J.ti, ntile = T * (T + 1) / 2;
+  const int split = local / ntile;
+  local %= ntile;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= local) ++ti;
+  const int tj = local - ti * (ti + 1) / 2;
+  const bool diag128 = ti == tj;
+  const int si = wave >> 1, sj = wave & 1;
+  const bool idle = diag128 && sj > si;        // the 64 x 64 sub-tile above the diagonal
+  const bool dsub = diag128 && si == sj;       // diagonal sub-tile: 16-blocks with jj <= ii only
+  const int64_t nch = Rp / 16;
+  const int64_t c_lo = split * nch / nsplit, c_hi = (split + 1) * nch / nsplit;
+  double* Pt = tsm;                            // [2][128][T128_LD]
+  double* Qt = tsm + 2 * 128 * T128_LD;        // [2][128][T128_LD]  (unused on a diagonal tile: Q's rows are P's rows)
+  double* Sc = tsm + 4 * 128 * T128_LD;        // [2][16]
+  // staging: thread -> (row = tid / 2, half = tid % 2): data rows 8 half .. 8 half + 7 of its operand row (64 contiguous bytes)
+  const int srow = tid >> 1, sh = tid & 1;
+  typedef const d4 __attribute__((address_space(1)))* gd4;
+  gcptr Pg = (gcptr)(J.P + (int64_t)(128 * ti + srow) * ld + 8 * sh);
+  gcptr Qg = (gcptr)(J.Q + (int64_t)(128 * tj + srow) * ld + 8 * sh);
+  gcptr Sg = (gcptr)J.scale;
+  d4 p0 = (d4){0, 0, 0, 0}, p1 = p0, q0 = p0, q1 = p0;
+  double sv = 1.0;
+  auto gload = [&](int64_t ch) {
+    const int64_t rb = ch * 16;
+    p0 = *reinterpret_cast<gd4>(Pg + rb);
+    p1 = *reinterpret_cast<gd4>(Pg + rb + 4);
+    if (!diag128) {
+      q0 = *reinterpret_cast<gd4>(Qg + rb);
+      q1 = *reinterpret_cast<gd4>(Qg + rb + 4);
+    }
+    if (Sg && tid < 16) sv = Sg[rb + tid];
+  };
+  auto lstore = [&](int buf) {
+    double* pd = Pt + (buf * 128 + srow) * T128_LD + 8 * sh;
+    *reinterpret_cast<d4*>(pd) = p0;
+    *reinterpret_cast<d4*>(pd + 4) = p1;
+    if (!diag128) {
+      double* qd = Qt + (buf * 128 + srow) * T128_LD + 8 * sh;
+      *reinterpret_cast<d4*>(qd) = q0;
+      *reinterpret_cast<d4*>(qd + 4) = q1;
+    }
+    if (tid < 16) Sc[buf * 16 + tid] = sv;
+  };
+  d4 acc[4][4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
+  if (c_lo < c_hi) {
+    gload(c_lo);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
+    const bool more = ch + 1 < c_hi;
+    if (more) gload(ch + 1);                   // in flight during the MFMAs of this chunk
+    if (!idle) {
+      const double* __restrict__ pb = Pt + (cur * 128 + 64 * si + c) * T128_LD;
+      const double* __restrict__ qb = (diag128 ? Pt : Qt) + (cur * 128 + 64 * sj + c) * T128_LD;
+      const double* __restrict__ sc = Sc + cur * 16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 4 * t + g;
+        const double s = sc[k];
+        double pa[4], qv[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) pa[ii] = pb[16 * ii * T128_LD + k];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) qv[jj] = qb[16 * jj * T128_LD + k] * s;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (!dsub || jj <= ii) acc[ii][jj] = mfma_f64(pa[ii], qv[jj], acc[ii][jj]);
+      }
+    }
+    if (more) lstore(cur ^ 1);                 // the other buffer: every wave finished reading it before the previous barrier
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (idle) return;
+  gptr o = (gptr)(J.out + (int64_t)split * (128 * T) * J.ldo);
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (!dsub || jj <= ii) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[(int64_t)(128 * ti + 64 * si + 16 * ii + g + 4 * t) * J.ldo + 128 * tj + 64 * sj + 16 * jj + c] = acc[ii][jj][t];
+      }
+}
+int wgrad_t128_enabled() {
+  static const int on = getenv("DSDGP_WGRAD_T128") ? atoi(getenv("DSDGP_WGRAD_T128")) : 0;
+  return on;
+}
+int wgrad_t128_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
+                      hipStream_t stream) {
+  if (total_tasks <= 0) return DSDGP_OK;
+  hipStream_t st = stream ? stream : ctx->stream;
+  ProfScope ps(ctx, "wgrad", st);
+  static bool attr = false;
+  if (!attr) {
+    DS_HIP(hipFuncSetAttribute((const void*)k_wgrad_t128, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_t128_lds_bytes()));
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_wgrad_t128, dim3(total_tasks), dim3(256), wgrad_t128_lds_bytes(), st, jobs_dev, njobs, nsplit, ld, Rp);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
 int wgrad_coop_enabled() {
   static const int on = getenv("DSDGP_WGRAD_COOP") ? atoi(getenv("DSDGP_WGRAD_COOP")) : 1;
   return on;

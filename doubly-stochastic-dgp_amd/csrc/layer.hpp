@@ -100,6 +100,10 @@ struct WgradJob {
 int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
 // jobs_dev: device copy of `njobs` jobs with task_start filled (tasks = nsplit*ti*tj each); NI/NJ in {4,2}/{4,2,1}
+// 128 x 128-tile form for symmetric jobs (J.ti = result rows / 128; tasks = nsplit * ti (ti + 1) / 2 each)
+int wgrad_t128_enabled();
+int wgrad_t128_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
+                      hipStream_t stream = nullptr);
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
                  int NI, int NJ, hipStream_t stream = nullptr);
 size_t layer_fwd_lds_bytes(int Mp, int D_in);

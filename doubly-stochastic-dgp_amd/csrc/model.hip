@@ -69,6 +69,8 @@ struct LayerState {
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
+  WgradJob* wj128 = nullptr;    // symmetric jobs in the 128 x 128-tile form (their own launch)
+  int n128 = 0, tot128 = 0;
   int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
@@ -207,6 +209,17 @@ static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks)
   return ns;
 }
 
+// 128 x 128-tile form of the symmetric weight-gradient products (layer.hip: k_wgrad_t128): usable when the products' row count is a
+// multiple of 128; K splits so that the launch has about `target` workgroups, every split at least four 16-row chunks
+static bool wgrad_t128_ok(int Mp) { return wgrad_t128_enabled() && sm_chain_enabled() && pad_Mw(Mp) % 128 == 0; }
+static int wgrad_t128_nsplit(int D_out, int Mp, int64_t nchunks) {
+  static const int target = getenv("DSDGP_WGRAD_T128_TARGET") ? atoi(getenv("DSDGP_WGRAD_T128_TARGET")) : 512;
+  const int T = pad_Mw(Mp) / 128, ntile = T * (T + 1) / 2;
+  int ns = target / std::max(1, D_out * ntile);
+  const int64_t cap = std::max<int64_t>(1, nchunks / 4);
+  if (ns > cap) ns = (int)cap;
+  return ns < 1 ? 1 : ns;
+}
 static void wgrad_shapes(int Mp, int& NI, int& ti) {
   static const int ni_env = getenv("DSDGP_WGRAD_NI") ? atoi(getenv("DSDGP_WGRAD_NI")) : 0;   // tuning knob: 2 -> 32x32 tiles
   NI = (ni_env != 2) ? 4 : 2;
@@ -318,6 +331,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     const int tj_big = ti;
     S.nsplit_big_max = choose_nsplit((v.alg_g ? 0 : ti * tj_big) + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
                                      S.ld_max / 16, 1024);
+    if (wgrad_t128_ok(v.Mp)) S.nsplit_big_max = std::max(S.nsplit_big_max, wgrad_t128_nsplit(d.D_out, v.Mp, S.ld_max / 16));
     S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * Mw * Mw);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
@@ -327,6 +341,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.bpart = sm_chain_enabled() ? b.take<double>((size_t)1024 * (Mp * 16 + 16)) : nullptr;
     S.bcnt = sm_chain_enabled() ? b.take<int>(512) : nullptr;
     S.lq = b.take<GemmProblem>(12);
+    S.wj128 = b.take<WgradJob>(d.D_out + 1);
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
@@ -1531,8 +1546,12 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     // assembles sum_r e a^T from the P_d).
     const int n_off = ti * (ti - 1) / 2;
     const double dfrac = (NI + 1) / (2.0 * NI);
-    int ns = choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
+    const bool t128 = wgrad_t128_ok(v.Mp);
+    int ns = t128 ? wgrad_t128_nsplit(v.D_out, v.Mp, nch)
+                  : choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
+    std::vector<WgradJob> jobs128;
+    int start128 = 0;
     St.ns_big = ns;
     const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
     int start = 0;
@@ -1545,8 +1564,15 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = start;
       J.sym = (j >= 1) ? 1 : 0; J.qrows16 = Mw / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
       J.ns_diag = ns_diag; J.pad = 0;
-      start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
-      jobs.push_back(J);
+      if (t128 && J.sym) {          // 128 x 128 tiles, every split covers every tile
+        const int T = Mw / 128;
+        J.ti = T; J.tj = T; J.task_start = start128;
+        start128 += ns * (T * (T + 1) / 2);
+        jobs128.push_back(J);
+      } else {
+        start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
+        jobs.push_back(J);
+      }
       red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
     }
     // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
@@ -1574,6 +1600,9 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
+    St.n128 = (int)jobs128.size();
+    St.tot128 = start128;
+    if (St.n128) DS_HIP(hipMemcpyAsync(St.wj128, jobs128.data(), jobs128.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
     St.red_n = (int)red.size() - St.red_off;
@@ -1681,6 +1710,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
     }
+    if (St.n128) DS_TRY(wgrad_t128_launch(ctx, St.wj128, St.n128, St.tot128, St.ns_big, ld, ld, ws));
     DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
     if (pipelined) {
       // this layer's reduction of the split-K partials, P_d T_d / GS_d products and gradient assembly right behind its products
