@@ -635,3 +635,30 @@ print(repr(e)); print(g.tobytes().hex()[:64]); print(float(np.abs(g).sum()).hex(
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-3:])
     assert outs[0] == outs[1]
+
+
+def test_wgrad_128_tile_form_matches():
+    """DSDGP_WGRAD_T128=1 (128 x 128-tile weight-gradient products staged through LDS; off by default because it measured slower)
+    against the oracle gradient, in a subprocess (the switch is read once per process): M = 128 and 256, symmetric P_d jobs."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "doubly-stochastic-dgp_amd")
+from tests.helpers import kern_spec, make_case
+from tests.test_gpu_parity import _grad_check
+for M in (128, 256):
+    rng = np.random.RandomState(M)
+    N, D, S = 150, 3, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=600)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
+    _grad_check(X, Y, spec, state, model, zs, S, num_data=600)
+print("OK")
+'''
+    env = dict(os.environ, DSDGP_WGRAD_T128="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
