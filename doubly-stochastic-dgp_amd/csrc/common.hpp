@@ -95,12 +95,6 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 // exist for every multiple of 16 up to 128, of 32 up to 256, of 64 up to 512 and of 128 up to 1024: M = 100 (the reference
 // demo size, demos/run_regression.py:57) runs as 112, not 128; M = 300 as 320, not 512.
 static inline int pad_M(int M) {
-  static const int pow2 = getenv("DSDGP_CHAIN_SM") && atoi(getenv("DSDGP_CHAIN_SM")) == 0;   // the generation-2 kernels (layer.hip)
-  if (pow2) {                                                                                // exist for powers of two only
-    int p = 32;
-    while (p < M) p *= 2;
-    return p;
-  }
   if (M <= 32) return 32;
   if (M <= 128) return (int)round_up(M, 16);
   if (M <= 256) return (int)round_up(M, 32);

@@ -1,4 +1,4 @@
-// SVGP_Layer hot path on gfx950: register-resident MFMA chains (one wavefront owns 16 data rows end to end).
+// SVGP_Layer hot path on gfx950: argument blocks of the chain kernels and of the split-K weight-gradient products.
 #pragma once
 #include "common.hpp"
 
@@ -32,7 +32,6 @@ struct LayerFwdArgs {
   int64_t ldA;
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
   double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
-  int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
   unsigned long long* phase_clk;   // debug aid (DSDGP_FWD_TIMING): [workgroup][8] shader-clock stamps of the forward chain's phases, or NULL
 };
 
@@ -71,7 +70,6 @@ struct LayerBwdArgs {
   const double* varp;   // the previous layer's variances (Rin x Dp)
   int32_t Dp, prop;     // previous layer's D_out, input_prop_dim
   double jitter;
-  int32_t flags;        // experiment switches (DSDGP_DBG): 1 = non-temporal Csave traffic
   unsigned long long* phase_clk;   // debug aid (DSDGP_BWD_TIMING): [workgroup][8] shader-clock stamps of the backward chain's phases, or NULL
   // split-M kernels, small launches: gridDim.y = d_split workgroups share a row block, each takes D_out / d_split outputs of the d-loop
   // and leaves its partial abar tile (+ its share of sum_d vbar_d) in `part` ([row block][d_split][Mp * 16 + 16]); the workgroup that
@@ -97,20 +95,11 @@ struct WgradJob {
   int32_t pad;
 };
 
-int layer_fwd_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
-int layer_bwd_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
-// jobs_dev: device copy of `njobs` jobs with task_start filled (tasks = nsplit*ti*tj each); NI/NJ in {4,2}/{4,2,1}
-// 128 x 128-tile form for symmetric jobs (J.ti = result rows / 128; tasks = nsplit * ti (ti + 1) / 2 each)
-int wgrad_t128_enabled();
-int wgrad_t128_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                      hipStream_t stream = nullptr);
+// jobs_dev: device copy of `njobs` jobs with task_start filled (64 x 64 tiles, one workgroup per (job, split, tile) task)
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                 int NI, int NJ, hipStream_t stream = nullptr);
-size_t layer_fwd_lds_bytes(int Mp, int D_in);
-int wgrad_coop_enabled();   // one workgroup per split-K task, four waves reducing through LDS (default) instead of one wave per task
-// split-M variants (layer_sm.hip): 4 waves cooperate on one block of 16*CB rows
+                 hipStream_t stream = nullptr);
+// chain kernels (layer_sm.hip): the NW waves of a workgroup cooperate on one block of 16 rows
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
-int sm_chain_enabled();
 int sm_cs_built(int Mp);     // the split-M backward chain has a Csave instance for this padded inducing count
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in);   // number of hyp_part rows the split-M backward writes for ld padded rows

@@ -1,4 +1,4 @@
-// Dispatch of the split-M SVGP_Layer chain kernels (layer_sm_impl.hpp).  The instances are compiled in three parts
+// Dispatch of the SVGP_Layer chain kernels (layer_sm_impl.hpp).  The instances are compiled in three parts
 // (layer_sm_a / _b / _c.hip: padded inducing counts 32..112, 128..256, 320..1024) so that they build in parallel.
 #include <stdlib.h>
 
@@ -12,21 +12,16 @@ int layer_bwd_sm_a(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
 int layer_bwd_sm_b(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
 int layer_bwd_sm_c(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
 
-int sm_chain_enabled() {
-  static const int on = getenv("DSDGP_CHAIN_SM") ? atoi(getenv("DSDGP_CHAIN_SM")) : 1;
-  return on;
-}
 // waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
 // one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
 #define SM_SMALL_BLOCKS 160
 static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
-  static const int on = getenv("DSDGP_SM_SMALL") ? atoi(getenv("DSDGP_SM_SMALL")) : 1;
   // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
   // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
   // (the 4-wave forward instance has the early-mean specialisation)
   // Mp = 160 .. 224 follow the M = 256 rule (tools/bench_padding.py: with 4 waves M = 224 ran no faster than M = 256 with 8)
   const int64_t lim = (Mp > 128 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
-  return on && Mp >= 128 && Mp <= 256 && nblk <= lim && D_in <= XCH;
+  return Mp >= 128 && Mp <= 256 && nblk <= lim && D_in <= XCH;
 }
 // waves per row block of the instance that a launch of this shape takes
 static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {

@@ -69,9 +69,8 @@ struct LayerState {
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
-  WgradJob* wj128 = nullptr;    // symmetric jobs in the 128 x 128-tile form (their own launch)
-  int n128 = 0, tot128 = 0;
   int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
+  int red_nA = 0, red_blknA = 0;                            //   of which the leading red_nA jobs / red_blknA blocks belong to the A jobs
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
@@ -83,7 +82,12 @@ struct LayerState {
   // step on this layer alone: the other layers' S_d / U_d / ... are still those of the previous evaluation)
   GemmProblem* lq = nullptr;
   int lq_nf = 0, lq_tf = 0, lq_n1 = 0, lq_t1 = 0, lq_n2 = 0, lq_t2 = 0, lq_np = 0, lq_tp = 0;   // forward / U, n, KS / U U^T / P_d T_d, GS_d
-  WgradJob* wj;        // device: (1 + D_out) big jobs followed by 2 thin jobs, rebuilt when (n, S) changes
+  // weight-gradient jobs, rebuilt when (n, S) changes.  wj = [A | B]: the A jobs (P_d = A diag(vbar_d) A^T, A mbar^T, the mean-function
+  // product) read only what the FORWARD chain and the producer of this layer's upstream adjoints left, so they can start before this
+  // layer's backward chain; the B jobs (E A^T, GW [X|1]^T) read the backward chain's outputs.  wjB = the B jobs with their own task
+  // numbering (launched alone when A went ahead).
+  WgradJob *wj, *wjB;
+  int njobsA = 0, totA = 0, njobsB = 0, totB = 0;
   int ns_big, ns_thin, tot_big, tot_thin;
   // z actually used by the last forward (for the backward pass)
   const double* z_used;
@@ -141,9 +145,40 @@ struct dsdgp_model {
   // side stream: the weight-gradient products of layer l overlap the backward chain of layer l-1 (disjoint buffers)
   hipStream_t side;
   hipEvent_t ev_bwd[DSDGP_MAX_LAYERS];
+  hipEvent_t ev_adj[DSDGP_MAX_LAYERS];   // upstream adjoints (MB / VB) of layer l written: its A jobs may start
   hipEvent_t ev_side;
   bool overlap;
+  // DSDGP_FORCE="key=value,...": test hooks that force the large-launch variants onto small, oracle-checkable shapes (read when
+  // the model is created).  save_c: Csave backward chain 0 never / 1 for Mp > 256 / 2 every size with an instance (thresholds
+  // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
+  // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
+  // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0; } force;
 };
+static void parse_force(dsdgp_model* m) {
+  const char* e = getenv("DSDGP_FORCE");
+  if (!e) return;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos < str.size()) {
+    size_t end = str.find(',', pos);
+    if (end == std::string::npos) end = str.size();
+    const std::string kv = str.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq != std::string::npos) {
+      const std::string k = kv.substr(0, eq);
+      const int v = atoi(kv.c_str() + eq + 1);
+      if (k == "save_c") m->force.save_c = v;
+      else if (k == "cs_min_blocks") m->force.cs_min_blocks = v;
+      else if (k == "cs_min_dout") m->force.cs_min_dout = v;
+      else if (k == "alg_g") m->force.alg_g = v;
+      else if (k == "bwd_split") m->force.bwd_split = v;
+      else if (k == "early_wgrad") m->force.early_wgrad = v;
+      else if (k == "pipe_tail") m->force.pipe_tail = v;
+    }
+    pos = end + 1;
+  }
+}
 
 struct Bump {
   char* base;
@@ -157,28 +192,12 @@ struct Bump {
   }
 };
 
-// padded inducing count from which the multi-workgroup blocked Cholesky / inverse replaces the one-workgroup kernel: 512, or
-// 256 when all layers share M and are factorised as ONE batch (measured: config 3 +2 %; per-layer sequences at 256 would lose
-// to the single launch that factors all layers side by side)
-// the forward chain keeps c_d = q_sqrt_d^T a (D_out x Mp doubles per row) so that the backward chain's abar = sum_d 2 vbar_d S_d a
-// becomes the triangular product sum_d q_sqrt_d (2 vbar_d c_d): half the MFMAs of that loop for D_out x Mp x 8 bytes per row of
-// HBM traffic each way (cfg 2: 164 MB per 20 000-row layer, streamed under MFMA-bound kernels)
-static int dbg_flags() {
-  static const int f = getenv("DSDGP_DBG") ? atoi(getenv("DSDGP_DBG")) : 0;
-  return f;
-}
-// read per call (not cached) so that the parity tests can force the Csave chain onto small shapes
-static int cs_min_dout() { return getenv("DSDGP_CS_MIN_DOUT") ? atoi(getenv("DSDGP_CS_MIN_DOUT")) : 3; }
-static int cs_min_blocks() { return getenv("DSDGP_CS_MIN_BLOCKS") ? atoi(getenv("DSDGP_CS_MIN_BLOCKS")) : 160; }
-// Policy (measured, profiles/r02_fp64_mfma_notes.md, last section): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %: the per-output products are
-// long enough to hide the staging latency); at Mp = 128 / 256 the d-loop turns from MFMA-throughput-bound into latency-bound and
-// the chain gets no faster (cfg 2) or slower (cfg 3, register pressure halves the occupancy), so those sizes keep the S_d form.
-//   DSDGP_SAVE_C = 0: never, 1 (default): Mp > 256 (the 8- / 16-wave row-oriented instances), 2: every size that has an
-//   instance (parity tests force the small ones)
-static int save_c_mode() { return getenv("DSDGP_SAVE_C") ? atoi(getenv("DSDGP_SAVE_C")) : 1; }
-static bool save_c_enabled(int Mp = 1 << 30) {
-  const int mode = save_c_mode();
-  return sm_chain_enabled() && (mode >= 2 || (mode == 1 && Mp > 256));
+// Csave backward chain: the forward chain keeps c_d = q_sqrt_d^T a (D_out x Mp doubles per row) so that the backward chain's
+// abar = sum_d 2 vbar_d S_d a becomes the triangular product sum_d q_sqrt_d (2 vbar_d c_d): half the MFMAs of that loop.  Measured
+// (profiles/r02_fp64_mfma_notes.md): a clear win from Mp = 512 (cfg 4 +10 %, cfg 5 +14 %); at Mp = 128 / 256 the d-loop turns from
+// MFMA-throughput-bound into latency-bound and the chain gets no faster, so those sizes keep the S_d form.
+static bool save_c_enabled(const dsdgp_model* m, int Mp) {
+  return m->force.save_c >= 2 || (m->force.save_c == 1 && Mp > 256);
 }
 // workgroups per row block of a chain launch with few row blocks (the d-split).  < 256 row blocks (first layers, small shards): up to
 // four, ~512 workgroups.  256..511 row blocks (the per-GPU shards of configs 4 / 5: two rounds on 256 CUs, the second a quarter to a
@@ -191,39 +210,24 @@ static int chain_d_split(int64_t nblk, int D_out) {
   if (ds > D_out) ds = D_out;
   return ds < 1 ? 1 : ds;
 }
-static int big_mp(bool uniform) {
-  static const int v = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 256;
-  return uniform ? v : 512;
-}
-// target_tasks: tasks of the launch (1024 = one per SIMD).  Cooperative launches count WORKGROUP tasks (four waves each): the
-// default 512 gives two waves per SIMD with half the partials of the one-wave-per-task form at 1024.
+// padded inducing count from which the multi-workgroup blocked Cholesky / inverse replaces the one-workgroup kernel: 512, or
+// 256 when all layers share M and are factorised as ONE batch (measured: config 3 +2 %; per-layer sequences at 256 would lose
+// to the single launch that factors all layers side by side)
+static int big_mp(bool uniform) { return uniform ? 256 : 512; }
+// K splits of a weight-gradient launch: about `target_tasks` workgroup tasks (512 = two workgroups of four waves per CU), every
+// wave at least two 16-row chunks
 static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
-  const bool coop = wgrad_coop_enabled() != 0;
-  static const int scale = getenv("DSDGP_WGRAD_TARGET") ? atoi(getenv("DSDGP_WGRAD_TARGET")) : (coop ? 512 : 1024);   // tuning knob
-  target_tasks = (int)((int64_t)target_tasks * scale / 1024);
   int ns = target_tasks / (tiles_per_split > 0 ? tiles_per_split : 1);
   if (ns < 1) ns = 1;
-  int64_t cap = nchunks / (coop ? 8 : 4);      // every wave keeps at least two (coop) / four 16-row chunks
+  int64_t cap = nchunks / 8;
   if (cap < 1) cap = 1;
   if (ns > cap) ns = (int)cap;
   return ns;
 }
-
-// 128 x 128-tile form of the symmetric weight-gradient products (layer.hip: k_wgrad_t128): usable when the products' row count is a
-// multiple of 128; K splits so that the launch has about `target` workgroups, every split at least four 16-row chunks
-static bool wgrad_t128_ok(int Mp) { return wgrad_t128_enabled() && sm_chain_enabled() && pad_Mw(Mp) % 128 == 0; }
-static int wgrad_t128_nsplit(int D_out, int Mp, int64_t nchunks) {
-  static const int target = getenv("DSDGP_WGRAD_T128_TARGET") ? atoi(getenv("DSDGP_WGRAD_T128_TARGET")) : 512;
-  const int T = pad_Mw(Mp) / 128, ntile = T * (T + 1) / 2;
-  int ns = target / std::max(1, D_out * ntile);
-  const int64_t cap = std::max<int64_t>(1, nchunks / 4);
-  if (ns > cap) ns = (int)cap;
-  return ns < 1 ? 1 : ns;
-}
+// 64 x 64 tiles (NI = 4 blocks of 16) on Mw = round_up(Mp, 64) rows (zero rows beyond Mp)
 static void wgrad_shapes(int Mp, int& NI, int& ti) {
-  static const int ni_env = getenv("DSDGP_WGRAD_NI") ? atoi(getenv("DSDGP_WGRAD_NI")) : 0;   // tuning knob: 2 -> 32x32 tiles
-  NI = (ni_env != 2) ? 4 : 2;
-  ti = pad_Mw(Mp) / (16 * NI);        // the products run on Mw = round_up(Mp, 64) rows (zero rows beyond Mp)
+  NI = 4;
+  ti = pad_Mw(Mp) / 64;
 }
 
 static void layout(dsdgp_model* m, char* base, size_t* total) {
@@ -299,10 +303,10 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
     {
-      const int alg_env = getenv("DSDGP_ALG_G") ? atoi(getenv("DSDGP_ALG_G")) : -1;   // -1: heuristic, 0: never, 1: always (read per model)
+      const int alg_env = m->force.alg_g;   // -1: heuristic, 0: never, 1: always
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
-      v.alg_g = (!D.white && sm_chain_enabled() && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
-      v.need_tpt = (v.Mp > 256 || save_c_enabled(v.Mp)) ? 1 : 0;
+      v.alg_g = (!D.white && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
+      v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp)) ? 1 : 0;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }
@@ -318,7 +322,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.ld_max = round_up(Rin_max, 16);
     const size_t Mw = pad_Mw(v.Mp);      // rows Mp..Mw-1 stay zero (never written): whole tiles for the weight-gradient products
     S.A = b.take<double>(Mw * S.ld_max); S.E = b.take<double>(Mw * S.ld_max); S.GW = b.take<double>(Mw * S.ld_max);
-    S.C = save_c_enabled((int)Mp) ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
+    S.C = save_c_enabled(m, (int)Mp) ? b.take<double>((size_t)d.D_out * Mp * S.ld_max) : nullptr;
     S.VB = b.take<double>(v.DP16 * S.ld_max); S.MB = b.take<double>(v.DP16 * S.ld_max);
     S.XT1 = b.take<double>((size_t)round_up(v.DinP16, 64) * S.ld_max);   // rows >= DinP16 stay zero: whole 64-row tiles for the mean-gradient product
     S.F = b.take<double>(S.R_max * d.D_out); S.mean = b.take<double>(S.R_max * d.D_out);
@@ -330,19 +334,18 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     wgrad_shapes(v.Mp, NI, ti);
     const int tj_big = ti;
     S.nsplit_big_max = choose_nsplit((v.alg_g ? 0 : ti * tj_big) + d.D_out * (ti * (ti - 1) / 2) + (int)ceil(d.D_out * ti * (NI + 1) / (2.0 * NI)),
-                                     S.ld_max / 16, 1024);
-    if (wgrad_t128_ok(v.Mp)) S.nsplit_big_max = std::max(S.nsplit_big_max, wgrad_t128_nsplit(d.D_out, v.Mp, S.ld_max / 16));
-    S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 512);
+                                     S.ld_max / 16, 512);
+    S.nsplit_thin_max = choose_nsplit(ti * (v.DP16 / 16 + v.DinP16 / 16), S.ld_max / 16, 256);
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * Mw * Mw);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
     // d-split of the backward chain on small launches (at most 1024 workgroups): partial abar tiles + arrival counters
-    S.bpart = sm_chain_enabled() ? b.take<double>((size_t)1024 * (Mp * 16 + 16)) : nullptr;
-    S.bcnt = sm_chain_enabled() ? b.take<int>(512) : nullptr;
+    S.bpart = b.take<double>((size_t)1024 * (Mp * 16 + 16));
+    S.bcnt = b.take<int>(512);
     S.lq = b.take<GemmProblem>(12);
-    S.wj128 = b.take<WgradJob>(d.D_out + 1);
     S.wj = b.take<WgradJob>(d.D_out + 4);
+    S.wjB = b.take<WgradJob>(4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
   }
@@ -1064,7 +1067,7 @@ static int validate_desc(const dsdgp_model_desc* d) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
     DS_CHECK_ARG(y.kern_kind == DSDGP_KERN_RBF || y.kern_kind == DSDGP_KERN_MATERN52);
-    if (pad_M(y.M) > (sm_chain_enabled() ? 1024 : 256)) {
+    if (pad_M(y.M) > 1024) {
       dsdgp_set_error("layer %d: M=%d inducing points exceeds the built chain kernels (<= 1024)", l, y.M);
       return DSDGP_ERR_UNSUPPORTED;
     }
@@ -1080,6 +1083,7 @@ extern "C" int dsdgp_model_workspace_bytes(const dsdgp_model_desc* desc, int64_t
   DS_TRY(validate_desc(desc));
   DS_CHECK_ARG(bytes && n_max > 0 && s_max > 0);
   dsdgp_model tmp{};
+  parse_force(&tmp);
   tmp.desc = *desc;
   tmp.n_max = n_max;
   tmp.s_max = s_max;
@@ -1107,6 +1111,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_TRY(validate_desc(desc));
   DS_CHECK_ARG(((uintptr_t)workspace & 255) == 0);
   dsdgp_model* m = new dsdgp_model();
+  parse_force(m);
   m->ctx = ctx;
   m->desc = *desc;
   m->n_max = n_max;
@@ -1151,7 +1156,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     gf.push_back(P);
     // S_d = q_sqrt_d q_sqrt_d^T feeds the dense backward chain and KS_d; layers whose backward chain always takes the Csave
     // form (Mp >= 512) and that do not assemble dl/dKu algebraically never read it
-    if (!(sm_chain_enabled() && Mp > 256 && save_c_enabled(Mp)) || v.alg_g) {
+    if (!(Mp > 256 && save_c_enabled(m, Mp)) || v.alg_g) {
       fill_gemm(P, v.Tp, v.Tp, v.Sd, Mp, Mp, Mp, Mp, Mp, Mp, 0, 1, v.D_out, MM, MM, MM, 0);            // S_d
       P.lower_only = 1; P.tri = 2 | 4 | 16;                                                              //   lower x lower^T, symmetric
       gf.push_back(P);
@@ -1285,7 +1290,10 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_HIP(hipStreamSynchronize(st));
   m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
   DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-  for (int l = 0; l < L; ++l) DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
+  for (int l = 0; l < L; ++l) {
+    DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
+    DS_HIP(hipEventCreateWithFlags(&m->ev_adj[l], hipEventDisableTiming));
+  }
   DS_HIP(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&m->ev_prep_side, hipEventDisableTiming));
@@ -1301,7 +1309,10 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
   if (m) {
     hipStreamSynchronize(m->ctx->stream);
     hipStreamSynchronize(m->side);
-    for (int l = 0; l < m->desc.L; ++l) hipEventDestroy(m->ev_bwd[l]);
+    for (int l = 0; l < m->desc.L; ++l) {
+      hipEventDestroy(m->ev_bwd[l]);
+      hipEventDestroy(m->ev_adj[l]);
+    }
     hipEventDestroy(m->ev_side);
     hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
     hipStreamDestroy(m->side);
@@ -1342,8 +1353,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
-  static const int reuse_on = getenv("DSDGP_KUU_REUSE") ? atoi(getenv("DSDGP_KUU_REUSE")) : 1;
-  const bool keep_kuu = reuse_on && m->track_theta && m->kuu_valid;
+  const bool keep_kuu = m->track_theta && m->kuu_valid;
   hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
                      m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
                      m->prep_blocks, keep_kuu ? 1 : 0);
@@ -1487,18 +1497,15 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     // c_d is kept for the backward chain where that pays: enough row blocks to hide the extra latency per output (the N-row first
     // layer is a latency-bound launch) and enough outputs for the halved d-loop to matter
     // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
-    St.c_used = save_l && St.C && sm_cs_built(v.Mp) && (v.Mp > 256 || ((Rin + 15) / 16 > cs_min_blocks() && v.D_out >= cs_min_dout()));
+    St.c_used = save_l && St.C && sm_cs_built(v.Mp) &&
+                (v.Mp > 256 || ((Rin + 15) / 16 > m->force.cs_min_blocks && v.D_out >= m->force.cs_min_dout));
     a.Csave = St.c_used ? St.C : nullptr;
-    a.flags = dbg_flags();
-    a.XT1 = (save_l && sm_chain_enabled()) ? St.XT1 : nullptr;
+    a.XT1 = save_l ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
       a.d_split = chain_d_split(nblk, v.D_out);
     }
-    if (sm_chain_enabled())
-      DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
-    else
-      DS_TRY(layer_fwd_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
+    DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
     if (St.prop && !last) {
@@ -1539,73 +1546,81 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const int64_t MM = (int64_t)v.Mp * v.Mp;
     const int Mw = pad_Mw(v.Mp);
     const int64_t MMw = (int64_t)Mw * Mw;
-    St.red_off = (int)red.size();
-    std::vector<WgradJob> jobs;
-    // G is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
+    // G = E A^T is full; the D_out P_d are symmetric: off-diagonal tiles cost 1, diagonal tiles (NI+1)/(2 NI) and get that fraction
     // of the K splits, so every task carries about the same number of MFMAs.  alg_g layers have no G job (k_asm_kbar
     // assembles sum_r e a^T from the P_d).
     const int n_off = ti * (ti - 1) / 2;
     const double dfrac = (NI + 1) / (2.0 * NI);
-    const bool t128 = wgrad_t128_ok(v.Mp);
-    int ns = t128 ? wgrad_t128_nsplit(v.D_out, v.Mp, nch)
-                  : choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 1024);
+    int ns = choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 512);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
-    std::vector<WgradJob> jobs128;
-    int start128 = 0;
     St.ns_big = ns;
+    St.ns_thin = ns;
     const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
-    int start = 0;
-    for (int j = v.alg_g ? 1 : 0; j <= v.D_out; ++j) {
-      WgradJob J{};
-      J.P = (j == 0) ? St.E : St.A;
-      J.Q = St.A;
-      J.scale = (j == 0) ? nullptr : St.VB + (int64_t)(j - 1) * ld;
-      J.out = St.part_big + (int64_t)j * ns * MMw;
-      J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = start;
-      J.sym = (j >= 1) ? 1 : 0; J.qrows16 = Mw / 16;     // P_d = sum_r v a a^T is symmetric; G = E A^T is not
-      J.ns_diag = ns_diag; J.pad = 0;
-      if (t128 && J.sym) {          // 128 x 128 tiles, every split covers every tile
-        const int T = Mw / 128;
-        J.ti = T; J.tj = T; J.task_start = start128;
-        start128 += ns * (T * (T + 1) / 2);
-        jobs128.push_back(J);
-      } else {
-        start += J.sym ? ns * n_off + ns_diag * ti : ns * ti * ti;
-        jobs.push_back(J);
-      }
-      red.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, J.sym ? v.Mp : 0, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
-    }
-    // the two thin products (A MB^T -> q_mu, GW [X|1]^T -> Z) ride in the same launch: same splits, partial last j tile
-    const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI), nt = ns;
-    St.ns_thin = nt;
+    const int tjq = ceil_div(v.DP16 / 16, NI), tjz = ceil_div(v.DinP16 / 16, NI);
     double* const out_q = St.part_thin;
-    double* const out_z = St.part_thin + (int64_t)nt * Mw * v.DP16;
-    jobs.push_back(WgradJob{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, start, 0, v.DP16 / 16, 0, 0});
-    start += nt * ti * tjq;
-    jobs.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, start, 0, v.DinP16 / 16, 0, 0});
-    start += nt * ti * tjz;
+    double* const out_z = St.part_thin + (int64_t)ns * Mw * v.DP16;
+    std::vector<WgradJob> jobsA, jobsB;
+    std::vector<RedJob> redA, redB;
+    int startA = 0, startB = 0;
+    // ---- A jobs: operands from the forward chain (A, [X^T;1]) and from the producer of this layer's upstream adjoints (VB, MB)
+    for (int j = 1; j <= v.D_out; ++j) {
+      WgradJob J{};
+      J.P = St.A; J.Q = St.A;
+      J.scale = St.VB + (int64_t)(j - 1) * ld;
+      J.out = St.part_big + (int64_t)j * ns * MMw;
+      J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = startA;
+      J.sym = 1; J.qrows16 = Mw / 16;                     // P_d = sum_r vbar_d a a^T is symmetric
+      J.ns_diag = ns_diag; J.pad = 0;
+      startA += ns * n_off + ns_diag * ti;
+      jobsA.push_back(J);
+      redA.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, v.Mp, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
+    }
+    jobsA.push_back(WgradJob{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, startA, 0, v.DP16 / 16, 0, 0});      // A mbar^T -> q_mu
+    startA += ns * ti * tjq;
+    redA.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DP16, 0, 0});
     if (St.mean_grad) {
       // trainable Linear mean function: d loss / d [A ; b] = [X ; 1]^T MB^T  (XT1 is zero-padded to whole 16*NI-row tiles)
       const int tim = ceil_div(v.DinP16 / 16, NI), tjm = ceil_div(v.DP16 / 16, NI);
-      jobs.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, start, 0, v.DP16 / 16, 0, 0});
-      start += nt * tim * tjm;
-      red.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, nt, 0, 0, 0, 0, (int64_t)16 * NI * tim * v.DP16, 0, 0});
+      jobsA.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, startA, 0, v.DP16 / 16, 0, 0});
+      startA += ns * tim * tjm;
+      redA.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, ns, 0, 0, 0, 0, (int64_t)16 * NI * tim * v.DP16, 0, 0});
     }
-    const int njobs_l = (int)jobs.size();
-    St.njobs = njobs_l;
-    St.tot_big = start;
+    // ---- B jobs: operands from this layer's backward chain (E, GW)
+    if (!v.alg_g) {
+      WgradJob J{};
+      J.P = St.E; J.Q = St.A; J.scale = nullptr;
+      J.out = St.part_big;
+      J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = startB;
+      J.sym = 0; J.qrows16 = Mw / 16; J.ns_diag = ns_diag; J.pad = 0;
+      startB += ns * ti * ti;
+      jobsB.push_back(J);
+      redB.push_back(RedJob{J.out, v.bigred, MM, ns, 0, 0, 0, 16, MMw, Mw, v.Mp});
+    }
+    jobsB.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, startB, 0, v.DinP16 / 16, 0, 0});   // GW [X|1]^T -> Z
+    startB += ns * ti * tjz;
+    redB.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
+    redB.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, (int)sm_hyp_parts(ld, v.Mp, v.D_in), 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
+    St.njobsA = (int)jobsA.size(); St.totA = startA;
+    St.njobsB = (int)jobsB.size(); St.totB = startB;
+    // combined list [A | B] with cumulative task numbers (one launch when nothing is overlapped)
+    std::vector<WgradJob> jobs(jobsA);
+    for (WgradJob J : jobsB) {
+      J.task_start += startA;
+      jobs.push_back(J);
+    }
+    St.njobs = (int)jobs.size();
+    St.tot_big = startA + startB;
     St.tot_thin = 0;
-    red.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, nt, 0, 0, 0, 0, (int64_t)Mw * v.DP16, 0, 0});
-    red.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, nt, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
-    red.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, sm_chain_enabled() ? (int)sm_hyp_parts(ld, v.Mp, v.D_in) : (int)nch, 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
+    St.red_off = (int)red.size();
+    St.red_nA = (int)redA.size();
+    red.insert(red.end(), redA.begin(), redA.end());
+    red.insert(red.end(), redB.begin(), redB.end());
+    St.red_n = (int)red.size() - St.red_off;
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
-    St.n128 = (int)jobs128.size();
-    St.tot128 = start128;
-    if (St.n128) DS_HIP(hipMemcpyAsync(St.wj128, jobs128.data(), jobs128.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
+    DS_HIP(hipMemcpyAsync(St.wjB, jobsB.data(), jobsB.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
-    St.red_n = (int)red.size() - St.red_off;
   }
   int blocks = 0;
   for (auto& r : red) {
@@ -1614,9 +1629,10 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
   }
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
-    St.red_blk0 = red[St.red_off].blk_start;
-    const int nxt = St.red_off + St.red_n;
-    St.red_blkn = (nxt < (int)red.size() ? red[nxt].blk_start : blocks) - St.red_blk0;
+    auto blk_at = [&](int idx) { return idx < (int)red.size() ? red[idx].blk_start : blocks; };
+    St.red_blk0 = blk_at(St.red_off);
+    St.red_blknA = blk_at(St.red_off + St.red_nA) - St.red_blk0;
+    St.red_blkn = blk_at(St.red_off + St.red_n) - St.red_blk0;
   }
   if ((int)red.size() > m->rjobs_cap) {
     dsdgp_set_error("internal: reduction job list overflow");
@@ -1640,6 +1656,14 @@ static int launch_finalize(dsdgp_model* m, hipStream_t st) {
   return DSDGP_OK;
 }
 
+// Reverse pass.  Streams (when the launches are long enough to pay for cross-stream events, overlap_on):
+//   main : [adjoint prep] backward chain L-1, L-2, ..., gfirst | join | gradient assembly
+//   side : A jobs of layer l as soon as its upstream adjoints exist — i.e. UNDER the backward chain of layer l (the P_d products read
+//          the forward chain's A and the adjoints only; they are 95 % of the weight-gradient flops and fill the MFMA pipe while the
+//          chain's workgroups sit in their load / reduction phases and in the launch's tail) — then the B jobs behind that chain, then
+//          (pipelined tail) this layer's split-K reduction and its P_d T_d / GS_d products.
+// Every reduction is fixed-order, so the schedule does not change a bit of the result (tests/test_gpu_parity.py:
+// test_stream_overlap_is_bitwise_neutral, tests/test_gpu_round3.py).
 static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
@@ -1647,14 +1671,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool overlap = overlap_on(m, n, S);
   DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
-  // Pipelined tail (DSDGP_PIPE_TAIL=1, OFF by default): every layer's reduction / M x M products / gradient assembly enqueued right
-  // behind its weight-gradient products instead of once for all layers after the last chain — the per-layer "bucket" a
-  // bucketed all-reduce would hang on.  Measured on one GPU it LOSES: config 2 0.643 -> 0.662 ms per
-  // step, configs 3 / 4 / 5 +0.2 .. 0.9 % — the three-fold launches of small kernels take more from the chains they run under than
-  // the shorter tail gives back (those kernels are latency-bound and as long for one layer as for three).  Parity-tested
-  // (tests/test_gpu_round2.py); kept for multi-GPU runs where a per-layer all-reduce could follow each bucket.
-  static const int pipe_on = getenv("DSDGP_PIPE_TAIL") ? atoi(getenv("DSDGP_PIPE_TAIL")) : 0;
-  const bool pipelined = pipe_on && overlap && !m->desc.white && m->n_wz == 0;
+  const bool early = overlap && m->force.early_wgrad != 0;
+  const bool pipelined = overlap && m->force.pipe_tail != 0 && !m->desc.white;
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1663,21 +1681,26 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     const int rep = St.rep_used;
     // transposed upstream adjoints MB / VB (+ [X^T ; 1]): written by the producer where one exists — the likelihood kernel
     // for the last layer, the next layer's backward chain for inner layers — else (first layer: S output rows per input
-    // row; generation-2 kernels; MultiClass) by k_adj_prep
-    const bool sm = sm_chain_enabled();
-    const bool fused = sm && ((last && m->fused_last) || (!last && l >= 1));
+    // row; MultiClass) by k_adj_prep
+    const bool fused = (last && m->fused_last) || (!last && l >= 1);
     if (!fused)
-    hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
-                       last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
-                       St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
-                       St.MB, St.VB, St.XT1, v.D_out + St.prop, St.prop);
+      hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
+                         last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
+                         St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
+                         St.MB, St.VB, St.XT1, v.D_out + St.prop, St.prop);
     DS_HIP(hipGetLastError());
+    if (early) {
+      DS_HIP(hipEventRecord(m->ev_adj[l], ctx->stream));
+      DS_HIP(hipStreamWaitEvent(m->side, m->ev_adj[l], 0));
+      DS_TRY(wgrad_launch(ctx, St.wj, St.njobsA, St.totA, St.ns_big, ld, ld, m->side));
+    }
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
-    b.flags = dbg_flags(); b.Asave = St.A; b.Csave = St.c_used ? St.C : nullptr; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB; b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
+    b.Asave = St.A; b.Csave = St.c_used ? St.C : nullptr; b.Tp = v.Tp; b.TpT = v.TpT; b.ldA = ld; b.VB = St.VB; b.MB = St.MB;
+    b.E = v.alg_g ? nullptr : St.E; b.GW = St.GW;
     b.dX = (l > gfirst) ? m->L[l - 1].dF : nullptr;
-    if (sm && l >= 2 && l > gfirst) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
+    if (l >= 2 && l > gfirst) {   // the previous layer is an inner layer: hand it its transposed adjoints directly
       LayerState& Pv = m->L[l - 1];
       b.dX = nullptr;
       b.MBp = Pv.MB; b.VBp = Pv.VB;
@@ -1687,40 +1710,28 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     b.mean_kind = St.d.mean_kind; b.mean_A = St.meanA;
     b.hyp_part = St.hyp_part;
     {   // few row blocks (the N-row first layer, small shards): spread the d-loop over up to four workgroups per row block.
-        // Only from Mp = 512 (DSDGP_BWD_SPLIT = 2 forces it everywhere, 0 disables): the hand-over needs two device-scope fences
+        // Only from Mp = 512 (bwd_split = 2 forces it everywhere, 0 disables): the hand-over needs two device-scope fences
         // per workgroup, which on this multi-XCD part write back / invalidate a whole L2 — measured +57 us on the 63-row-block
         // first layer of config 2 (M = 128) against -0.9 ms on the 32-row-block, 30-output first layer of config 4 (M = 512)
-      static const int bsplit_on = getenv("DSDGP_BWD_SPLIT") ? atoi(getenv("DSDGP_BWD_SPLIT")) : 1;
       const int64_t nblk = ld / 16;
-      const bool want = bsplit_on >= 2 || (bsplit_on == 1 && v.Mp > 256);
+      const bool want = m->force.bwd_split >= 2 || (m->force.bwd_split == 1 && v.Mp > 256);
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
-    if (sm_chain_enabled())
-      DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
-    else
-      DS_TRY(layer_bwd_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
-    int NI, ti;
-    wgrad_shapes(v.Mp, NI, ti);
+    DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     hipStream_t ws = ctx->stream;
-    // pipelined tail: the last layer of the reverse pass keeps its weight-gradient products and its assembly on the main stream
-    // (which has nothing else left), the others run theirs on the side stream under the following chains
-    if (overlap && !(pipelined && l == gfirst)) {
+    if (overlap) {
       DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
       ws = m->side;
     }
-    if (St.n128) DS_TRY(wgrad_t128_launch(ctx, St.wj128, St.n128, St.tot128, St.ns_big, ld, ld, ws));
-    DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, NI, NI, ws));
+    if (early) DS_TRY(wgrad_launch(ctx, St.wjB, St.njobsB, St.totB, St.ns_big, ld, ld, ws));
+    else DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, ws));
     if (pipelined) {
-      // this layer's reduction of the split-K partials, P_d T_d / GS_d products and gradient assembly right behind its products
+      // this layer's reduction of the split-K partials and its P_d T_d / GS_d products right behind its weight-gradient products
       hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, ws, m->rjobs + St.red_off, St.red_n, St.red_blk0);
-      DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, ws));
-      const LayerDev* lay1 = m->layers_dev + l;
-      hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, 1), dim3(256), 0, ws, lay1, kl_weight);
-      if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, 1), dim3(256), 0, ws, lay1);
-      hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, 1), dim3(256), 0, ws, lay1, m->grad, kl_weight);
       DS_HIP(hipGetLastError());
+      DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, ws));
     }
   }
   if (overlap) {
@@ -1731,28 +1742,29 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
   }
-  if (pipelined) return DSDGP_OK;
-  hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
-  DS_HIP(hipGetLastError());
-  if (m->desc.white) {
-    hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
-    DS_TRY(gemm_launch(ctx, m->gp_w1, 2 * L, m->t_w1));
-    hipLaunchKernelGGL(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
-    DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
-    DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
-  } else if (gfirst > 0) {
-    for (int l = gfirst; l < L; ++l) {
-      LayerState& Sq = m->L[l];
-      DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf + Sq.lq_n1 + Sq.lq_n2, Sq.lq_np, Sq.lq_tp));
+  if (!pipelined) {
+    hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
+    DS_HIP(hipGetLastError());
+    if (m->desc.white) {
+      hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+      DS_TRY(gemm_launch(ctx, m->gp_w1, 2 * L, m->t_w1));
+      hipLaunchKernelGGL(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+      DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
+      DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
+    } else if (gfirst > 0) {
+      for (int l = gfirst; l < L; ++l) {
+        LayerState& Sq = m->L[l];
+        DS_TRY(gemm_launch(ctx, Sq.lq + Sq.lq_nf + Sq.lq_n1 + Sq.lq_n2, Sq.lq_np, Sq.lq_tp));
+      }
+    } else {
+      DS_TRY(gemm_launch(ctx, m->gp_pt, m->n_pt, m->t_pt));
     }
-  } else {
-    DS_TRY(gemm_launch(ctx, m->gp_pt, m->n_pt, m->t_pt));
   }
   // the assembly of the layers that took part (their gradient entries; those of the layers below gfirst keep their old content)
   const LayerDev* lay = m->layers_dev + gfirst;
   const int La = L - gfirst;
   hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, La), dim3(256), 0, ctx->stream, lay, kl_weight);
-  if (m->n_wz && gfirst == 0) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));
+  if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));   // (wm of the layers below gfirst is stale: their WZ is never read)
   if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, La), dim3(256), 0, ctx->stream, lay);
   hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, La), dim3(256), 0, ctx->stream, lay, m->grad, kl_weight);
   DS_HIP(hipGetLastError());
@@ -1773,8 +1785,7 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   // fresh N(0,1) draws do not depend on the parameters: generate them on the side stream while Ku is factorised
   bool z_side = false;
   const bool ovl = overlap_on(m, n, S);
-  static const int z_side_on = getenv("DSDGP_Z_SIDE") ? atoi(getenv("DSDGP_Z_SIDE")) : 1;
-  if (ovl && z_side_on) {
+  if (ovl) {
     DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));     // after the previous step's readers of zbuf
     DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     for (int l = 0; l + 1 < L; ++l)
@@ -1795,7 +1806,7 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   // the last layer of a deep model has one output row per input row: its transposed adjoints come straight from the
   // likelihood kernel (no k_adj_prep launch on the critical path)
   const bool elementwise = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN || m->desc.lik_kind == DSDGP_LIK_BERNOULLI;
-  m->fused_last = with_grad && L > 1 && sm_chain_enabled() && elementwise;
+  m->fused_last = with_grad && L > 1 && elementwise;
   if (elementwise) {
     const int64_t ldt = round_up((int64_t)S * n, 16);
     if (m->fused_last) nblocks = ceil_div(ldt * DY, 256);
@@ -1905,8 +1916,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
-  if (sm_chain_enabled()) return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
-  return layer_fwd_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
+  return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
 }
 
 extern "C" int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, const double* z, double jitter,

@@ -1,0 +1,159 @@
+// Split-K "weight gradient" products over the data rows of the DS-DGP reverse pass (reverse mode of layers.py:184-217 w.r.t. Ku,
+// q_sqrt, q_mu, Z: sums over the rows of the minibatch x samples) on gfx950 fp64 MFMA.
+#include "layer.hpp"
+#include <stdlib.h>
+
+// out = P diag(scale) Q^T with P (rowsP x R), Q (rowsQ x R) both M-major.  Operands go straight from L2 / Infinity Cache to MFMA
+// registers: each lane loads 4 consecutive r (32 B) of one row, and the t-th of them is the k-operand of the t-th MFMA, so a
+// 16-row x 16-r fragment costs two 16-B loads per lane and no LDS.
+// K loop of one (split, tile) task; GUARD: only the first njv of the NJ column blocks of Q exist (thin products A MB^T,
+// GW [X|1]^T ride in the same launch as the M x M products, their Q has 16..DinP16 rows)
+// DIAG: diagonal tile of a symmetric result (P == Q): only the 16x16 blocks on or below the block diagonal are formed
+// (10 of 16 MFMAs per k-step at NI = NJ = 4); the reduction mirrors at 16-block granularity.
+template <int NI, int NJ, bool GUARD, bool DIAG>
+__device__ __forceinline__ void wgrad_loop(gcptr Pp, gcptr Qp, gcptr scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
+                                           int njv, d4 (&acc)[NI][NJ]) {
+  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
+    const int64_t rb = ch * 16;
+    d4 pa[NI], qb[NJ];
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) pa[ii] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Pp + (int64_t)16 * ii * ld + rb);
+    if constexpr (DIAG) {
+      // diagonal tile of a symmetric product: Q's rows ARE P's rows — no second load (a third less operand traffic per P_d at Mw = 128;
+      // the launch moves ~5.6 TB/s out of L2 / Infinity Cache and did not get faster with deeper prefetch: bandwidth, not latency)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) qb[jj] = pa[jj];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (!GUARD || jj < njv) qb[jj] = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(Qp + (int64_t)16 * jj * ld + rb);
+    }
+    if (scale) {
+      const d4 sc = *reinterpret_cast<const d4 __attribute__((address_space(1)))*>(scale + rb + 4 * g);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (!GUARD || jj < njv) qb[jj] *= sc;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+          if ((!GUARD || jj < njv) && (!DIAG || jj <= ii)) acc[ii][jj] = mfma_f64(pa[ii][t], qb[jj][t], acc[ii][jj]);
+  }
+}
+
+
+// ONE WORKGROUP per (job, split, tile) task; its four waves take a quarter of the split's row range each and reduce their
+// accumulators through LDS in a fixed order ((w0 + w2) + (w1 + w3)) before wave 0 stores the partial: a quarter of the split-K
+// partials of a one-wave-per-task form at the same wave-level parallelism (fp64 MFMA needs >= 2 waves per SIMD for its pipe rate).
+// Forms measured slower and removed in round 3: one wave per task, 32 x 32 tiles, 128 x 128 tiles staged through LDS.
+template <int NI, int NJ>
+__global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
+                                                    int64_t Rp, int total_tasks) {
+  __shared__ double red[2 * NI * NJ * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int w = blockIdx.x;
+  int jb = 0;
+  while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
+  const WgradJob J = jobs[jb];
+  int local = w - J.task_start;
+  int split, tile_i, tile_j, ns_eff = nsplit;
+  if (J.sym) {
+    const int n_off = J.ti * (J.ti - 1) / 2;
+    if (local < nsplit * n_off) {
+      split = local / n_off;
+      local = local % n_off;
+      tile_i = 1;
+      while (tile_i * (tile_i + 1) / 2 <= local) ++tile_i;
+      tile_j = local - tile_i * (tile_i - 1) / 2;
+    } else {
+      local -= nsplit * n_off;
+      split = local / J.ti;
+      tile_i = tile_j = local % J.ti;
+      ns_eff = J.ns_diag;
+    }
+  } else {
+    const int tiles = J.ti * J.tj;
+    split = local / tiles;
+    local = local % tiles;
+    tile_i = local / J.tj;
+    tile_j = local % J.tj;
+  }
+  const int64_t nch = Rp / 16;
+  const int64_t s_lo = split * nch / ns_eff, s_hi = (split + 1) * nch / ns_eff;
+  const int64_t c_lo = s_lo + (s_hi - s_lo) * wave / 4, c_hi = s_lo + (s_hi - s_lo) * (wave + 1) / 4;
+  const int njv = (J.qrows16 - NJ * tile_j < NJ) ? J.qrows16 - NJ * tile_j : NJ;
+  d4 acc[NI][NJ];
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = (d4){0, 0, 0, 0};
+  gcptr Pp = (gcptr)(J.P + (int64_t)(16 * NI * tile_i + c) * ld + 4 * g);      // job descriptors live in memory: see gcptr
+  gcptr Qp = (gcptr)(J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g);
+  const bool diag = J.sym && tile_i == tile_j && NI == NJ;
+  if (diag)
+    wgrad_loop<NI, NJ, false, true>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else if (njv == NJ)
+    wgrad_loop<NI, NJ, false, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
+  else
+    wgrad_loop<NI, NJ, true, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
+  // fixed-order tree over the four waves: slot s of a wave's accumulator lives at red[region][s][lane]
+  constexpr int NS = NI * NJ * 4;
+  if (wave >= 2) {
+    double* r = red + (wave - 2) * NS * 64 + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[((ii * NJ + jj) * 4 + t) * 64] = acc[ii][jj][t];
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const double* r = red + wave * NS * 64 + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ii][jj][t] += r[((ii * NJ + jj) * 4 + t) * 64];
+  }
+  __syncthreads();
+  if (wave == 1) {
+    double* r = red + lane;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[((ii * NJ + jj) * 4 + t) * 64] = acc[ii][jj][t];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const double* r = red + lane;
+  const int rowsP = 16 * NI * J.ti;
+  gptr o = (gptr)(J.out + (int64_t)split * rowsP * J.ldo);
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      if (jj < njv && !(diag && jj > ii)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] =
+              acc[ii][jj][t] + r[((ii * NJ + jj) * 4 + t) * 64];
+      }
+}
+
+int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
+                 hipStream_t stream) {
+  if (total_tasks <= 0) return DSDGP_OK;
+  hipStream_t st = stream ? stream : ctx->stream;
+  ProfScope ps(ctx, "wgrad", st);
+  hipLaunchKernelGGL((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}

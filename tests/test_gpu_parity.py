@@ -732,19 +732,6 @@ def test_step_up_single_point():
     assert np.isfinite(model.compute_log_likelihood())          # stochastic path with device-generated z
 
 
-def test_generation2_chain_kernels_still_agree():
-    # the LDS-panel chain kernels (DSDGP_CHAIN_SM=0, layer.hip) are kept as an alternative path: run a parity subset on them
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DSDGP_CHAIN_SM="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "layer_conditional or propagate_three or gradients_three or gradients_white or elbo_value"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("N,M,S", [(1, 5, 1), (2, 17, 3), (33, 31, 2), (257, 65, 5)])
 def test_ragged_sizes(N, M, S):
     # single rows, row counts and inducing counts that are not multiples of the 16-row / 16-column MFMA blocks, S = 1:

@@ -264,10 +264,7 @@ def test_negative_variance_gives_nan_like_the_reference():
 def test_csave_chain_and_alg_g_gradients(monkeypatch, white, M, D):
     """The production heuristics keep the c_d-saving backward chain and the algebraic dl/dKu assembly for large launches; force
     both onto small, oracle-checkable shapes (every Mp instance 32..256, both ownership tables, white and non-white)."""
-    monkeypatch.setenv("DSDGP_SAVE_C", "2")
-    monkeypatch.setenv("DSDGP_CS_MIN_BLOCKS", "0")
-    monkeypatch.setenv("DSDGP_CS_MIN_DOUT", "1")
-    monkeypatch.setenv("DSDGP_ALG_G", "1")
+    monkeypatch.setenv("DSDGP_FORCE", "save_c=2,cs_min_blocks=0,cs_min_dout=1,alg_g=1")      # read when the model is created
     rng = np.random.RandomState(M + D)
     N, S = 70, 3
     X, Y = rng.randn(N, D), rng.randn(N, 2)
@@ -503,13 +500,12 @@ def test_bernoulli_training_decreases_loss_and_classifies():
 
 def test_backward_d_split_forced_on_small_shapes(monkeypatch):
     """The d-split of the backward chain (several workgroups per row block share the per-output loop and hand their partial
-    tiles over through global memory) is used from Mp = 512 by default; DSDGP_BWD_SPLIT=2 forces it onto small shapes: dense
-    S_d form (M = 32, 100), Csave form (DSDGP_SAVE_C=2), white and non-white, D_out not divisible by the split."""
+    tiles over through global memory) is used from Mp = 512 by default; DSDGP_FORCE=bwd_split=2 forces it onto small shapes: dense
+    S_d form (M = 32, 100), Csave form (save_c=2), white and non-white, D_out not divisible by the split."""
     from tests.test_gpu_parity import _grad_check
-    monkeypatch.setenv("DSDGP_BWD_SPLIT", "2")
     rng = np.random.RandomState(77)
     for M, white, save_c in ((32, False, "1"), (100, True, "1"), (64, False, "2")):
-        monkeypatch.setenv("DSDGP_SAVE_C", save_c)
+        monkeypatch.setenv("DSDGP_FORCE", f"bwd_split=2,save_c={save_c},cs_min_blocks=0,cs_min_dout=1")
         N, D, S, DY = 70, 3, 3, 5
         X, Y = rng.randn(N, D), rng.randn(N, DY)
         Z = X[rng.permutation(N)[:min(M, N)]] if M <= N else np.vstack([X, rng.randn(M - N, D)])
@@ -605,60 +601,3 @@ def test_adam_step_refused_after_pruned_gradient():
         model.engine().adam_step(0.01)
     model._build_likelihood(X, Y, zs=zs, with_grad=True)          # a full gradient again
     model.engine().adam_step(0.01)
-
-
-def test_pipelined_tail_is_bitwise_neutral():
-    """DSDGP_PIPE_TAIL=1 (per-layer reduction + assembly behind each layer's weight-gradient products, off by default) must give
-    the gradient of the default schedule bit for bit: run in a subprocess (the switch is read once per process)."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "doubly-stochastic-dgp_amd")
-from tests.helpers import kern_spec, make_case
-rng = np.random.RandomState(4)
-N, D, M, S = 700, 4, 64, 8          # large enough for the two-stream schedule (n S Mp >= 2^20)
-X, Y = rng.randn(N, D), rng.randn(N, 2)
-Z = X[:M] + 0.01 * rng.randn(M, D)
-specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
-_, _, m = make_case(X, Y, Z, specs, S=S, num_data=3000)
-zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
-e = m._build_likelihood(X, Y, zs=zs, with_grad=True)
-g = m.engine().grad.cpu().numpy()
-print(repr(e)); print(g.tobytes().hex()[:64]); print(float(np.abs(g).sum()).hex())
-'''
-    outs = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, DSDGP_PIPE_TAIL=flag)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
-                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip().splitlines()[-3:])
-    assert outs[0] == outs[1]
-
-
-def test_wgrad_128_tile_form_matches():
-    """DSDGP_WGRAD_T128=1 (128 x 128-tile weight-gradient products staged through LDS; off by default because it measured slower)
-    against the oracle gradient, in a subprocess (the switch is read once per process): M = 128 and 256, symmetric P_d jobs."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "doubly-stochastic-dgp_amd")
-from tests.helpers import kern_spec, make_case
-from tests.test_gpu_parity import _grad_check
-for M in (128, 256):
-    rng = np.random.RandomState(M)
-    N, D, S = 150, 3, 3
-    X, Y = rng.randn(N, D), rng.randn(N, 2)
-    Z = rng.randn(M, D)
-    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("rbf", D, 0.8, 1.2)]
-    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=600)
-    zs = [rng.randn(S, N, D), rng.randn(S, N, 2)]
-    _grad_check(X, Y, spec, state, model, zs, S, num_data=600)
-print("OK")
-'''
-    env = dict(os.environ, DSDGP_WGRAD_T128="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])

@@ -1,0 +1,86 @@
+"""-m gpu tests added in round 3: the reverse pass's stream schedule (weight-gradient products of a layer launched UNDER that
+layer's backward chain, per-layer pipelined tail), the fused head kernel, the small-matrix GEMM path, the blocked / batched
+triangular solve and the fused tail.  Every schedule variant must reproduce the serial schedule bit for bit (all reductions on
+the path are fixed-order); values are compared with the oracle elsewhere (tests/test_gpu_parity.py).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import dgp_oracle as O
+from oracle import model as OM
+from tests.helpers import kern_spec, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from doubly_stochastic_dgp.engine import Context
+    return Context.get()
+
+
+def _dev(ctx, a):
+    return ctx.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _train_state(monkeypatch, force, no_overlap, steps=12, white=False):
+    """Parameters after `steps` Adam steps of a 3-layer model large enough for the two-stream schedule (n S Mp >= 2^20)."""
+    import os
+    monkeypatch.setenv("DSDGP_FORCE", force)
+    os.environ["DSDGP_NO_OVERLAP"] = "1" if no_overlap else "0"
+    try:
+        rng = np.random.RandomState(5)
+        N, D, M, S = 1000, 5, 96, 14
+        X, Y = rng.randn(N, D), rng.randn(N, 2)
+        Z = X[:M] + 0.05 * rng.randn(M, D)
+        specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("matern52", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
+        _, _, model = make_case(X, Y, Z, specs, S=S, num_data=N, q_sqrt_scale=1e-2, minibatch_size=800, white=white)
+        for _ in range(steps):
+            model.train_step(0.01)
+        elbo = model.train_step(0.01, sync=True)
+        eng = model.engine()
+        g = eng.grad.cpu().numpy().copy()
+        eng.sync_to_host()
+        th = np.concatenate([np.ravel(l.q_mu.value) for l in model.layers] + [np.ravel(l.feature.Z.value) for l in model.layers] +
+                            [np.ravel(l.q_sqrt.value) for l in model.layers])
+        return elbo, g, th
+    finally:
+        os.environ["DSDGP_NO_OVERLAP"] = "0"
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_reverse_pass_schedules_are_bitwise_neutral(monkeypatch, white):
+    """serial (one stream) == weight-gradient products behind their chain == A jobs under their chain == + pipelined tail."""
+    ref = _train_state(monkeypatch, "early_wgrad=0,pipe_tail=0", True, white=white)
+    assert np.isfinite(ref[0])
+    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=0", "early_wgrad=1,pipe_tail=1", "early_wgrad=0,pipe_tail=1"):
+        got = _train_state(monkeypatch, force, False, white=white)
+        assert got[0] == ref[0], force
+        assert np.array_equal(got[1], ref[1]), force
+        assert np.array_equal(got[2], ref[2]), force
+
+
+def test_early_wgrad_with_pruned_reverse_pass(monkeypatch):
+    """grad_from_layer > 0 (NatGradOptimizer's var_list): the schedule variants agree on the entries of the participating layers."""
+    outs = []
+    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=1"):
+        monkeypatch.setenv("DSDGP_FORCE", force)
+        rng = np.random.RandomState(9)
+        N, D, M, S = 800, 4, 128, 12
+        X, Y = rng.randn(N, D), rng.randn(N, 1)
+        Z = X[:M] + 0.05 * rng.randn(M, D)
+        specs = [kern_spec("rbf", D), kern_spec("rbf", D), kern_spec("rbf", D)]
+        _, _, model = make_case(X, Y, Z, specs, S=S, num_data=N)
+        zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 1)]
+        e = model._build_likelihood(X, Y, zs=zs, with_grad=True, grad_from_layer=2)
+        g = model.engine().gradient_dict()
+        outs.append((e, g["l2.q_mu"].copy(), g["l2.q_sqrt"].copy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
