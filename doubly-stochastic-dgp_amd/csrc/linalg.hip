@@ -259,20 +259,132 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmProblem* __restrict_
       }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Short-K variant for the M <= 256 algebra of the training step (Ku^-1 = Lu^-T Lu^-1, Lu^-1 q_sqrt_d, S_d, U_d, U_d U_d^T, P_d T_d, GS_d
+// at M = 128: a few dozen 64 x 64 tiles of 4 MFLOP problems).  The LDS-staged kernel above pays one global round trip + two
+// barriers per 16-wide k-tile with a single tile of prefetch: eight dependent round trips = 14 us for a 128^3 problem, four times
+// per step.  Here there is NO LDS and NO barrier: each wave owns a 32 x 32 quarter of the tile and feeds the MFMAs straight from
+// global memory, as the weight-gradient products do — the operand that is contiguous along k comes in as ONE 32-byte load per lane
+// and 16-wide k-block (lane (g, c) takes k = 4 g .. 4 g + 3 and uses them in MFMA steps s = 0..3; the other operand's rows 4 g + s are
+// four 8-byte loads, 128 contiguous bytes across the 16 c-lanes), all loads of four k-blocks in flight at once.  Same descriptor,
+// structure hints and epilogue as k_gemm_grouped.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restrict__ probs, int nprob) {
+  const int bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  const GemmProblem P = probs[p];
+  int t = bid - P.tile_start;
+  const int tiles = P.tiles_m * P.tiles_n;
+  int b0, b1;
+  if (P.batch_reduce) {
+    b0 = 0;
+    b1 = P.batch;
+  } else {
+    b0 = t / tiles;
+    b1 = b0 + 1;
+    t = t % tiles;
+  }
+  const int m0 = (t / P.tiles_n) * GT, n0 = (t % P.tiles_n) * GT;
+  if (P.lower_only && n0 > m0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  int kmin = 0, kmax = P.k;
+  if (P.tri & 1) kmin = max(kmin, n0 + 32 * wc);
+  if (P.tri & 2) kmax = min(kmax, m0 + 32 * wr + 32);
+  if (P.tri & 4) kmax = min(kmax, n0 + 32 * wc + 32);
+  if (P.tri & 8) kmin = max(kmin, m0 + 32 * wr);
+  const int kb_lo = kmin / 16, kb_hi = (min(kmax, P.k) + 15) / 16;
+  // rows / columns of this wave's 2 x 2 blocks, clamped for the loads (partial tiles: thin right-hand sides, M = 16 * odd)
+  int ra[2], cb[2];
+  bool rok[2], cok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + 32 * wr + 16 * i + c, q = n0 + 32 * wc + 16 * i + c;
+    rok[i] = r < P.m; cok[i] = q < P.n;
+    ra[i] = rok[i] ? r : P.m - 1;
+    cb[i] = cok[i] ? q : P.n - 1;
+  }
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+  typedef const d4 __attribute__((address_space(1)))* gd4;
+  for (int b = b0; b < b1; ++b) {
+    gcptr A = (gcptr)(P.A + (int64_t)b * P.sA);
+    gcptr B = (gcptr)(P.B + (int64_t)b * P.sB);
+#pragma unroll 4
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+      const int k0 = 16 * kb + 4 * g;
+      d4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!P.transA) {
+          av[i] = *reinterpret_cast<gd4>(A + (int64_t)ra[i] * P.lda + k0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) av[i][s] = A[(int64_t)(k0 + s) * P.lda + ra[i]];
+        }
+        if (P.transB) {
+          bv[i] = *reinterpret_cast<gd4>(B + (int64_t)cb[i] * P.ldb + k0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bv[i][s] = B[(int64_t)(k0 + s) * P.ldb + cb[i]];
+        }
+        if (!rok[i]) av[i] = (d4){0, 0, 0, 0};
+        if (!cok[i]) bv[i] = (d4){0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(av[i][s], bv[j][s], acc[i][j]);
+    }
+  }
+  gptr Cp = (gptr)(P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC));
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 32 + ib * 16 + g + 4 * r;
+        const int col = n0 + wc * 32 + jb * 16 + c;
+        if (row < P.m && col < P.n) {
+          double v = P.alpha * acc[ib][jb][r];
+          if (P.beta != 0.0) v += P.beta * Cp[(int64_t)row * P.ldc + col];
+          Cp[(int64_t)row * P.ldc + col] = v;
+          if ((P.tri & 16) && n0 < m0) Cp[(int64_t)col * P.ldc + row] = v;     // mirror of a symmetric result
+        }
+      }
+}
+
 // Launches whose largest problem is at least GEMM_BIG_MIN in both output dimensions take the 128 x 128 kernel; the planned
-// tile count carries the choice in GEMM_BIG_FLAG so that every call site keeps passing plan -> launch unchanged.
+// tile count carries the choice in GEMM_BIG_FLAG / GEMM_SMALL_FLAG so that every call site keeps passing plan -> launch unchanged.
 #define GEMM_BIG_FLAG (1 << 30)
 #define GEMM_BIG_MIN 512
-static int gemm_big_enabled() {
-  static const int on = getenv("DSDGP_GEMM_BIG") ? atoi(getenv("DSDGP_GEMM_BIG")) : 1;
-  return on;
+// Launches whose every problem is short in k (<= GEMM_SMALL_K, whole 16-blocks, 32-byte aligned rows) take the LDS-free kernel.
+#define GEMM_SMALL_FLAG (1 << 29)
+#define GEMM_SMALL_K 256
+static bool gemm_small_ok(const GemmProblem& P) {
+  if (P.k > GEMM_SMALL_K || P.k % 16 != 0 || P.m < 1 || P.n < 1) return false;
+  auto al = [](const double* p, int64_t ld, int64_t st) { return ((uintptr_t)p & 31) == 0 && ld % 4 == 0 && st % 4 == 0; };
+  if (!P.transA && !al(P.A, P.lda, P.sA)) return false;      // the operand contiguous along k is read with 32-byte loads
+  if (P.transB && !al(P.B, P.ldb, P.sB)) return false;
+  if (P.C == P.A || P.C == P.B) return false;                // in-place updates: a wave would overwrite what its neighbour still reads
+  return true;
 }
 
 int gemm_plan(GemmProblem* host, int nprob, bool allow_big) {
-  int big = 0;
-  if (allow_big && gemm_big_enabled())
+  int big = 0, small = nprob > 0;
+  if (allow_big)
     for (int i = 0; i < nprob; ++i)
       if (host[i].m >= GEMM_BIG_MIN && host[i].n >= GEMM_BIG_MIN && host[i].k >= 64) big = 1;
+  for (int i = 0; i < nprob; ++i) small = small && gemm_small_ok(host[i]);
+  if (big) small = 0;
   const int T = big ? BT : GT;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -282,19 +394,25 @@ int gemm_plan(GemmProblem* host, int nprob, bool allow_big) {
     P.tile_start = total;
     total += P.tiles_m * P.tiles_n * (P.batch_reduce ? 1 : P.batch);
   }
-  return big ? (total | GEMM_BIG_FLAG) : total;
+  return big ? (total | GEMM_BIG_FLAG) : (small ? (total | GEMM_SMALL_FLAG) : total);
 }
 
-int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream) {
-  const bool big = (total_tiles & GEMM_BIG_FLAG) != 0;
-  total_tiles &= ~GEMM_BIG_FLAG;
-  if (total_tiles <= 0) return DSDGP_OK;
-  hipStream_t st = stream ? stream : ctx->stream;
-  ProfScope ps(ctx, "gemm", st);
+static void gemm_dispatch(const GemmProblem* dev, int nprob, int planned, hipStream_t st) {
+  const bool big = (planned & GEMM_BIG_FLAG) != 0, small = (planned & GEMM_SMALL_FLAG) != 0;
+  const int total_tiles = planned & ~(GEMM_BIG_FLAG | GEMM_SMALL_FLAG);
+  if (total_tiles <= 0) return;
   if (big)
     hipLaunchKernelGGL(k_gemm_big, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+  else if (small)
+    hipLaunchKernelGGL(k_gemm_small, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
   else
     hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+}
+int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream) {
+  if ((total_tiles & ~(GEMM_BIG_FLAG | GEMM_SMALL_FLAG)) <= 0) return DSDGP_OK;
+  hipStream_t st = stream ? stream : ctx->stream;
+  ProfScope ps(ctx, "gemm", st);
+  gemm_dispatch(dev, nprob, total_tiles, st);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -1026,14 +1144,7 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
   ProfScope ps(ctx, "potrf");
   const int nb = P.nb, batch = P.batch;
   int gi = 0;
-  auto launch = [&](int i) {
-    const bool big = (P.tiles[i] & (1 << 30)) != 0;
-    const int tiles = P.tiles[i] & ~(1 << 30);
-    if (big)
-      hipLaunchKernelGGL(k_gemm_big, dim3(tiles), dim3(256), 0, ctx->stream, P.gp + P.first[i], P.nprob[i]);
-    else
-      hipLaunchKernelGGL(k_gemm_grouped, dim3(tiles), dim3(256), 0, ctx->stream, P.gp + P.first[i], P.nprob[i]);
-  };
+  auto launch = [&](int i) { gemm_dispatch(P.gp + P.first[i], P.nprob[i], P.tiles[i], ctx->stream); };
   if (!P.from_tri) {
     if (P.scal)
       for (int b = 0; b < batch; ++b) DS_HIP(hipMemsetAsync(P.scal + b * P.scal_stride, 0, 2 * sizeof(double), ctx->stream));
