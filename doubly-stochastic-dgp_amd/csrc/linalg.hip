@@ -269,6 +269,41 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmProblem* __restrict_
 // four 8-byte loads, 128 contiguous bytes across the 16 c-lanes), all loads of four k-blocks in flight at once.  Same descriptor,
 // structure hints and epilogue as k_gemm_grouped.
 // ------------------------------------------------------------------------------------------------------
+// k loop of one wave's 32 x 32 quarter; TA / TB as template parameters so that the loop body is ONE basic block (a run-time
+// transpose test inside it put every load behind its own branch: the round trips serialised and the kernel measured 20 us for
+// a 128^3 problem, slower than the LDS-staged one)
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_small_loop(gcptr A, gcptr B, int64_t lda, int64_t ldb, const int (&ra)[2], const int (&cb)[2],
+                                                int kb_lo, int kb_hi, int g, d4 (&acc)[2][2]) {
+  typedef const d4 __attribute__((address_space(1)))* gd4;
+#pragma unroll 4
+  for (int kb = kb_lo; kb < kb_hi; ++kb) {
+    const int k0 = 16 * kb + 4 * g;
+    d4 av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (!TA) {
+        av[i] = *reinterpret_cast<gd4>(A + (int64_t)ra[i] * lda + k0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[i][s] = A[(int64_t)(k0 + s) * lda + ra[i]];
+      }
+      if constexpr (TB) {
+        bv[i] = *reinterpret_cast<gd4>(B + (int64_t)cb[i] * ldb + k0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[i][s] = B[(int64_t)(k0 + s) * ldb + cb[i]];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(av[i][s], bv[j][s], acc[i][j]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restrict__ probs, int nprob) {
   const int bid = blockIdx.x;
   int p = 0;
@@ -296,53 +331,26 @@ __global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restric
   if (P.tri & 4) kmax = min(kmax, n0 + 32 * wc + 32);
   if (P.tri & 8) kmin = max(kmin, m0 + 32 * wr);
   const int kb_lo = kmin / 16, kb_hi = (min(kmax, P.k) + 15) / 16;
-  // rows / columns of this wave's 2 x 2 blocks, clamped for the loads (partial tiles: thin right-hand sides, M = 16 * odd)
+  // rows / columns of this wave's 2 x 2 blocks, clamped for the loads (partial tiles: thin right-hand sides, M = 16 * odd): the
+  // clamped lanes compute a copy of the last row / column, which the guarded epilogue drops
   int ra[2], cb[2];
-  bool rok[2], cok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = m0 + 32 * wr + 16 * i + c, q = n0 + 32 * wc + 16 * i + c;
-    rok[i] = r < P.m; cok[i] = q < P.n;
-    ra[i] = rok[i] ? r : P.m - 1;
-    cb[i] = cok[i] ? q : P.n - 1;
+    ra[i] = min(m0 + 32 * wr + 16 * i + c, P.m - 1);
+    cb[i] = min(n0 + 32 * wc + 16 * i + c, P.n - 1);
   }
   d4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
-  typedef const d4 __attribute__((address_space(1)))* gd4;
   for (int b = b0; b < b1; ++b) {
     gcptr A = (gcptr)(P.A + (int64_t)b * P.sA);
     gcptr B = (gcptr)(P.B + (int64_t)b * P.sB);
-#pragma unroll 4
-    for (int kb = kb_lo; kb < kb_hi; ++kb) {
-      const int k0 = 16 * kb + 4 * g;
-      d4 av[2], bv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!P.transA) {
-          av[i] = *reinterpret_cast<gd4>(A + (int64_t)ra[i] * P.lda + k0);
-        } else {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) av[i][s] = A[(int64_t)(k0 + s) * P.lda + ra[i]];
-        }
-        if (P.transB) {
-          bv[i] = *reinterpret_cast<gd4>(B + (int64_t)cb[i] * P.ldb + k0);
-        } else {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) bv[i][s] = B[(int64_t)(k0 + s) * P.ldb + cb[i]];
-        }
-        if (!rok[i]) av[i] = (d4){0, 0, 0, 0};
-        if (!cok[i]) bv[i] = (d4){0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(av[i][s], bv[j][s], acc[i][j]);
-    }
+    if (!P.transA && !P.transB) gemm_small_loop<false, false>(A, B, P.lda, P.ldb, ra, cb, kb_lo, kb_hi, g, acc);
+    else if (!P.transA) gemm_small_loop<false, true>(A, B, P.lda, P.ldb, ra, cb, kb_lo, kb_hi, g, acc);
+    else if (!P.transB) gemm_small_loop<true, false>(A, B, P.lda, P.ldb, ra, cb, kb_lo, kb_hi, g, acc);
+    else gemm_small_loop<true, true>(A, B, P.lda, P.ldb, ra, cb, kb_lo, kb_hi, g, acc);
   }
   gptr Cp = (gptr)(P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC));
 #pragma unroll

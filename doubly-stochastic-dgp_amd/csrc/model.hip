@@ -153,7 +153,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -175,6 +175,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "bwd_split") m->force.bwd_split = v;
       else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
+      else if (k == "side_prio") m->force.side_prio = v;
     }
     pos = end + 1;
   }
@@ -1289,7 +1290,16 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DS_HIP(hipStreamSynchronize(st));
   m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
-  DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+  if (m->force.side_prio) {
+    // the side stream's launches (weight-gradient products, parameter-only algebra) run UNDER a chain launch whose workgroups fill
+    // every CU: at equal priority their workgroups were dispatched only when the chain's queue had drained (a 17 us launch took
+    // 136 us, profiles/r03_timeline_*.txt) — with the higher priority they take the slots the chain's workgroups free
+    int least = 0, greatest = 0;
+    DS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DS_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, greatest));
+  } else {
+    DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+  }
   for (int l = 0; l < L; ++l) {
     DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
     DS_HIP(hipEventCreateWithFlags(&m->ev_adj[l], hipEventDisableTiming));
@@ -1673,6 +1683,23 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
   const bool early = overlap && m->force.early_wgrad != 0;
   const bool pipelined = overlap && m->force.pipe_tail != 0 && !m->desc.white;
+  // split-K reduction + P_d T_d / GS_d products of one layer right behind its weight-gradient products (pipelined tail)
+  auto layer_tail = [&](LayerState& St, hipStream_t st) -> int {
+    hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
+    DS_HIP(hipGetLastError());
+    return gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st);
+  };
+  int pendingB = -1;      // layer whose B jobs wait for the next layer's A jobs to be enqueued first (the side stream is in-order: a
+                          // small B launch stuck behind the co-running chain must not hold the big A launch back)
+  auto flush_B = [&]() -> int {
+    if (pendingB < 0) return DSDGP_OK;
+    LayerState& Sp = m->L[pendingB];
+    DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[pendingB], 0));
+    DS_TRY(wgrad_launch(ctx, Sp.wjB, Sp.njobsB, Sp.totB, Sp.ns_big, Sp.ld_used, Sp.ld_used, m->side));
+    if (pipelined) DS_TRY(layer_tail(Sp, m->side));
+    pendingB = -1;
+    return DSDGP_OK;
+  };
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1689,11 +1716,15 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
                          St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
                          St.MB, St.VB, St.XT1, v.D_out + St.prop, St.prop);
     DS_HIP(hipGetLastError());
-    if (early) {
+    // the lowest layer of the reverse pass keeps its products on the main stream: nothing is left to run them under, and the
+    // join below then waits for side-stream work that finished long ago instead of for a just-in-time signal
+    const bool on_main = early && l == gfirst && L - gfirst > 1;
+    if (early && !on_main) {
       DS_HIP(hipEventRecord(m->ev_adj[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_adj[l], 0));
       DS_TRY(wgrad_launch(ctx, St.wj, St.njobsA, St.totA, St.ns_big, ld, ld, m->side));
     }
+    DS_TRY(flush_B());
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
@@ -1719,21 +1750,20 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
     DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
-    hipStream_t ws = ctx->stream;
-    if (overlap) {
+    if (early && !on_main) {
+      DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
+      pendingB = l;
+    } else if (overlap && !on_main) {
       DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
       DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
-      ws = m->side;
-    }
-    if (early) DS_TRY(wgrad_launch(ctx, St.wjB, St.njobsB, St.totB, St.ns_big, ld, ld, ws));
-    else DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, ws));
-    if (pipelined) {
-      // this layer's reduction of the split-K partials and its P_d T_d / GS_d products right behind its weight-gradient products
-      hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, ws, m->rjobs + St.red_off, St.red_n, St.red_blk0);
-      DS_HIP(hipGetLastError());
-      DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, ws));
+      DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, m->side));
+      if (pipelined) DS_TRY(layer_tail(St, m->side));
+    } else {
+      DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, ctx->stream));
+      if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
     }
   }
+  DS_TRY(flush_B());
   if (overlap) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and

@@ -42,6 +42,10 @@ class Minibatch:
         self._pos += self.batch_size
         return self._perm, start, self._epoch
 
+    def next_chunk(self, k):
+        """The indices of the next k minibatches, concatenated (k * batch_size,)."""
+        return np.concatenate([self.next_indices() for _ in range(int(k))])
+
     def next_indices(self):
         out = []
         need = self.batch_size
@@ -103,16 +107,22 @@ class DGP_Base(Parameterized):
             return Xd, Yd
         eng = self.engine()
         ctx = eng.ctx
-        span = self._minibatch.next_span()
-        if span is not None:
-            perm, start, epoch = span
-            if getattr(self, "_perm_epoch", None) != epoch:          # one index upload per epoch
-                self._perm_dev = ctx.torch.as_tensor(perm.astype(np.int64)).to(Xd.device)
-                self._perm_epoch = epoch
-            idx, off, n = self._perm_dev, start, self.minibatch_size
-        else:                                                      # minibatch straddles an epoch boundary
-            idx = ctx.torch.as_tensor(self._minibatch.next_indices()).to(Xd.device)
-            off, n = 0, idx.shape[0]
+        mb = self._minibatch
+        # The row indices of the next CHUNK minibatches are drawn on the host in one go and uploaded once (pinned, asynchronous);
+        # a step then only moves an offset.  One upload per epoch (or per step when a minibatch straddles an epoch boundary — 2 of
+        # every 7 steps at 7372 / 1000) stalled the host behind the stream and the GPU behind the host: ~50 us on each such step.
+        if getattr(self, "_idx_src", None) is not mb or self._idx_pos >= self._idx_cnt:
+            k = max(1, min(512, (1 << 18) // max(1, mb.batch_size)))
+            host = ctx.torch.from_numpy(mb.next_chunk(k))
+            try:
+                host = host.pin_memory()
+            except RuntimeError:
+                pass
+            self._idx_host = host                                  # alive until the copy has run
+            self._idx_dev = host.to(Xd.device, non_blocking=True)
+            self._idx_src, self._idx_pos, self._idx_cnt = mb, 0, k
+        idx, off, n = self._idx_dev, self._idx_pos * mb.batch_size, mb.batch_size
+        self._idx_pos += 1
         Xb, Yb = ctx.empty(n, Xd.shape[1]), ctx.empty(n, Yd.shape[1])
         _lib.check(ctx.lib.dsdgp_gather_rows2(ctx.handle, C.c_void_p(Xd.data_ptr()), Xd.shape[1], C.c_void_p(Xb.data_ptr()),
                                               C.c_void_p(Yd.data_ptr()), Yd.shape[1], C.c_void_p(Yb.data_ptr()),
