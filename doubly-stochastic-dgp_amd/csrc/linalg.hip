@@ -430,42 +430,6 @@ int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_til
 // ------------------------------------------------------------------------------------------------------
 // INLDS: the working matrix lives in LDS (n <= 128: n x (n+4) doubles <= 135 KB of the 160 KB), so the ~35 dependent
 // phases of the factorisation pay LDS latency instead of L2 round trips; the result is written back at the end.
-template <int J, int K>
-struct Chol16Upd {
-  static __device__ __forceinline__ void run(double (&a)[16], double lij) {
-    const double lkj = bcast_lane<K>(lij);
-    a[K] -= lij * lkj;
-    Chol16Upd<J, K + 1>::run(a, lij);
-  }
-};
-template <int J>
-struct Chol16Upd<J, 16> {
-  static __device__ __forceinline__ void run(double (&)[16], double) {}
-};
-template <int J>
-struct Chol16 {
-  static __device__ __forceinline__ void run(double (&a)[16], int i, double& myinv, int& bad) {
-    const double ajj = bcast_lane<J>(a[J]);
-    if (!(ajj > 0.0) && bad == 0) bad = J + 1;
-    // hardware v_rsq_f64 seed + two Newton steps (the library rsqrt() expands to a ~800-cycle sqrt + divide chain,
-    // 16 of them in sequence per diagonal block dominated the whole factorisation)
-    double inv = __builtin_amdgcn_rsq(ajj);
-    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
-    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
-    myinv = (i == J) ? inv : myinv;
-    // no (i >= J) masking here: lanes above the diagonal carry garbage that never reaches a lower lane and is
-    // zeroed when the block is stored — keeps the 16-pivot chain free of exec-mask branches
-    const double lij = a[J] * inv;
-    a[J] = lij;
-    Chol16Upd<J, J + 1>::run(a, lij);
-    Chol16<J + 1>::run(a, i, myinv, bad);
-  }
-};
-template <>
-struct Chol16<16> {
-  static __device__ __forceinline__ void run(double (&)[16], int, double&, int&) {}
-};
-
 // INLDS: the working matrix lives in LDS (n <= 128: n x (n+4) doubles <= 135 KB of the 160 KB), so the dependent phases
 // of the factorisation pay LDS latency instead of L2 round trips; the factor is written back at the end.
 // Triangular inverse: block-column forward substitution — wave w owns block columns {w, nb-1-w, ...} of X = L^-1 and keeps

@@ -64,3 +64,47 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
                   int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri);
 int bigchol_run(dsdgp_ctx* ctx, const BigChol& P);
 void bigchol_free(BigChol& P);
+
+#ifdef __HIPCC__
+// ---- Cholesky of a 16-column panel held one ROW per lane (a[j] = column j of this lane's row).  Lanes 0..15 hold the 16 x 16
+// diagonal block; any further lanes hold rows of the panel BELOW it and come out as L_ij = A_ij L_jj^-T for free: at pivot J every
+// lane scales its column-J entry by 1 / l_JJ and subtracts l_iJ l_KJ from its entries K > J, where l_KJ is read from diagonal lane K
+// with v_readlane (lane indices are compile-time constants).  One hardware v_rsq_f64 + two Newton steps per pivot (the library
+// rsqrt() expands to a ~800-cycle sqrt + divide chain), no f64 division, no exec-mask branches in the 16-pivot chain.
+template <int J, int K>
+struct Chol16Upd {
+  static __device__ __forceinline__ void run(double (&a)[16], double lij) {
+    const double lkj = bcast_lane<K>(lij);
+    a[K] -= lij * lkj;
+    Chol16Upd<J, K + 1>::run(a, lij);
+  }
+};
+template <int J>
+struct Chol16Upd<J, 16> {
+  static __device__ __forceinline__ void run(double (&)[16], double) {}
+};
+template <int J>
+struct Chol16 {
+  static __device__ __forceinline__ void run(double (&a)[16], int i, double& myinv, int& bad) {
+    const double ajj = bcast_lane<J>(a[J]);
+    if (!(ajj > 0.0) && bad == 0) bad = J + 1;
+    // hardware v_rsq_f64 seed + two Newton steps (the library rsqrt() expands to a ~800-cycle sqrt + divide chain,
+    // 16 of them in sequence per diagonal block dominated the whole factorisation)
+    double inv = __builtin_amdgcn_rsq(ajj);
+    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * ajj * inv, inv, 1.5);
+    myinv = (i == J) ? inv : myinv;
+    // no (i >= J) masking here: lanes above the diagonal carry garbage that never reaches a lower lane and is
+    // zeroed when the block is stored — keeps the 16-pivot chain free of exec-mask branches
+    const double lij = a[J] * inv;
+    a[J] = lij;
+    Chol16Upd<J, J + 1>::run(a, lij);
+    Chol16<J + 1>::run(a, i, myinv, bad);
+  }
+};
+template <>
+struct Chol16<16> {
+  static __device__ __forceinline__ void run(double (&)[16], int, double&, int&) {}
+};
+
+#endif

@@ -133,6 +133,8 @@ struct dsdgp_model {
   bool uniform_big = false;     // all layers share M and Mp >= 256: ONE batched multi-workgroup Cholesky for all layers
   BigChol big_all;
   bool need_hyp_part = false;
+  bool head_ok = false;         // every layer has Mp <= 128 and D_in <= 16: parameter transforms, Ku, its factorisation and inverse
+                                // factor (and the inner layers' N(0,1) draws) in ONE launch (k_head, head_impl.hpp)
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
   // arguments of the pending k_finalize (value + likelihood-variance gradient): launched on the side stream beside the
   // backward chain when streams overlap, otherwise on the main stream after it
@@ -153,7 +155,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 0, head = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -176,6 +178,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
       else if (k == "side_prio") m->force.side_prio = v;
+      else if (k == "head") m->force.head = v;
     }
     pos = end + 1;
   }
@@ -462,6 +465,42 @@ __global__ __launch_bounds__(256) void k_prep_kuu(const double* __restrict__ the
     kuu_body(v, theta, jitter, blockIdx.x - nprep, gridDim.x - nprep);
 }
 
+// Philox4x32-10 + Box–Muller: replaces tf.random_normal (layers.py:101-102)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+// pairs t0, t0 + nth, ... of the stream (seed, stream): out[2 i], out[2 i + 1] from counter i
+__device__ __forceinline__ void randn_body(uint64_t seed, uint64_t stream, int64_t count, double* __restrict__ out, int64_t t0, int64_t nth) {
+  const int64_t npairs = (count + 1) / 2;
+  for (int64_t i = t0; i < npairs; i += nth) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const uint64_t a = ((uint64_t)c[1] << 32) | c[0], b = ((uint64_t)c[3] << 32) | c[2];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    out[2 * i] = rad * cs;
+    if (2 * i + 1 < count) out[2 * i + 1] = rad * sn;
+  }
+}
+// fresh N(0,1) draws of the inner layers generated inside the head launch (they depend on nothing)
+struct HeadRand {
+  double* out[DSDGP_MAX_LAYERS];
+  int64_t count[DSDGP_MAX_LAYERS];      // 0: this layer takes no draw from here
+  uint64_t seed;
+  int32_t nblk;                         // block columns of the launch that generate draws
+};
+
+#include "head_impl.hpp"
+
 __device__ double block_sum_256(double x, double* sh) {
   x = sum_wave(x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -654,30 +693,8 @@ __global__ __launch_bounds__(256) void k_finalize(const LayerDev* __restrict__ l
   }
 }
 
-// Philox4x32-10 + Box–Muller: replaces tf.random_normal (layers.py:101-102)
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
 __global__ void k_randn(uint64_t seed, uint64_t stream, int64_t count, double* __restrict__ out) {
-  const int64_t npairs = (count + 1) / 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
-    const uint64_t a = ((uint64_t)c[1] << 32) | c[0], b = ((uint64_t)c[3] << 32) | c[2];
-    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    out[2 * i] = rad * cs;
-    if (2 * i + 1 < count) out[2 * i + 1] = rad * sn;
-  }
+  randn_body(seed, stream, count, out, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 __global__ void k_reparam(const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ z,
@@ -1249,6 +1266,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     ld[l].hyp_parts = v.hyp_parts;
     if (!fold) m->need_hyp_part = true;
   }
+  m->head_ok = m->force.head != 0 && !m->uniform_big;
+  for (int l = 0; l < L; ++l) m->head_ok = m->head_ok && m->L[l].dev.Mp <= HEAD_MAX_N && m->L[l].dev.D_in <= HEAD_MAX_DIN;
   m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
   m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
   m->n_pt = (int)gpt.size(); m->t_pt = gemm_plan(gpt.data(), m->n_pt);
@@ -1359,18 +1378,37 @@ static int join_prep(dsdgp_model* m) {
 // U_d U_d^T — which nothing needs before the backward pass / the final reduction: with `side` it runs on the side stream
 // concurrently with the forward layers and the caller joins (join_prep) where it is first consumed.
 // (`side` = run that part on the side stream.)
-static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = false) {
+static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = false, const HeadRand* hr = nullptr) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
   const bool keep_kuu = m->track_theta && m->kuu_valid;
-  hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
-                     m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
-                     m->prep_blocks, keep_kuu ? 1 : 0);
-  DS_HIP(hipGetLastError());
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
-  if (keep_kuu) {
+  if (m->head_ok) {
+    ProfScope ps(ctx, "potrf");
+    const size_t lds = head_lds_bytes(mp_max);
+    static size_t lds_set = 0;     // the attribute is sticky: one driver call per size
+    if (lds > lds_set) {
+      DS_HIP(hipFuncSetAttribute((const void*)k_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set = lds;
+    }
+    HeadRand none{};
+    const HeadRand& r = hr ? *hr : none;
+    const int nprep = std::max(32, m->prep_blocks / 2);
+    hipLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk, L), dim3(HEAD_THREADS), lds, ctx->stream, m->theta, m->layers_dev, m->lik_const,
+                       m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep, keep_kuu ? 1 : 0,
+                       m->desc.white ? 1 : 0, r);
+    DS_HIP(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
+                       m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
+                       m->prep_blocks, keep_kuu ? 1 : 0);
+    DS_HIP(hipGetLastError());
+  }
+  if (m->head_ok) {
+    // (factorised inside k_head)
+  } else if (keep_kuu) {
     // Z and the kernel hyper-parameters are those of the previous evaluation: Lu, Lu^-1, log det stay
   } else if (m->uniform_big) {
     DS_TRY(bigchol_run(ctx, m->big_all));
@@ -1813,9 +1851,20 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   // fresh N(0,1) draws do not depend on the parameters: generate them on the side stream while Ku is factorised
-  bool z_side = false;
+  bool z_side = false, z_head = false;
   const bool ovl = overlap_on(m, n, S);
-  if (ovl) {
+  HeadRand hr{};
+  if (m->head_ok) {
+    // ... or, with the fused head launch, in spare block columns of that launch (no second stream, no events)
+    hr.seed = seed;
+    for (int l = 0; l + 1 < L; ++l)
+      if (!(zs && zs[l])) {
+        hr.out[l] = m->L[l].zbuf;
+        hr.count[l] = (int64_t)S * n * m->L[l].dev.D_out;
+        hr.nblk = std::max<int>(hr.nblk, (int)std::min<int64_t>(64, ceil_div((hr.count[l] + 1) / 2, 4 * HEAD_THREADS)));
+        z_head = true;
+      }
+  } else if (ovl) {
     DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));     // after the previous step's readers of zbuf
     DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     for (int l = 0; l + 1 < L; ++l)
@@ -1825,9 +1874,9 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
       }
     if (z_side) DS_HIP(hipEventRecord(m->ev_z, m->side));
   }
-  DS_TRY(prepare_async(m, with_grad != 0, ovl));
+  DS_TRY(prepare_async(m, with_grad != 0, ovl, z_head ? &hr : nullptr));
   if (z_side) DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_z, 0));
-  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side));
+  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side || z_head));
   LayerState& last = m->L[L - 1];
   const int DY = last.dev.D_out;
   const int64_t total = (int64_t)S * n * DY;
