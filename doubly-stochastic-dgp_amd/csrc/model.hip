@@ -287,7 +287,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     if (uniform) {
       v.Kp = Kp_all + l * MM; v.Linv = Linv_all + l * MM; v.LinvT = LinvT_all + l * MM; v.scal = scal_all + l * 8;
     } else {
-      v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.scal = b.take<double>(8);
+      v.Kp = b.take<double>(MM); v.Linv = b.take<double>(MM); v.LinvT = b.take<double>(MM); v.scal = b.take<double>(16);
     }
     v.Kinv = b.take<double>(MM);
     v.V = b.take<double>(d.D_out * MM); v.nL = b.take<double>(Mp * v.DP4); v.Sd = b.take<double>(d.D_out * MM);
@@ -1398,7 +1398,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     const int nprep = std::max(32, m->prep_blocks / 2);
     hipLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk, L), dim3(HEAD_THREADS), lds, ctx->stream, m->theta, m->layers_dev, m->lik_const,
                        m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep, keep_kuu ? 1 : 0,
-                       m->desc.white ? 1 : 0, r);
+                       m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r);
     DS_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
@@ -1471,11 +1471,16 @@ static int read_info(dsdgp_model* m, int* info) {
   if (!info) return DSDGP_OK;
   *info = 0;
   if (getenv("DSDGP_POTRF_TIMING")) {   // debug aid: per-phase shader cycles of layer 0's factorisation
-    double sc[8];
+    double sc[12];
     hipMemcpyAsync(sc, m->L[0].dev.scal, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream);
     hipStreamSynchronize(m->ctx->stream);
-    fprintf(stderr, "[potrf cycles] factor %.0f inverse %.0f panel %.0f trailing %.0f logdet+writeback %.0f copyin+trtri %.0f\n", sc[2],
-            sc[3], sc[4], sc[5], sc[6], sc[7]);
+    if (m->head_ok)
+      fprintf(stderr, "[head cycles] start + Z staging %.0f | Ku %.0f | first panel %.0f | block columns 1.. (+ inverse rows) %.0f | logdet + last two "
+              "inverse rows %.0f || wave 0 in the loop: tile %.0f, barrier %.0f, panel %.0f, barrier %.0f\n", sc[2], sc[3], sc[4], sc[5], sc[6], sc[7],
+              sc[8], sc[9], sc[10]);
+    else
+      fprintf(stderr, "[potrf cycles] factor %.0f inverse %.0f panel %.0f trailing %.0f logdet+writeback %.0f copyin+trtri %.0f\n", sc[2],
+              sc[3], sc[4], sc[5], sc[6], sc[7]);
   }
   for (int l = 0; l < m->desc.L; ++l) {
     double sc[2];
