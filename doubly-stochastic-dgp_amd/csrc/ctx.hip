@@ -151,7 +151,8 @@ static int resolve_rccl() {
     if (h) sym = dlsym(h, "ncclAllReduce");
   }
   if (!sym) {
-    dsdgp_set_error("dsdgp_allreduce: RCCL (ncclAllReduce) is not loadable in this process: %s", dlerror() ? dlerror() : "symbol not found");
+    const char* why = dlerror();      // (one call: dlerror() clears the error state)
+    dsdgp_set_error("dsdgp_allreduce: RCCL (ncclAllReduce) is not loadable in this process: %s", why ? why : "symbol not found");
     return DSDGP_ERR_RCCL;
   }
   g_allreduce = (nccl_allreduce_fn)sym;

@@ -133,6 +133,9 @@ struct dsdgp_model {
   bool uniform_big = false;     // all layers share M and Mp >= 256: ONE batched multi-workgroup Cholesky for all layers
   BigChol big_all;
   bool need_hyp_part = false;
+  bool tail_ok = false;         // non-white, every D_in <= WIDE_DIN: gradient assembly in k_asm_rows + k_tail (one wave per inducing row)
+  struct { int on; double lr_t, b1, b2, eps; } fuse_adam = {0, 0, 0, 0, 0};   // dsdgp_model_train_step: Adam applied inside k_tail
+  int mp_max_all = 0, m_max_all = 0;
   bool head_ok = false;         // every layer has Mp <= 128 and D_in <= 16: parameter transforms, Ku, its factorisation and inverse
                                 // factor (and the inner layers' N(0,1) draws) in ONE launch (k_head, head_impl.hpp)
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
@@ -155,7 +158,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 0, head = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 0, head = 1, tail = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -179,6 +182,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "pipe_tail") m->force.pipe_tail = v;
       else if (k == "side_prio") m->force.side_prio = v;
       else if (k == "head") m->force.head = v;
+      else if (k == "tail") m->force.tail = v;
     }
     pos = end + 1;
   }
@@ -1076,6 +1080,171 @@ __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ gr
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Fused tail (non-white models whose layers all have D_in <= WIDE_DIN): k_asm_kbar + k_asm_params become ONE pass with a wave per
+// inducing row, k_finalize + the hyper-parameter reduction + (single-process training) the Adam update a second small launch.
+// Before: reduce 22 us -> P_d T_d 13 -> k_asm_kbar 15 -> k_asm_params 7 -> k_adam 5 (+ k_finalize 5 on the side stream and its join).
+// ------------------------------------------------------------------------------------------------------
+// Row i of dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T) (k_asm_kbar's formula) stays in registers / a
+// wave-private LDS row as wm = Kbar ∘ dk/dr2; from it the Z gradient of row i and this row's partial sums of the kernel
+// hyper-parameter gradients (hyp2part row i: sum wk, Kbar_ii, sum_j wm_ij (z_iq - z_jq)^2), then the q_mu / q_sqrt gradient rows.
+// grid (ceil(M_max / 4), layers), 256 threads, 4 * mp_max doubles of dynamic LDS.
+__global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w, int mp_max) {
+  extern __shared__ __attribute__((aligned(16))) double asm_dyn[];
+  const LayerDev v = layers[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (int)blockIdx.x * 4 + wave;
+  const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out;
+  if (i >= M) return;                         // (no workgroup barrier below: every wave works alone)
+  lptr wm = (lptr)(asm_dyn + (size_t)wave * mp_max);
+  const int64_t MM = (int64_t)Mp * Mp;
+  const double kvar = v.hyp[HYP_VAR];
+  double a_sum = 0.0, tr = 0.0;
+  for (int j = lane; j < M; j += 64) {
+    const int64_t idx = (int64_t)i * Mp + j, idt = (int64_t)j * Mp + i;
+    double nn = 0.0, uu = 0.0, gsym;
+    for (int d = 0; d < Dout; ++d) {
+      nn = fma(v.n4[i * v.DP4 + d], v.n4[j * v.DP4 + d], nn);
+      uu += v.UU[d * MM + idx];
+    }
+    if (v.alg_g) {
+      // sym(sum_r e a^T) = sum_d (GS_d + GS_d^T - P_d) + 1/2 (n t^T + t n^T),  t = A mbar^T (thinq)
+      double gs = 0.0, nt = 0.0;
+      for (int d = 0; d < Dout; ++d) {
+        gs += (v.GS[d * MM + idx] + v.GS[d * MM + idt]) - v.bigred[MM + d * MM + idx];
+        nt += v.n4[i * v.DP4 + d] * v.thinq[j * v.DP16 + d] + v.n4[j * v.DP4 + d] * v.thinq[i * v.DP16 + d];
+      }
+      gsym = gs + 0.5 * nt;
+    } else {
+      gsym = 0.5 * (v.bigred[idx] + v.bigred[idt]);
+    }
+    const double kb = -gsym + kl_w * (0.5 * Dout * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
+    double k, dk;
+    if (v.kern_kind == DSDGP_KERN_RBF)
+      kern_val_grad<DSDGP_KERN_RBF>(v.R2[idx], kvar, k, dk);
+    else
+      kern_val_grad<DSDGP_KERN_MATERN52>(v.R2[idx], kvar, k, dk);
+    wm[j] = kb * dk;
+    a_sum += kb * k / kvar;
+    if (j == i) tr = kb;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's own LDS row: written above, read below
+  a_sum = sum_wave(a_sum);
+  tr = sum_wave(tr);
+  double* __restrict__ hp = v.hyp2part + (int64_t)i * (Din + 2);
+  if (lane == 0) {
+    hp[0] = a_sum;
+    hp[1] = tr;
+  }
+  const double* __restrict__ ils = v.hyp + HYP_ILS;
+  for (int q = 0; q < Din; ++q) {
+    const double zi = v.Zp[i * Din + q];
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = lane; j < M; j += 64) {
+      const double df = zi - v.Zp[j * Din + q], w = wm[j];
+      s1 = fma(w, df, s1);
+      s2 = fma(w * df, df, s2);
+    }
+    s1 = sum_wave(s1);
+    s2 = sum_wave(s2);
+    if (lane == 0) {
+      const double il2 = ils[q] * ils[q];
+      grad[v.off_Z + (int64_t)i * Din + q] = 4.0 * il2 * s1 - 2.0 * il2 * (v.thinz[i * v.DinP16 + q] - zi * v.thinz[i * v.DinP16 + Din]);
+      hp[2 + q] = s2;
+    }
+  }
+  // q_mu: A mbar + kl_w Ku^-1 q_mu
+  for (int d = lane; d < Dout; d += 64) grad[v.off_q_mu + (int64_t)i * Dout + d] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
+  // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
+  for (int d = 0; d < Dout; ++d)
+    for (int j = lane; j < M; j += 64) {
+      double gq = 0.0;
+      if (j <= i) {
+        const int64_t p = d * MM + (int64_t)i * Mp + j;
+        gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
+      }
+      grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = gq;
+    }
+  // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
+  if (v.meanAB) {
+    if (v.off_mean_A >= 0)
+      for (int64_t idx = (int64_t)i * 64 + lane; idx < (int64_t)Din * Dout; idx += (int64_t)M * 64)
+        grad[v.off_mean_A + idx] = v.meanAB[(idx / Dout) * v.DP16 + idx % Dout];
+    if (v.off_mean_b >= 0 && i == 0)
+      for (int idx = lane; idx < Dout; idx += 64) grad[v.off_mean_b + idx] = v.meanAB[(int64_t)Din * v.DP16 + idx];
+  }
+}
+
+struct AdamArgs {
+  double* theta; double* m; double* v; const double* mask;
+  int64_t n;
+  double lr_t, b1, b2, eps;
+  int32_t on;
+};
+__device__ __forceinline__ void adam_one(const AdamArgs& A, int64_t i, double g) {
+  const double mi = A.b1 * A.m[i] + (1.0 - A.b1) * g;
+  const double vi = A.b2 * A.v[i] + (1.0 - A.b2) * g * g;
+  A.m[i] = mi;
+  A.v[i] = vi;
+  A.theta[i] -= A.lr_t * mi / (sqrt(vi) + A.eps);
+}
+struct FinArgs {
+  const double* part; int nblocks; double w, kl_weight; const double* lik_const; int64_t off_lik; double* out; int L;
+};
+// blocks 0 .. La-1: kernel hyper-parameter gradients of layer first + b from the row partials (asm_hyp_final);
+// block La: ELBO value + likelihood-variance gradient (k_finalize's job);  blocks > La (only with A.on): Adam on every entry those
+// blocks do not own (mask 1), the owners apply it to theirs (mask 2) right after writing the gradient.
+__global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layers_all, int first, int La, double* __restrict__ grad,
+                                              const FinArgs F, const AdamArgs A) {
+  __shared__ double sh[4];
+  const int b = (int)blockIdx.x;
+  if (b < La) {
+    const LayerDev v = layers_all[first + b];
+    asm_hyp_final(v, grad);
+    if (A.on) {
+      __syncthreads();      // (the values were written by threads of this block: re-read below by the same threads that wrote them)
+      const int Din = v.D_in;
+      if (threadIdx.x == 0) {
+        if (A.mask[v.off_kvar] != 0.0) adam_one(A, v.off_kvar, grad[v.off_kvar]);
+        if (v.has_white && A.mask[v.off_wvar] != 0.0) adam_one(A, v.off_wvar, grad[v.off_wvar]);
+        if (!v.ard && A.mask[v.off_kls] != 0.0) adam_one(A, v.off_kls, grad[v.off_kls]);
+      }
+      if (v.ard && (int)threadIdx.x < Din && A.mask[v.off_kls + threadIdx.x] != 0.0)
+        adam_one(A, v.off_kls + threadIdx.x, grad[v.off_kls + threadIdx.x]);
+    }
+    return;
+  }
+  if (b == La) {
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < F.nblocks; i += 256) {
+      a += F.part[2 * i];
+      c += F.part[2 * i + 1];
+    }
+    a = block_sum_256(a, sh);
+    c = block_sum_256(c, sh);
+    if (threadIdx.x == 0) {
+      double kl = 0.0, info = 0.0;
+      for (int l = 0; l < F.L; ++l) {
+        kl += layers_all[l].klv[0];
+        if (layers_all[l].scal[1] != 0.0 && info == 0.0) info = layers_all[l].scal[1];
+      }
+      F.out[0] = F.w * a - F.kl_weight * kl;
+      F.out[1] = F.w * a;
+      F.out[2] = F.kl_weight * kl;
+      F.out[3] = info;
+      if (F.off_lik >= 0) {
+        const double g = -F.w * c * F.lik_const[1];
+        grad[F.off_lik] = g;
+        if (A.on && A.mask[F.off_lik] != 0.0) adam_one(A, F.off_lik, g);
+      }
+    }
+    return;
+  }
+  const int64_t nth = (int64_t)(gridDim.x - La - 1) * 256;
+  for (int64_t i = (int64_t)(b - La - 1) * 256 + threadIdx.x; i < A.n; i += nth)
+    if (A.mask[i] == 1.0) adam_one(A, i, grad[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int validate_desc(const dsdgp_model_desc* d) {
@@ -1259,10 +1428,16 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       }
     }
   }
+  m->tail_ok = m->force.tail != 0 && !desc->white;
+  for (int l = 0; l < L; ++l) {
+    m->tail_ok = m->tail_ok && m->L[l].dev.D_in <= WIDE_DIN;
+    m->mp_max_all = std::max(m->mp_max_all, (int)m->L[l].dev.Mp);
+    m->m_max_all = std::max(m->m_max_all, (int)m->L[l].dev.M);
+  }
   for (int l = 0; l < L; ++l) {
     LayerDev& v = m->L[l].dev;
     const bool fold = v.D_in <= WIDE_DIN && (int64_t)m->kuu_blocks * 256 >= (int64_t)v.Mp * v.Mp;
-    v.hyp_parts = fold ? m->kuu_blocks : -NPART;
+    v.hyp_parts = m->tail_ok ? v.M : (fold ? m->kuu_blocks : -NPART);      // fused tail: one partial row per inducing row (k_asm_rows)
     ld[l].hyp_parts = v.hyp_parts;
     if (!fold) m->need_hyp_part = true;
   }
@@ -1292,20 +1467,21 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   // trainable mask (set_trainable(False) of the reference, e.g. tests/test_dgp.py:141-145)
   std::vector<double> mask(desc->n_theta, 0.0);
   auto mark = [&](int64_t off, int64_t cnt, int on) {
-    for (int64_t i = 0; i < cnt; ++i) mask[off + i] = on ? 1.0 : 0.0;
+    for (int64_t i = 0; i < cnt; ++i) mask[off + i] = (double)on;
   };
   for (int l = 0; l < L; ++l) {
     const dsdgp_layer_desc& y = desc->layers[l];
     mark(y.off_Z, (int64_t)y.M * y.D_in, y.trainable_Z);
     mark(y.off_q_mu, (int64_t)y.M * y.D_out, y.trainable_q_mu);
     mark(y.off_q_sqrt, (int64_t)y.D_out * y.M * y.M, y.trainable_q_sqrt);
-    mark(y.off_kvar, 1, y.trainable_kvar);
-    mark(y.off_kls, y.ard ? y.D_in : 1, y.trainable_kls);
-    if (y.has_white) mark(y.off_wvar, 1, y.trainable_wvar);
+    // (2: entries whose gradient k_tail's hyper-parameter / likelihood blocks produce and, in a fused training step, update themselves)
+    mark(y.off_kvar, 1, 2 * y.trainable_kvar);
+    mark(y.off_kls, y.ard ? y.D_in : 1, 2 * y.trainable_kls);
+    if (y.has_white) mark(y.off_wvar, 1, 2 * y.trainable_wvar);
     if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_A >= 0) mark(y.off_mean_A, (int64_t)y.D_in * y.D_out, y.trainable_mean_A);
     if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_b >= 0) mark(y.off_mean_b, y.D_out, y.trainable_mean_b);
   }
-  if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, desc->trainable_lik_var);
+  if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, 2 * desc->trainable_lik_var);
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DS_HIP(hipStreamSynchronize(st));
   m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
@@ -1811,7 +1987,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
     // everything queued behind it on this stream waited with it
-    if (!m->fin.done) DS_TRY(launch_finalize(m, m->side));
+    if (!m->fin.done && !m->tail_ok) DS_TRY(launch_finalize(m, m->side));
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
   }
@@ -1836,6 +2012,19 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   // the assembly of the layers that took part (their gradient entries; those of the layers below gfirst keep their old content)
   const LayerDev* lay = m->layers_dev + gfirst;
   const int La = L - gfirst;
+  if (m->tail_ok) {
+    hipLaunchKernelGGL(k_asm_rows, dim3(ceil_div(m->m_max_all, 4), La), dim3(256), (size_t)4 * m->mp_max_all * sizeof(double), ctx->stream, lay,
+                       m->grad, kl_weight, m->mp_max_all);
+    FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
+              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L};
+    AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
+               m->fuse_adam.eps, (m->fuse_adam.on && gfirst == 0) ? 1 : 0};
+    const int nadam = A.on ? (int)std::min<int64_t>(512, ceil_div(m->desc.n_theta, 256)) : 0;
+    hipLaunchKernelGGL(k_tail, dim3(La + 1 + nadam), dim3(256), 0, ctx->stream, m->layers_dev, gfirst, La, m->grad, F, A);
+    DS_HIP(hipGetLastError());
+    m->fin.done = true;
+    return DSDGP_OK;
+  }
   hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, La), dim3(256), 0, ctx->stream, lay, kl_weight);
   if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));   // (wm of the layers below gfirst is stale: their WZ is never read)
   if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, La), dim3(256), 0, ctx->stream, lay);
@@ -1952,6 +2141,33 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
   hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
                      lr_t, beta1, beta2, eps);
   DS_HIP(hipGetLastError());
+  m->prepared = false;
+  m->kuu_valid = false;
+  m->q_dirty = -2;
+  return DSDGP_OK;
+}
+
+// One optimiser step in one call: ELBO + gradient with the Adam update applied by the tail launch of the reverse pass (no separate
+// k_adam launch; `session.run(opt_op)` of demos/demo_regression_UCI.ipynb:324).  Falls back to elbo + adam_step where the fused tail
+// does not apply (white=True, wide inputs).
+extern "C" int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
+                                      const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
+                                      double beta2, double eps, int64_t t, double* out) {
+  DS_CHECK_ARG(m && m->grad && m->adam_m && m->adam_v && t >= 1);
+  if (!m->desc.white && m->grad_first > 0) {
+    dsdgp_set_error("dsdgp_model_train_step: the reverse pass is restricted to layers >= %d (dsdgp_model_set_grad_first_layer)", m->grad_first);
+    return DSDGP_ERR_BAD_ARG;
+  }
+  if (!m->tail_ok) {
+    DS_TRY(dsdgp_model_elbo(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out));
+    return dsdgp_model_adam_step(m, lr, beta1, beta2, eps, t);
+  }
+  m->fuse_adam.on = 1;
+  m->fuse_adam.lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  m->fuse_adam.b1 = beta1; m->fuse_adam.b2 = beta2; m->fuse_adam.eps = eps;
+  const int rc = dsdgp_model_elbo(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out);
+  m->fuse_adam.on = 0;
+  DS_TRY(rc);
   m->prepared = false;
   m->kuu_valid = false;
   m->q_dirty = -2;

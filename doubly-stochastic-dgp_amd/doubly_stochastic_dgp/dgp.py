@@ -191,6 +191,8 @@ class DGP_Base(Parameterized):
                        kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer)
         if allreduce is not None:
             out = allreduce(eng, with_grad)
+            if out[3] != 0.0:          # every rank factorises the same Kuu ([UPSTREAM] tf.cholesky raises)
+                raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(out[3])})")
         return float(out[0])
 
     def compute_log_likelihood(self, X=None, Y=None, zs=None):
@@ -208,11 +210,16 @@ class DGP_Base(Parameterized):
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)
-        out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
-                       kl_weight=klw, with_grad=True, sync=False)
-        if allreduce is not None:
+        if allreduce is None:
+            # single process: ELBO, gradient and Adam update in one library call (the update rides in the reverse pass's last launch)
+            eng.train_step(X, Y, self.num_samples, zs=zs, seed=self._next_seed(), data_scale=scale, kl_weight=klw, lr=lr, beta1=beta1,
+                           beta2=beta2, eps=eps)
+            out = None
+        else:
+            out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
+                           kl_weight=klw, with_grad=True, sync=False)
             out = allreduce(eng, True, sync=sync)
-        eng.adam_step(lr, beta1, beta2, eps)
+            eng.adam_step(lr, beta1, beta2, eps)
         if sync:
             eng.ctx.sync()
             o = eng.out4.cpu().numpy() if out is None else out

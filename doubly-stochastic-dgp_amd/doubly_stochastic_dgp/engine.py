@@ -355,6 +355,7 @@ class Engine:
         Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
         Yd = Y if hasattr(Y, "data_ptr") else self.ctx.to_device(Y)
         n = Xd.shape[0]
+        self._check_targets_shape(Yd, n)
         self._ensure(n, S)
         self._upload_if_needed()
         zp, zst, keep = self._zs_args(zs, S, n)
@@ -373,10 +374,36 @@ class Engine:
         return out
 
     def adam_step(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+        # the library refuses a pruned gradient: count the step only once it has been taken
+        _lib.check(self.lib.dsdgp_model_adam_step(self.model, lr, beta1, beta2, eps, self.adam_t + 1))
         self.adam_t += 1
-        _lib.check(self.lib.dsdgp_model_adam_step(self.model, lr, beta1, beta2, eps, self.adam_t))
         self._dev_dirty = True
         self._needs_prepare = True
+
+    def train_step(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+        """ELBO + gradient + Adam update in one library call (single-process training); asynchronous, result scalars in out4."""
+        Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
+        Yd = Y if hasattr(Y, "data_ptr") else self.ctx.to_device(Y)
+        n = Xd.shape[0]
+        self._check_targets_shape(Yd, n)
+        self._ensure(n, S)
+        self._upload_if_needed()
+        zp, zst, keep = self._zs_args(zs, S, n)
+        if getattr(self, "_grad_first", 0) != 0:
+            _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, 0))
+            self._grad_first = 0
+        _lib.check(self.lib.dsdgp_model_train_step(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed), float(data_scale),
+                                                   float(kl_weight), lr, beta1, beta2, eps, self.adam_t + 1, ptr(self.out4)))
+        self.adam_t += 1
+        self._dev_dirty = True
+        self._needs_prepare = True
+
+    def _check_targets_shape(self, Yd, n):
+        """Y must be (n, D_out of the last layer) for the element-wise likelihoods, (n, 1) labels for MultiClass: the likelihood
+        kernels index Y[(row % n) * DY + d] and would read out of bounds otherwise."""
+        want = 1 if isinstance(self.likelihood, MultiClass) else self.layers[-1].num_outputs
+        if tuple(Yd.shape) != (n, want):
+            raise ValueError(f"Y has shape {tuple(Yd.shape)}, expected {(n, want)} (rows of X x outputs of the last layer)")
 
     def natgrad_step(self, l, gamma, check=True):
         """[UPSTREAM] NatGradOptimizer(gamma) step on layer l's (q_mu, q_sqrt) from the gradient of the last

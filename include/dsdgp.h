@@ -169,6 +169,16 @@ int dsdgp_model_set_sample_weights(dsdgp_model* m, const double* w, int32_t S);
 /* [UPSTREAM] tf.train.AdamOptimizer step on theta using grad (t counts from 1). Non-trainable entries are skipped. */
 int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2, double eps, int64_t t);
 
+/* One optimiser step of -ELBO in ONE call — `session.run(opt_op)` of demos/demo_regression_UCI.ipynb:324 with
+ * opt_op = AdamOptimizer(lr).minimize(model): dsdgp_model_elbo(with_grad = 1) followed by the Adam update (t counts from 1), the
+ * update applied by the last launch of the reverse pass instead of a launch of its own.  Same arguments and `out` as
+ * dsdgp_model_elbo; `grad` holds the gradient the update used.  Single-process training only: a data-parallel step needs the
+ * all-reduce between the two halves (dsdgp_model_elbo, dsdgp_allreduce, dsdgp_model_adam_step).  DSDGP_ERR_BAD_ARG while
+ * dsdgp_model_set_grad_first_layer restricts the reverse pass. */
+int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
+                           const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
+                           double beta2, double eps, int64_t t, double* out);
+
 /* [UPSTREAM] gpflow.training.NatGradOptimizer(gamma) step on layer l's (q_mu, q_sqrt), using the loss gradient left in
  * `grad` by the last dsdgp_model_elbo(with_grad=1) (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100):
  * per output, natural parameters theta <- theta - gamma dL/d eta, then back to (mean, Cholesky factor).
