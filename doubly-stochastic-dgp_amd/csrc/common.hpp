@@ -53,6 +53,7 @@ struct dsdgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t side = nullptr;      // second stream of the models of this context (created with the first model)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int prof_on = 0;

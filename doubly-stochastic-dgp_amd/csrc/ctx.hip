@@ -51,6 +51,10 @@ extern "C" int dsdgp_ctx_destroy(dsdgp_ctx* ctx) {
     }
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pin) hipHostFree(ctx->pin);
+  if (ctx->side) {
+    hipStreamSynchronize(ctx->side);
+    hipStreamDestroy(ctx->side);
+  }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return DSDGP_OK;

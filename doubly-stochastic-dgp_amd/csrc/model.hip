@@ -52,6 +52,8 @@ struct RedJob {
   int64_t pstride;     // elements between consecutive splits of `part`
   int32_t in_ld, out_ld;   // > 0: 2-D result, `part` rows have leading dimension in_ld (the weight-gradient products run on
                            // whole 64-row tiles: Mw = round_up(Mp, 64)), `out` rows out_ld; 0: linear
+  int32_t ways;            // 4: a workgroup owns 64 outputs, each of its four waves a quarter of the splits (many splits, few outputs:
+                           // one thread per output walked 156 splits eight at a time — 20 dependent round trips); else one thread each
 };
 
 struct LayerState {
@@ -150,7 +152,6 @@ struct dsdgp_model {
   // side stream: the weight-gradient products of layer l overlap the backward chain of layer l-1 (disjoint buffers)
   hipStream_t side;
   hipEvent_t ev_bwd[DSDGP_MAX_LAYERS];
-  hipEvent_t ev_adj[DSDGP_MAX_LAYERS];   // upstream adjoints (MB / VB) of layer l written: its A jobs may start
   hipEvent_t ev_side;
   bool overlap;
   // DSDGP_FORCE="key=value,...": test hooks that force the large-launch variants onto small, oracle-checkable shapes (read when
@@ -158,7 +159,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, side_prio = 0, head = 1, tail = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -180,9 +181,9 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "bwd_split") m->force.bwd_split = v;
       else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
-      else if (k == "side_prio") m->force.side_prio = v;
       else if (k == "head") m->force.head = v;
       else if (k == "tail") m->force.tail = v;
+      else if (k == "ns_cap") m->force.ns_cap = v;
     }
     pos = end + 1;
   }
@@ -793,9 +794,13 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     if (threadIdx.x == 0) J.out[i] = s;
     return;
   }
-  const int64_t i0 = (int64_t)(bx - J.blk_start) * 256 + threadIdx.x;
-  if (i0 >= J.count) return;
-  int64_t i = i0, o = i0;
+  const bool four = J.ways == 4;
+  const int rwave = threadIdx.x >> 6;
+  const int64_t i0 = four ? (int64_t)(bx - J.blk_start) * 64 + (threadIdx.x & 63) : (int64_t)(bx - J.blk_start) * 256 + threadIdx.x;
+  if (!four && i0 >= J.count) return;
+  const bool live = i0 < J.count;
+  int64_t i = live ? i0 : 0, o = i;
+  if (live)
   if (J.out_ld > 0) {
     const int64_t r = i0 / J.out_ld, cc = i0 % J.out_ld;
     i = r * J.in_ld + cc;
@@ -811,13 +816,22 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     }
   }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int sp = 0;
-  for (; sp + 8 <= J.nsplit; sp += 8) {     // eight independent loads in flight; fixed order -> deterministic
+  const int st = four ? 4 : 1;
+  int sp = four ? rwave : 0;
+  for (; sp + 7 * st < J.nsplit; sp += 8 * st) {     // eight independent loads in flight; fixed order -> deterministic
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u) * J.pstride + i];
+    for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u * st) * J.pstride + i];
   }
-  for (; sp < J.nsplit; ++sp) s[0] += J.part[(int64_t)sp * J.pstride + i];
-  J.out[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  for (; sp < J.nsplit; sp += st) s[0] += J.part[(int64_t)sp * J.pstride + i];
+  const double tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (!four) {
+    J.out[o] = tot;
+    return;
+  }
+  __shared__ double sh4[4][64];
+  sh4[rwave][threadIdx.x & 63] = tot;
+  __syncthreads();
+  if (rwave == 0 && live) J.out[o] = (sh4[0][threadIdx.x] + sh4[1][threadIdx.x]) + (sh4[2][threadIdx.x] + sh4[3][threadIdx.x]);
 }
 
 // dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T),  U_d = Ku^-1 q_sqrt_d, n = Ku^-1 q_mu
@@ -1084,22 +1098,24 @@ __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ gr
 // inducing row, k_finalize + the hyper-parameter reduction + (single-process training) the Adam update a second small launch.
 // Before: reduce 22 us -> P_d T_d 13 -> k_asm_kbar 15 -> k_asm_params 7 -> k_adam 5 (+ k_finalize 5 on the side stream and its join).
 // ------------------------------------------------------------------------------------------------------
-// Row i of dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T) (k_asm_kbar's formula) stays in registers / a
-// wave-private LDS row as wm = Kbar ∘ dk/dr2; from it the Z gradient of row i and this row's partial sums of the kernel
-// hyper-parameter gradients (hyp2part row i: sum wk, Kbar_ii, sum_j wm_ij (z_iq - z_jq)^2), then the q_mu / q_sqrt gradient rows.
-// grid (ceil(M_max / 4), layers), 256 threads, 4 * mp_max doubles of dynamic LDS.
+// Row i of dl/dKu = -sym(G) + kl_w (D/2 Ku^-1 - 1/2 sum_d U_d U_d^T - 1/2 n n^T) (k_asm_kbar's formula) goes to an LDS row as
+// wm = Kbar ∘ dk/dr2; from it the Z gradient of row i and this row's partial sums of the kernel hyper-parameter gradients (hyp2part
+// row i: sum wk, Kbar_ii, sum_j wm_ij (z_iq - z_jq)^2), then the q_mu / q_sqrt gradient rows.  One WORKGROUP per inducing row: its
+// four waves share the row of Kbar, then split the input dimensions and the (output, column) pairs of the q_sqrt rows — a wave per
+// row walked ten dependent memory round trips one after the other (30 us).  grid (M_max, layers), 256 threads, mp_max doubles of LDS.
 __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w, int mp_max) {
   extern __shared__ __attribute__((aligned(16))) double asm_dyn[];
+  __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = (int)blockIdx.x * 4 + wave;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = (int)blockIdx.x;
   const int Mp = v.Mp, M = v.M, Din = v.D_in, Dout = v.D_out;
-  if (i >= M) return;                         // (no workgroup barrier below: every wave works alone)
-  lptr wm = (lptr)(asm_dyn + (size_t)wave * mp_max);
+  if (i >= M) return;
+  lptr wm = (lptr)asm_dyn;
   const int64_t MM = (int64_t)Mp * Mp;
   const double kvar = v.hyp[HYP_VAR];
   double a_sum = 0.0, tr = 0.0;
-  for (int j = lane; j < M; j += 64) {
+  for (int j = tid; j < M; j += 256) {
     const int64_t idx = (int64_t)i * Mp + j, idt = (int64_t)j * Mp + i;
     double nn = 0.0, uu = 0.0, gsym;
     for (int d = 0; d < Dout; ++d) {
@@ -1127,16 +1143,15 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
     a_sum += kb * k / kvar;
     if (j == i) tr = kb;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's own LDS row: written above, read below
-  a_sum = sum_wave(a_sum);
-  tr = sum_wave(tr);
+  a_sum = block_sum_256(a_sum, sh);           // (its barriers also publish the wm row)
+  tr = block_sum_256(tr, sh);
   double* __restrict__ hp = v.hyp2part + (int64_t)i * (Din + 2);
-  if (lane == 0) {
+  if (tid == 0) {
     hp[0] = a_sum;
     hp[1] = tr;
   }
   const double* __restrict__ ils = v.hyp + HYP_ILS;
-  for (int q = 0; q < Din; ++q) {
+  for (int q = wave; q < Din; q += 4) {
     const double zi = v.Zp[i * Din + q];
     double s1 = 0.0, s2 = 0.0;
     for (int j = lane; j < M; j += 64) {
@@ -1153,24 +1168,21 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
     }
   }
   // q_mu: A mbar + kl_w Ku^-1 q_mu
-  for (int d = lane; d < Dout; d += 64) grad[v.off_q_mu + (int64_t)i * Dout + d] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
-  // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
-  for (int d = 0; d < Dout; ++d)
-    for (int j = lane; j < M; j += 64) {
-      double gq = 0.0;
-      if (j <= i) {
-        const int64_t p = d * MM + (int64_t)i * Mp + j;
-        gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
-      }
-      grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = gq;
-    }
+  for (int d = tid; d < Dout; d += 256) grad[v.off_q_mu + (int64_t)i * Dout + d] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
+  // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii)); clamped (unconditional) loads so that several are in flight
+  for (int e = tid; e < Dout * M; e += 256) {
+    const int d = e / M, j = e - d * M;
+    const int64_t p = d * MM + (int64_t)i * Mp + (j <= i ? j : i);
+    const double gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
+    grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = (j <= i) ? gq : 0.0;
+  }
   // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
   if (v.meanAB) {
     if (v.off_mean_A >= 0)
-      for (int64_t idx = (int64_t)i * 64 + lane; idx < (int64_t)Din * Dout; idx += (int64_t)M * 64)
+      for (int64_t idx = (int64_t)i * 256 + tid; idx < (int64_t)Din * Dout; idx += (int64_t)M * 256)
         grad[v.off_mean_A + idx] = v.meanAB[(idx / Dout) * v.DP16 + idx % Dout];
     if (v.off_mean_b >= 0 && i == 0)
-      for (int idx = lane; idx < Dout; idx += 64) grad[v.off_mean_b + idx] = v.meanAB[(int64_t)Din * v.DP16 + idx];
+      for (int idx = tid; idx < Dout; idx += 256) grad[v.off_mean_b + idx] = v.meanAB[(int64_t)Din * v.DP16 + idx];
   }
 }
 
@@ -1485,19 +1497,13 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DS_HIP(hipStreamSynchronize(st));
   m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
-  if (m->force.side_prio) {
-    // the side stream's launches (weight-gradient products, parameter-only algebra) run UNDER a chain launch whose workgroups fill
-    // every CU: at equal priority their workgroups were dispatched only when the chain's queue had drained (a 17 us launch took
-    // 136 us, profiles/r03_timeline_*.txt) — with the higher priority they take the slots the chain's workgroups free
-    int least = 0, greatest = 0;
-    DS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    DS_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, greatest));
-  } else {
-    DS_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-  }
+  // ONE side stream per context, shared by its models: a stream per model left the mapping of streams to hardware queues to the
+  // order in which models had been created and destroyed (a process that had built several models occasionally ran a later one
+  // 15 - 140 % slower, tools/ab_force.py)
+  if (!ctx->side) DS_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  m->side = ctx->side;
   for (int l = 0; l < L; ++l) {
     DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
-    DS_HIP(hipEventCreateWithFlags(&m->ev_adj[l], hipEventDisableTiming));
   }
   DS_HIP(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -1516,11 +1522,9 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     hipStreamSynchronize(m->side);
     for (int l = 0; l < m->desc.L; ++l) {
       hipEventDestroy(m->ev_bwd[l]);
-      hipEventDestroy(m->ev_adj[l]);
     }
     hipEventDestroy(m->ev_side);
     hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
-    hipStreamDestroy(m->side);
     for (int l = 0; l < m->desc.L; ++l) {
       if (l == 0) bigchol_free(m->big_all);
       bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngS); bigchol_free(m->L[l].big_ngT);
@@ -1782,6 +1786,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const double dfrac = (NI + 1) / (2.0 * NI);
     int ns = choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 512);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
+    if (ns > m->force.ns_cap) ns = m->force.ns_cap;
     St.ns_big = ns;
     St.ns_thin = ns;
     const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
@@ -1853,8 +1858,9 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
   }
   int blocks = 0;
   for (auto& r : red) {
+    r.ways = (!r.wide && r.nsplit >= 12) ? 4 : 0;
     r.blk_start = blocks;
-    blocks += r.wide ? (int)r.count : ceil_div(r.count, 256);
+    blocks += r.wide ? (int)r.count : ceil_div(r.count, r.ways == 4 ? 64 : 256);
   }
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
@@ -1908,17 +1914,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipGetLastError());
     return gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st);
   };
-  int pendingB = -1;      // layer whose B jobs wait for the next layer's A jobs to be enqueued first (the side stream is in-order: a
-                          // small B launch stuck behind the co-running chain must not hold the big A launch back)
-  auto flush_B = [&]() -> int {
-    if (pendingB < 0) return DSDGP_OK;
-    LayerState& Sp = m->L[pendingB];
-    DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[pendingB], 0));
-    DS_TRY(wgrad_launch(ctx, Sp.wjB, Sp.njobsB, Sp.totB, Sp.ns_big, Sp.ld_used, Sp.ld_used, m->side));
-    if (pipelined) DS_TRY(layer_tail(Sp, m->side));
-    pendingB = -1;
-    return DSDGP_OK;
-  };
+  bool a_done[DSDGP_MAX_LAYERS] = {false};
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1937,13 +1933,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_HIP(hipGetLastError());
     // the lowest layer of the reverse pass keeps its products on the main stream: nothing is left to run them under, and the
     // join below then waits for side-stream work that finished long ago instead of for a just-in-time signal
-    const bool on_main = early && l == gfirst && L - gfirst > 1;
-    if (early && !on_main) {
-      DS_HIP(hipEventRecord(m->ev_adj[l], ctx->stream));
-      DS_HIP(hipStreamWaitEvent(m->side, m->ev_adj[l], 0));
-      DS_TRY(wgrad_launch(ctx, St.wj, St.njobsA, St.totA, St.ns_big, ld, ld, m->side));
-    }
-    DS_TRY(flush_B());
+    const bool on_main = overlap && l == gfirst && L - gfirst > 1;
     LayerBwdArgs b{};
     b.X = St.X_used; b.Rin = Rin; b.D_in = v.D_in; b.D_out = v.D_out; b.M = v.M; b.DP4 = v.DP4;
     b.Zp = v.Zp; b.Zs = v.Zs; b.hyp = v.hyp; b.Kinv = v.Kinv; b.Linv = v.Linv; b.LinvT = v.LinvT; b.Sd = v.Sd; b.qmu4 = v.qmu4;
@@ -1969,20 +1959,26 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
     DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
-    if (early && !on_main) {
-      DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
-      pendingB = l;
-    } else if (overlap && !on_main) {
-      DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
-      DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
-      DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, m->side));
-      if (pipelined) DS_TRY(layer_tail(St, m->side));
-    } else {
+    if (!overlap || on_main) {
       DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, ctx->stream));
       if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
+      continue;
     }
+    // ONE event per chain boundary (an event record costs the recording stream a few microseconds): behind it the side stream takes
+    // the A jobs of the NEXT layer first — its adjoints came out of this chain and its products are the large ones — then this
+    // layer's B jobs (or all of its jobs when its A jobs did not go ahead)
+    DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
+    DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
+    const int nl = l - 1;
+    if (early && nl >= gfirst && nl >= 1 && !(nl == gfirst && L - gfirst > 1)) {
+      LayerState& Sn = m->L[nl];
+      DS_TRY(wgrad_launch(ctx, Sn.wj, Sn.njobsA, Sn.totA, Sn.ns_big, Sn.ld_used, Sn.ld_used, m->side));
+      a_done[nl] = true;
+    }
+    if (a_done[l]) DS_TRY(wgrad_launch(ctx, St.wjB, St.njobsB, St.totB, St.ns_big, ld, ld, m->side));
+    else DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, m->side));
+    if (pipelined) DS_TRY(layer_tail(St, m->side));
   }
-  DS_TRY(flush_B());
   if (overlap) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
@@ -2013,8 +2009,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const LayerDev* lay = m->layers_dev + gfirst;
   const int La = L - gfirst;
   if (m->tail_ok) {
-    hipLaunchKernelGGL(k_asm_rows, dim3(ceil_div(m->m_max_all, 4), La), dim3(256), (size_t)4 * m->mp_max_all * sizeof(double), ctx->stream, lay,
-                       m->grad, kl_weight, m->mp_max_all);
+    hipLaunchKernelGGL(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
+                       kl_weight, m->mp_max_all);
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
               m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
