@@ -78,7 +78,20 @@ struct LayerBwdArgs {
   int32_t d_split;
   double* part;
   int* part_cnt;
+  // a layer with `up_rep` output rows per input row (the first layer: S samples share mean / var) gets its transposed upstream adjoints
+  // from the adjoint of the next layer's input right here, in the chain's prologue (k_adj_prep's job, one launch less on the
+  // critical path):  MB[d][r] = sum_s dF[s Rin + r][off + d],  VB[d][r] = sum_s dF[..] z[..] / (2 sqrt(var[r][d] + jitter)); written
+  // to MB / VB (the weight-gradient products read them too) by the workgroup that owns the row block.  NULL: MB / VB are ready.
+  const double* up_dF;
+  int32_t up_rep, up_ld, up_off;
+  const double* up_z;          // this layer's draws, element (row, d) at up_z[(row / n_inner) * up_zs + (row % n_inner) * up_zn + d * up_zd]
+  int64_t up_zs, up_zn, up_zd, up_n_inner;
+  const double* up_var;        // this layer's variances (Rin x D_out)
+  double up_jitter;
+  double *MBw, *VBw;           // = MB / VB, writable
 };
+// whether the backward chain of this shape can take the adjoint prologue (its LDS reduction scratch holds 2 x 16 x D_out partials)
+int sm_adj_fusable(int Mp, int64_t nblk, int D_in, int D_out);
 
 // out[split][i][j] = sum_{r in split} P[i][r] * scale[r] * Q[j][r]
 struct WgradJob {

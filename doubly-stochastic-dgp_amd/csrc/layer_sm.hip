@@ -29,6 +29,13 @@ static inline int sm_nw(int Mp, int64_t nblk, int D_in, bool bwd) {
 }
 // rows of hyp_part the backward chain writes (one per wave)
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in) { return (int64_t)sm_nw(Mp, ceil_div(ld, 16), D_in, true) * ceil_div(ld, 16); }
+// the adjoint prologue (LayerBwdArgs::up_dF) parks 2 x 16 x D_out partial sums in the chain's reduction scratch
+int sm_adj_fusable(int Mp, int64_t nblk, int D_in, int D_out) {
+  if (D_in > XCH) return 0;
+  const int NW = sm_nw(Mp, nblk, D_in, true);
+  const int xch = D_in < XCH ? D_in : XCH;
+  return NW * 16 * xch >= 2 * 16 * D_out;
+}
 // padded inducing counts whose backward chain has a Csave instance (layer_sm_impl.hpp: sm_cs_inst)
 int sm_cs_built(int Mp) { return Mp > 256 || Mp == 32 || Mp == 64 || Mp == 128 || Mp == 256; }
 

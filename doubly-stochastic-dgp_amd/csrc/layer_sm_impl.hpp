@@ -566,6 +566,51 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   const int64_t r = r0 + c;
   const bool rin = r < a.ldA, rvalid = r < a.Rin;
   BWD_STAMP(0);
+  if (a.up_dF) {
+    // upstream adjoints of this row block from the adjoint of the next layer's input (see LayerBwdArgs::up_dF).  (row, output) pairs
+    // x C chunks of the rep samples over the threads, partials through the (still unused) reduction scratch, fixed summation order.
+    const int npair = 16 * Dout, T = NW * 64;
+    const int cap = (L.total - L.red) / (2 * npair);
+    int C = T / npair;
+    if (C > a.up_rep) C = a.up_rep;
+    if (C > cap) C = cap;
+    if (C < 1) C = 1;
+    for (int e = tid; e < npair * C; e += T) {
+      const int pair = e % npair, ch = e / npair;
+      const int rr = pair / Dout, d = pair - rr * Dout;
+      const int64_t rw = r0 + rr;
+      double ms = 0.0, vs = 0.0;
+      if (rw < a.Rin) {
+        const int s_lo = ch * a.up_rep / C, s_hi = (ch + 1) * a.up_rep / C;
+        for (int s = s_lo; s < s_hi; ++s) {
+          const int64_t orow = (int64_t)s * a.Rin + rw;
+          const double f = a.up_dF[orow * a.up_ld + a.up_off + d];
+          ms += f;
+          vs = fma(f, a.up_z[(orow / a.up_n_inner) * a.up_zs + (orow % a.up_n_inner) * a.up_zn + d * a.up_zd], vs);
+        }
+      }
+      redx[2 * e] = ms;
+      redx[2 * e + 1] = vs;
+    }
+    __syncthreads();
+    for (int pair = tid; pair < npair; pair += T) {
+      const int rr = pair / Dout, d = pair - rr * Dout;
+      const int64_t rw = r0 + rr;
+      double ms = 0.0, vs = 0.0;
+      for (int ch = 0; ch < C; ++ch) {
+        ms += redx[2 * (ch * npair + pair)];
+        vs += redx[2 * (ch * npair + pair) + 1];
+      }
+      if (rw < a.Rin) {
+        a.MBw[(int64_t)d * a.ldA + rw] = ms;
+        a.VBw[(int64_t)d * a.ldA + rw] = vs * 0.5 * rsqrt(a.up_var[rw * Dout + d] + a.up_jitter);
+      } else if (rw < a.ldA) {
+        a.MBw[(int64_t)d * a.ldA + rw] = 0.0;
+        a.VBw[(int64_t)d * a.ldA + rw] = 0.0;
+      }
+    }
+    __syncthreads();       // (waits for the stores; the lines of this row block are read below by this workgroup only)
+  }
   d4 av[NQ], acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {

@@ -159,7 +159,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 1, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -184,6 +184,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "head") m->force.head = v;
       else if (k == "tail") m->force.tail = v;
       else if (k == "ns_cap") m->force.ns_cap = v;
+      else if (k == "adj_fuse") m->force.adj_fuse = v;
     }
     pos = end + 1;
   }
@@ -1502,6 +1503,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   // 15 - 140 % slower, tools/ab_force.py)
   if (!ctx->side) DS_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   m->side = ctx->side;
+
   for (int l = 0; l < L; ++l) {
     DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
   }
@@ -1520,10 +1522,12 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
   if (m) {
     hipStreamSynchronize(m->ctx->stream);
     hipStreamSynchronize(m->side);
+
     for (int l = 0; l < m->desc.L; ++l) {
       hipEventDestroy(m->ev_bwd[l]);
     }
     hipEventDestroy(m->ev_side);
+
     hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
     for (int l = 0; l < m->desc.L; ++l) {
       if (l == 0) bigchol_free(m->big_all);
@@ -1915,6 +1919,13 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     return gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st);
   };
   bool a_done[DSDGP_MAX_LAYERS] = {false};
+  // which: 1 = A jobs, 2 = B jobs, 3 = all
+  auto launch_wgrad = [&](LayerState& Sx, int which, hipStream_t st) -> int {
+    const int64_t ldx = Sx.ld_used;
+    if (which == 1) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st);
+    if (which == 2) return wgrad_launch(ctx, Sx.wjB, Sx.njobsB, Sx.totB, Sx.ns_big, ldx, ldx, st);
+    return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st);
+  };
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1925,7 +1936,9 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // for the last layer, the next layer's backward chain for inner layers — else (first layer: S output rows per input
     // row; MultiClass) by k_adj_prep
     const bool fused = (last && m->fused_last) || (!last && l >= 1);
-    if (!fused)
+    // ... or, for a first layer below others, by this layer's own backward chain in its prologue (LayerBwdArgs::up_dF)
+    const bool in_chain = !fused && !last && m->force.adj_fuse != 0 && !St.c_used && sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
+    if (!fused && !in_chain)
       hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                          last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
                          St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
@@ -1949,6 +1962,11 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     }
     b.mean_kind = St.d.mean_kind; b.mean_A = St.meanA;
     b.hyp_part = St.hyp_part;
+    if (in_chain) {
+      b.up_dF = St.dF; b.up_rep = rep; b.up_ld = v.D_out + St.prop; b.up_off = St.prop;
+      b.up_z = St.z_used; b.up_zs = St.zs_s; b.up_zn = St.zs_n; b.up_zd = St.zs_d; b.up_n_inner = n;
+      b.up_var = St.var; b.up_jitter = m->desc.jitter; b.MBw = St.MB; b.VBw = St.VB;
+    }
     {   // few row blocks (the N-row first layer, small shards): spread the d-loop over up to four workgroups per row block.
         // Only from Mp = 512 (bwd_split = 2 forces it everywhere, 0 disables): the hand-over needs two device-scope fences
         // per workgroup, which on this multi-XCD part write back / invalidate a whole L2 — measured +57 us on the 63-row-block
@@ -1960,24 +1978,25 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     }
     DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
-      DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, ctx->stream));
+      DS_TRY(launch_wgrad(St, 3, ctx->stream));
       if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
       continue;
     }
     // ONE event per chain boundary (an event record costs the recording stream a few microseconds): behind it the side stream takes
     // the A jobs of the NEXT layer first — its adjoints came out of this chain and its products are the large ones — then this
     // layer's B jobs (or all of its jobs when its A jobs did not go ahead)
+    hipStream_t ss = m->side;
     DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
-    DS_HIP(hipStreamWaitEvent(m->side, m->ev_bwd[l], 0));
+    DS_HIP(hipStreamWaitEvent(ss, m->ev_bwd[l], 0));
     const int nl = l - 1;
     if (early && nl >= gfirst && nl >= 1 && !(nl == gfirst && L - gfirst > 1)) {
       LayerState& Sn = m->L[nl];
-      DS_TRY(wgrad_launch(ctx, Sn.wj, Sn.njobsA, Sn.totA, Sn.ns_big, Sn.ld_used, Sn.ld_used, m->side));
+      DS_TRY(launch_wgrad(Sn, 1, ss));
       a_done[nl] = true;
     }
-    if (a_done[l]) DS_TRY(wgrad_launch(ctx, St.wjB, St.njobsB, St.totB, St.ns_big, ld, ld, m->side));
-    else DS_TRY(wgrad_launch(ctx, St.wj, St.njobs, St.tot_big, St.ns_big, ld, ld, m->side));
-    if (pipelined) DS_TRY(layer_tail(St, m->side));
+    if (a_done[l]) DS_TRY(launch_wgrad(St, 2, ss));
+    else DS_TRY(launch_wgrad(St, 3, ss));
+    if (pipelined) DS_TRY(layer_tail(St, ss));
   }
   if (overlap) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
@@ -1986,6 +2005,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     if (!m->fin.done && !m->tail_ok) DS_TRY(launch_finalize(m, m->side));
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
+
   }
   if (!pipelined) {
     hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
