@@ -4,6 +4,7 @@
 #include "layer.hpp"
 #include "linalg.hpp"
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 
 int multiclass_launch(dsdgp_ctx* ctx, const double* mean, const double* var, const double* Y, int64_t n, int64_t R, int K,
                       int mode, double wgt, double* out, double* dmean, double* dvar, int y_override);
@@ -159,7 +160,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -185,6 +186,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "tail") m->force.tail = v;
       else if (k == "ns_cap") m->force.ns_cap = v;
       else if (k == "adj_fuse") m->force.adj_fuse = v;
+      else if (k == "ext_ev") m->force.ext_ev = v;
     }
     pos = end + 1;
   }
@@ -1569,6 +1571,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   const bool keep_kuu = m->track_theta && m->kuu_valid;
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
+  bool head_event = false;
   if (m->head_ok) {
     ProfScope ps(ctx, "potrf");
     const size_t lds = head_lds_bytes(mp_max);
@@ -1580,9 +1583,13 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     HeadRand none{};
     const HeadRand& r = hr ? *hr : none;
     const int nprep = std::max(32, m->prep_blocks / 2);
-    hipLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk, L), dim3(HEAD_THREADS), lds, ctx->stream, m->theta, m->layers_dev, m->lik_const,
-                       m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep, keep_kuu ? 1 : 0,
-                       m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r);
+    // with a side stream the launch carries the fork event itself (hipExtLaunchKernel attaches it to the dispatch's completion signal):
+    // a separate hipEventRecord puts a marker packet on this stream that the next kernel queues behind (~6 us, profiles/r03_timeline_*)
+    head_event = side && m->force.ext_ev != 0;
+    hipExtLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk, L), dim3(HEAD_THREADS), (uint32_t)lds, ctx->stream, nullptr,
+                          head_event ? m->ev_fork : nullptr, 0, (const double*)m->theta, (const LayerDev*)m->layers_dev, m->lik_const,
+                          (int64_t)m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep,
+                          keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r);
     DS_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
@@ -1606,7 +1613,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   }
   hipStream_t st = ctx->stream;
   if (side) {
-    DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));
+    if (!head_event) DS_HIP(hipEventRecord(m->ev_fork, ctx->stream));
     DS_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     st = m->side;
   }
@@ -1920,12 +1927,14 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   };
   bool a_done[DSDGP_MAX_LAYERS] = {false};
   // which: 1 = A jobs, 2 = B jobs, 3 = all
-  auto launch_wgrad = [&](LayerState& Sx, int which, hipStream_t st) -> int {
+  auto launch_wgrad = [&](LayerState& Sx, int which, hipStream_t st, hipEvent_t done = nullptr) -> int {
     const int64_t ldx = Sx.ld_used;
-    if (which == 1) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st);
-    if (which == 2) return wgrad_launch(ctx, Sx.wjB, Sx.njobsB, Sx.totB, Sx.ns_big, ldx, ldx, st);
-    return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st);
+    if (which == 1) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st, done);
+    if (which == 2) return wgrad_launch(ctx, Sx.wjB, Sx.njobsB, Sx.totB, Sx.ns_big, ldx, ldx, st, done);
+    return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st, done);
   };
+  const bool ext = m->force.ext_ev >= 2;      // (measured: +3 us when the chain / weight-gradient launches carry their events; -2.5 us for k_head alone)
+  bool side_marked = false;      // ev_side already rides on the side stream's last launch
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1976,6 +1985,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
+    const bool to_side = overlap && !on_main;
+    b.done_event = (to_side && ext) ? m->ev_bwd[l] : nullptr;
     DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, 3, ctx->stream));
@@ -1986,7 +1997,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // the A jobs of the NEXT layer first — its adjoints came out of this chain and its products are the large ones — then this
     // layer's B jobs (or all of its jobs when its A jobs did not go ahead)
     hipStream_t ss = m->side;
-    DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
+    if (!ext) DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
     DS_HIP(hipStreamWaitEvent(ss, m->ev_bwd[l], 0));
     const int nl = l - 1;
     if (early && nl >= gfirst && nl >= 1 && !(nl == gfirst && L - gfirst > 1)) {
@@ -1994,8 +2005,11 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       DS_TRY(launch_wgrad(Sn, 1, ss));
       a_done[nl] = true;
     }
-    if (a_done[l]) DS_TRY(launch_wgrad(St, 2, ss));
-    else DS_TRY(launch_wgrad(St, 3, ss));
+    // the side stream's last launch of the pass carries the join event
+    const bool last_side = ext && !pipelined && m->tail_ok && (l == gfirst || (l == gfirst + 1 && L - gfirst > 1));
+    if (a_done[l]) DS_TRY(launch_wgrad(St, 2, ss, last_side ? m->ev_side : nullptr));
+    else DS_TRY(launch_wgrad(St, 3, ss, last_side ? m->ev_side : nullptr));
+    side_marked = side_marked || last_side;
     if (pipelined) DS_TRY(layer_tail(St, ss));
   }
   if (overlap) {
@@ -2003,7 +2017,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
     // everything queued behind it on this stream waited with it
     if (!m->fin.done && !m->tail_ok) DS_TRY(launch_finalize(m, m->side));
-    DS_HIP(hipEventRecord(m->ev_side, m->side));
+    if (!side_marked) DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
 
   }
