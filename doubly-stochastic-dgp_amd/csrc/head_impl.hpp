@@ -324,12 +324,24 @@ __device__ __forceinline__ void head_factor(const LayerDev& v, const double* __r
   HEAD_STAMP(4);     // log det, last block row of the inverse
 }
 
-// grid (1 + nprep + hr.nblk, L), HEAD_THREADS threads, head_lds_bytes(max Mp) of dynamic LDS
+// grid (1 + nprep + hr.nblk + hg.nblk, L), HEAD_THREADS threads, head_lds_bytes(max Mp) of dynamic LDS
 __global__ __launch_bounds__(HEAD_THREADS) void k_head(const double* __restrict__ theta, const LayerDev* __restrict__ layers,
                                                        double* __restrict__ lik_const, int64_t off_lik, int lik_gauss, double jitter,
-                                                       int nprep, int keep_kuu, int white, int timing, const HeadRand hr) {
+                                                       int nprep, int keep_kuu, int white, int timing, const HeadRand hr, const HeadGather hg) {
   extern __shared__ __attribute__((aligned(16))) double head_dyn[];
   const int bx = (int)blockIdx.x, l = (int)blockIdx.y;
+  if (bx > nprep + hr.nblk) {         // minibatch rows (Minibatch(X), Minibatch(Y) of dgp.py:51-52), block row 0 only
+    if (l != 0) return;
+    const int64_t ct = hg.dx + hg.dy, nth = (int64_t)hg.nblk * HEAD_THREADS;
+    for (int64_t i = (int64_t)(bx - 1 - nprep - hr.nblk) * HEAD_THREADS + threadIdx.x; i < hg.n * ct; i += nth) {
+      const int64_t r = i / ct, j = i % ct;
+      if (j < hg.dx)
+        hg.Xd[r * hg.dx + j] = hg.Xs[hg.idx[r] * hg.dx + j];
+      else
+        hg.Yd[r * hg.dy + (j - hg.dx)] = hg.Ys[hg.idx[r] * hg.dy + (j - hg.dx)];
+    }
+    return;
+  }
   if (bx > nprep) {                   // N(0,1) draws of layer l (Philox stream l, as dsdgp_randn / k_randn number them)
     if (hr.count[l] > 0)
       randn_body(hr.seed, (uint64_t)l, hr.count[l], hr.out[l], (int64_t)(bx - 1 - nprep) * HEAD_THREADS + threadIdx.x, (int64_t)hr.nblk * HEAD_THREADS);

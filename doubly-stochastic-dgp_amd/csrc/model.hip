@@ -139,6 +139,7 @@ struct dsdgp_model {
   bool tail_ok = false;         // non-white, every D_in <= WIDE_DIN: gradient assembly in k_asm_rows + k_tail (one wave per inducing row)
   struct { int on; double lr_t, b1, b2, eps; } fuse_adam = {0, 0, 0, 0, 0};   // dsdgp_model_train_step: Adam applied inside k_tail
   int mp_max_all = 0, m_max_all = 0;
+  double *Xmb = nullptr, *Ymb = nullptr;   // gathered minibatch of dsdgp_model_train_step_minibatch (n_max x D_in of layer 0 / x DY)
   bool head_ok = false;         // every layer has Mp <= 128 and D_in <= 16: parameter transforms, Ku, its factorisation and inverse
                                 // factor (and the inner layers' N(0,1) draws) in ONE launch (k_head, head_impl.hpp)
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
@@ -252,6 +253,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   const int64_t Rlast = (int64_t)m->s_max * m->n_max;
   m->lik_blocks_max = ceil_div((Rlast + 16) * D.layers[D.L - 1].D_out, 256) + 1;   // + the 16-row padding written by the fused adjoint path
   m->lik_part = b.take<double>((size_t)m->lik_blocks_max * 2);
+  m->Xmb = b.take<double>((size_t)m->n_max * D.layers[0].D_in);
+  m->Ymb = b.take<double>((size_t)m->n_max * D.layers[D.L - 1].D_out);
   m->lik_dmean = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
   m->lik_dvar = b.take<double>((size_t)Rlast * D.layers[D.L - 1].D_out);
   m->potrf_items = b.take<PotrfItem>(D.L);
@@ -505,6 +508,15 @@ struct HeadRand {
   int64_t count[DSDGP_MAX_LAYERS];      // 0: this layer takes no draw from here
   uint64_t seed;
   int32_t nblk;                         // block columns of the launch that generate draws
+};
+
+// the minibatch rows gathered inside the head launch too (dsdgp_model_train_step_minibatch): they depend on nothing but the indices
+struct HeadGather {
+  const double *Xs, *Ys;       // whole data (rows x dx / rows x dy)
+  const int64_t* idx;          // row indices of this minibatch (already offset)
+  double *Xd, *Yd;             // (n x dx), (n x dy)
+  int64_t n;
+  int32_t dx, dy, nblk;
 };
 
 #include "head_impl.hpp"
@@ -1564,7 +1576,8 @@ static int join_prep(dsdgp_model* m) {
 // U_d U_d^T — which nothing needs before the backward pass / the final reduction: with `side` it runs on the side stream
 // concurrently with the forward layers and the caller joins (join_prep) where it is first consumed.
 // (`side` = run that part on the side stream.)
-static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = false, const HeadRand* hr = nullptr) {
+static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = false, const HeadRand* hr = nullptr,
+                         const HeadGather* hg = nullptr) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
@@ -1582,14 +1595,16 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     }
     HeadRand none{};
     const HeadRand& r = hr ? *hr : none;
+    HeadGather gnone{};
+    const HeadGather& gq = hg ? *hg : gnone;
     const int nprep = std::max(32, m->prep_blocks / 2);
     // with a side stream the launch carries the fork event itself (hipExtLaunchKernel attaches it to the dispatch's completion signal):
     // a separate hipEventRecord puts a marker packet on this stream that the next kernel queues behind (~6 us, profiles/r03_timeline_*)
     head_event = side && m->force.ext_ev != 0;
-    hipExtLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk, L), dim3(HEAD_THREADS), (uint32_t)lds, ctx->stream, nullptr,
+    hipExtLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk + gq.nblk, L), dim3(HEAD_THREADS), (uint32_t)lds, ctx->stream, nullptr,
                           head_event ? m->ev_fork : nullptr, 0, (const double*)m->theta, (const LayerDev*)m->layers_dev, m->lik_const,
                           (int64_t)m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep,
-                          keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r);
+                          keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r, gq);
     DS_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
@@ -2063,10 +2078,15 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   return DSDGP_OK;
 }
 
-extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S,
-                                const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
-                                double kl_weight, int with_grad, double* out) {
-  DS_CHECK_ARG(m && X && Y && out);
+// minibatch to gather before the evaluation (dsdgp_model_train_step_minibatch): rows idx[0..n) of the resident data
+struct GatherSrc {
+  const double *Xs, *Ys;
+  const int64_t* idx;
+};
+static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
+                     const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, int with_grad, double* out,
+                     const GatherSrc* gs) {
+  DS_CHECK_ARG(m && out && ((X && Y) || gs));
   DS_CHECK_ARG(!zs || zstride);
   DS_CHECK_ARG(!m->sample_w || S == m->sample_w_S);
   if (with_grad) {
@@ -2098,7 +2118,19 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
       }
     if (z_side) DS_HIP(hipEventRecord(m->ev_z, m->side));
   }
-  DS_TRY(prepare_async(m, with_grad != 0, ovl, z_head ? &hr : nullptr));
+  HeadGather hg{};
+  if (gs) {
+    DS_CHECK_ARG(n > 0 && n <= m->n_max);
+    const int dx = m->desc.layers[0].D_in, dy = (m->desc.lik_kind == DSDGP_LIK_MULTICLASS) ? 1 : m->desc.layers[L - 1].D_out;
+    if (m->head_ok) {
+      hg = HeadGather{gs->Xs, gs->Ys, gs->idx, m->Xmb, m->Ymb, n, dx, dy, (int)std::min<int64_t>(16, ceil_div(n * (dx + dy), 2 * HEAD_THREADS))};
+    } else {
+      DS_TRY(dsdgp_gather_rows2(ctx, gs->Xs, dx, m->Xmb, gs->Ys, dy, m->Ymb, gs->idx, n, 0));
+    }
+    X = m->Xmb;
+    Y = m->Ymb;
+  }
+  DS_TRY(prepare_async(m, with_grad != 0, ovl, z_head ? &hr : nullptr, (gs && m->head_ok) ? &hg : nullptr));
   if (z_side) DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_z, 0));
   DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side || z_head));
   LayerState& last = m->L[L - 1];
@@ -2152,6 +2184,13 @@ extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y
   return DSDGP_OK;
 }
 
+extern "C" int dsdgp_model_elbo(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S,
+                                const double* const* zs, const int64_t* zstride, uint64_t seed, double data_scale,
+                                double kl_weight, int with_grad, double* out) {
+  DS_CHECK_ARG(X && Y);
+  return elbo_impl(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, with_grad, out, nullptr);
+}
+
 extern "C" int dsdgp_model_set_sample_weights(dsdgp_model* m, const double* w, int32_t S) {
   DS_CHECK_ARG(m && (!w || (S > 0 && S <= m->s_max)));
   m->sample_w = w;
@@ -2180,28 +2219,43 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
 // One optimiser step in one call: ELBO + gradient with the Adam update applied by the tail launch of the reverse pass (no separate
 // k_adam launch; `session.run(opt_op)` of demos/demo_regression_UCI.ipynb:324).  Falls back to elbo + adam_step where the fused tail
 // does not apply (white=True, wide inputs).
-extern "C" int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
-                                      const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
-                                      double beta2, double eps, int64_t t, double* out) {
+static int train_step_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
+                           const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
+                           double beta2, double eps, int64_t t, double* out, const GatherSrc* gs) {
   DS_CHECK_ARG(m && m->grad && m->adam_m && m->adam_v && t >= 1);
   if (!m->desc.white && m->grad_first > 0) {
     dsdgp_set_error("dsdgp_model_train_step: the reverse pass is restricted to layers >= %d (dsdgp_model_set_grad_first_layer)", m->grad_first);
     return DSDGP_ERR_BAD_ARG;
   }
   if (!m->tail_ok) {
-    DS_TRY(dsdgp_model_elbo(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out));
+    DS_TRY(elbo_impl(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out, gs));
     return dsdgp_model_adam_step(m, lr, beta1, beta2, eps, t);
   }
   m->fuse_adam.on = 1;
   m->fuse_adam.lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   m->fuse_adam.b1 = beta1; m->fuse_adam.b2 = beta2; m->fuse_adam.eps = eps;
-  const int rc = dsdgp_model_elbo(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out);
+  const int rc = elbo_impl(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, 1, out, gs);
   m->fuse_adam.on = 0;
   DS_TRY(rc);
   m->prepared = false;
   m->kuu_valid = false;
   m->q_dirty = -2;
   return DSDGP_OK;
+}
+extern "C" int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
+                                      const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
+                                      double beta2, double eps, int64_t t, double* out) {
+  DS_CHECK_ARG(X && Y);
+  return train_step_impl(m, X, Y, n, S, zs, zstride, seed, data_scale, kl_weight, lr, beta1, beta2, eps, t, out, nullptr);
+}
+// The same step on rows idx[idx_offset .. idx_offset + n) of the resident data: the gather ([UPSTREAM] gpflow.params.Minibatch,
+// dgp.py:51-52) happens inside the step's first launch instead of a launch of its own.
+extern "C" int dsdgp_model_train_step_minibatch(dsdgp_model* m, const double* X_all, const double* Y_all, const int64_t* idx,
+                                                int64_t idx_offset, int64_t n, int32_t S, uint64_t seed, double data_scale, double kl_weight,
+                                                double lr, double beta1, double beta2, double eps, int64_t t, double* out) {
+  DS_CHECK_ARG(X_all && Y_all && idx && idx_offset >= 0);
+  const GatherSrc gs{X_all, Y_all, idx + idx_offset};
+  return train_step_impl(m, nullptr, nullptr, n, S, nullptr, nullptr, seed, data_scale, kl_weight, lr, beta1, beta2, eps, t, out, &gs);
 }
 
 extern "C" int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first) {

@@ -100,17 +100,14 @@ class DGP_Base(Parameterized):
         self._seed += 1
         return self._seed
 
-    def next_minibatch(self):
-        """Device tensors (Xb, Yb) of the next minibatch (dgp.py:51-52), or the full data when not minibatching."""
-        Xd, Yd = self._device_data()
-        if self._minibatch is None:
-            return Xd, Yd
-        eng = self.engine()
-        ctx = eng.ctx
+    def _next_index_span(self):
+        """(device index tensor, offset, n) of the next minibatch.  The row indices of the next CHUNK minibatches are drawn on the
+        host in one go and uploaded once (pinned, asynchronous); a step then only moves an offset.  One upload per epoch (or per step
+        when a minibatch straddles an epoch boundary — 2 of every 7 steps at 7372 / 1000) stalled the host behind the stream and the
+        GPU behind the host: ~50 us on each such step."""
+        Xd, _ = self._device_data()
+        ctx = self.engine().ctx
         mb = self._minibatch
-        # The row indices of the next CHUNK minibatches are drawn on the host in one go and uploaded once (pinned, asynchronous);
-        # a step then only moves an offset.  One upload per epoch (or per step when a minibatch straddles an epoch boundary — 2 of
-        # every 7 steps at 7372 / 1000) stalled the host behind the stream and the GPU behind the host: ~50 us on each such step.
         if getattr(self, "_idx_src", None) is not mb or self._idx_pos >= self._idx_cnt:
             k = max(1, min(512, (1 << 18) // max(1, mb.batch_size)))
             host = ctx.torch.from_numpy(mb.next_chunk(k))
@@ -121,8 +118,17 @@ class DGP_Base(Parameterized):
             self._idx_host = host                                  # alive until the copy has run
             self._idx_dev = host.to(Xd.device, non_blocking=True)
             self._idx_src, self._idx_pos, self._idx_cnt = mb, 0, k
-        idx, off, n = self._idx_dev, self._idx_pos * mb.batch_size, mb.batch_size
+        off = self._idx_pos * mb.batch_size
         self._idx_pos += 1
+        return self._idx_dev, off, mb.batch_size
+
+    def next_minibatch(self):
+        """Device tensors (Xb, Yb) of the next minibatch (dgp.py:51-52), or the full data when not minibatching."""
+        Xd, Yd = self._device_data()
+        if self._minibatch is None:
+            return Xd, Yd
+        ctx = self.engine().ctx
+        idx, off, n = self._next_index_span()
         Xb, Yb = ctx.empty(n, Xd.shape[1]), ctx.empty(n, Yd.shape[1])
         _lib.check(ctx.lib.dsdgp_gather_rows2(ctx.handle, C.c_void_p(Xd.data_ptr()), Xd.shape[1], C.c_void_p(Xb.data_ptr()),
                                               C.c_void_p(Yd.data_ptr()), Yd.shape[1], C.c_void_p(Yb.data_ptr()),
@@ -203,12 +209,20 @@ class DGP_Base(Parameterized):
         """One optimiser step of -ELBO: minibatch gather + forward + reverse-mode gradient + Adam
         (one `session.run(opt_op)` of demos/demo_regression_UCI.ipynb:324).  Returns the ELBO if sync=True."""
         eng = self.engine()
+        rank, world, allreduce = self._dist if self._dist else (0, 1, None)
+        if X is None and zs is None and allreduce is None and self._minibatch is not None:
+            # the whole step — minibatch gather, ELBO, gradient, Adam — in one library call
+            Xd, Yd = self._device_data()
+            idx, off, n = self._next_index_span()
+            scale, klw = shard_terms(self.num_data, n, 1)
+            eng.train_step_minibatch(Xd, Yd, idx, off, n, self.num_samples, seed=self._next_seed(), data_scale=scale, kl_weight=klw,
+                                     lr=lr, beta1=beta1, beta2=beta2, eps=eps)
+            return self._sync_result(eng, None, world) if sync else None
         if X is None:
             X, Y = self.next_minibatch()
         elif not hasattr(Y, "data_ptr"):
             self.likelihood.check_targets(Y)
         n_local = X.shape[0]
-        rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)
         if allreduce is None:
             # single process: ELBO, gradient and Adam update in one library call (the update rides in the reverse pass's last launch)
@@ -220,15 +234,17 @@ class DGP_Base(Parameterized):
                            kl_weight=klw, with_grad=True, sync=False)
             out = allreduce(eng, True, sync=sync)
             eng.adam_step(lr, beta1, beta2, eps)
-        if sync:
-            eng.ctx.sync()
-            o = eng.out4.cpu().numpy() if out is None else out
-            if out is None and world > 1:
-                o = o.copy(); o[3] /= world
-            if o[3] != 0.0:      # asynchronous steps report a failed Kuu factorisation here ([UPSTREAM] tf.cholesky raises)
-                raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(o[3])})")
-            return float(o[0])
-        return None
+        return self._sync_result(eng, out, world) if sync else None
+
+    @staticmethod
+    def _sync_result(eng, out, world):
+        eng.ctx.sync()
+        o = eng.out4.cpu().numpy() if out is None else out
+        if out is None and world > 1:
+            o = o.copy(); o[3] /= world
+        if o[3] != 0.0:      # asynchronous steps report a failed Kuu factorisation here ([UPSTREAM] tf.cholesky raises)
+            raise _lib.CholeskyError(f"Cholesky decomposition was not successful (Kuu pivot {int(o[3])})")
+        return float(o[0])
 
     # ------------------------------------------------------------------ dgp.py:100-126
     def predict_f(self, Xnew, num_samples):

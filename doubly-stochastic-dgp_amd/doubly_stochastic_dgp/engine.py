@@ -398,6 +398,22 @@ class Engine:
         self._dev_dirty = True
         self._needs_prepare = True
 
+    def train_step_minibatch(self, Xall, Yall, idx, idx_offset, n, S, seed=0, data_scale=1.0, kl_weight=1.0, lr=0.01, beta1=0.9,
+                             beta2=0.999, eps=1e-8):
+        """train_step on rows idx[idx_offset : idx_offset + n] of the device-resident data (gather inside the step's first launch)."""
+        self._check_targets_shape(Yall, Yall.shape[0])
+        self._ensure(n, S)
+        self._upload_if_needed()
+        if getattr(self, "_grad_first", 0) != 0:
+            _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, 0))
+            self._grad_first = 0
+        _lib.check(self.lib.dsdgp_model_train_step_minibatch(self.model, ptr(Xall), ptr(Yall), ptr(idx), int(idx_offset), int(n), S,
+                                                             C.c_uint64(seed), float(data_scale), float(kl_weight), lr, beta1, beta2,
+                                                             eps, self.adam_t + 1, ptr(self.out4)))
+        self.adam_t += 1
+        self._dev_dirty = True
+        self._needs_prepare = True
+
     def _check_targets_shape(self, Yd, n):
         """Y must be (n, D_out of the last layer) for the element-wise likelihoods, (n, 1) labels for MultiClass: the likelihood
         kernels index Y[(row % n) * DY + d] and would read out of bounds otherwise."""

@@ -179,6 +179,13 @@ int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int
                            const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
                            double beta2, double eps, int64_t t, double* out);
 
+/* dsdgp_model_train_step on the minibatch rows idx[idx_offset .. idx_offset + n) of the resident data X_all (rows x D_in of the first
+ * layer) / Y_all (rows x D_Y): the two Minibatch iterators of dgp.py:51-52 and the optimiser step in one call; the gather runs inside
+ * the step's first launch.  idx: device int64.  Fresh N(0,1) draws (Philox, `seed`); no explicit zs. */
+int dsdgp_model_train_step_minibatch(dsdgp_model* m, const double* X_all, const double* Y_all, const int64_t* idx, int64_t idx_offset,
+                                     int64_t n, int32_t S, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
+                                     double beta2, double eps, int64_t t, double* out);
+
 /* [UPSTREAM] gpflow.training.NatGradOptimizer(gamma) step on layer l's (q_mu, q_sqrt), using the loss gradient left in
  * `grad` by the last dsdgp_model_elbo(with_grad=1) (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100):
  * per output, natural parameters theta <- theta - gamma dL/d eta, then back to (mean, Cholesky factor).

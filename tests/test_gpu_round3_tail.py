@@ -70,3 +70,28 @@ def test_fused_adam_matches_separate_adam(monkeypatch):
         outs.append((after, eng.out4.cpu().numpy().copy()))
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_minibatch_step_in_one_call_matches_gather_then_step(monkeypatch):
+    """dsdgp_model_train_step_minibatch (gather inside the head launch) == dsdgp_gather_rows2 + dsdgp_model_train_step on the same
+    index stream, bit for bit; also with the separate head kernels (DSDGP_FORCE=head=0: the gather falls back to its own launch)."""
+    for force in ("head=1", "head=0"):
+        outs = []
+        for fused in (True, False):
+            monkeypatch.setenv("DSDGP_FORCE", force)
+            rng = np.random.RandomState(21)
+            N, D, M, S = 330, 3, 24, 4
+            X, Y = rng.randn(N, D), rng.randn(N, 2)
+            Z = X[:M] + 0.05 * rng.randn(M, D)
+            _, _, model = make_case(X, Y, Z, [kern_spec("rbf", D), kern_spec("rbf", D)], S=S, num_data=N, minibatch_size=100)
+            for _ in range(9):                       # 330 / 100: minibatches straddle the epoch boundary
+                if fused:
+                    model.train_step(0.01)
+                else:
+                    Xb, Yb = model.next_minibatch()
+                    model.train_step(0.01, X=Xb, Y=Yb)
+            eng = model.engine()
+            eng.ctx.sync()
+            outs.append((eng.theta.cpu().numpy().copy(), eng.out4.cpu().numpy().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]), force
+        assert np.array_equal(outs[0][1], outs[1][1]), force
