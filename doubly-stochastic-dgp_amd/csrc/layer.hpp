@@ -33,6 +33,14 @@ struct LayerFwdArgs {
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
   double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
   unsigned long long* phase_clk;   // debug aid (DSDGP_FWD_TIMING): [workgroup][8] shader-clock stamps of the forward chain's phases, or NULL
+  // last layer of a training step with the Gaussian likelihood: [UPSTREAM] Gaussian.variational_expectations (dgp.py:89-90) and its
+  // adjoints in this chain's epilogue (k_lik_gauss's job: one launch less between the forward and the reverse pass).  lik_Y NULL: off.
+  const double* lik_Y;             // (n_inner x D_out) targets
+  const double* lik_const;         // [0] = likelihood variance
+  double lik_w;                    // data_scale / S
+  double* lik_part;                // [workgroup][2]: sum of the variational expectations, sum of d / d variance
+  double *lik_MB, *lik_VB;         // (D_out x lik_ld) transposed adjoints w.r.t. mean / var of this layer (the backward chain reads them)
+  int64_t lik_ld;
 };
 
 struct LayerBwdArgs {

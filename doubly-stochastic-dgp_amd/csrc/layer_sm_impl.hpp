@@ -416,6 +416,9 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   FWD_STAMP(4);      // mean partials
 
   const double kdiag = a.hyp[HYP_KDIAG];
+  const double lik_s2 = a.lik_Y ? a.lik_const[0] : 1.0;
+  const double lik_c0 = -0.91893853320467274178 - 0.5 * log(lik_s2);
+  double lik_ve = 0.0, lik_dl = 0.0;
   // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
   const int dchunk = (Dout + (int)gridDim.y - 1) / (int)gridDim.y;
   const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
@@ -488,7 +491,13 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       const int s0 = flat ? e / (16 * gs) : 0, e2 = e % (16 * gs);
       const int cc = e2 / gs, dd = e2 % gs, d = d0 + dd;
       const int64_t r = r0 + cc;
-      if (r >= a.Rin) continue;
+      if (r >= a.Rin) {
+        if (a.lik_Y && r < a.lik_ld && s0 == 0) {          // rows of the 16-row padding of the transposed adjoints
+          a.lik_MB[(int64_t)d * a.lik_ld + r] = 0.0;
+          a.lik_VB[(int64_t)d * a.lik_ld + r] = 0.0;
+        }
+        continue;
+      }
       double s1 = 0.0, s2sum = 0.0, mu = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
@@ -515,7 +524,35 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
           const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
           a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
         }
+        if (a.lik_Y) {
+          const double y = a.lik_Y[(orow % a.n_inner) * Dout + d];
+          const double q = (y - mu) * (y - mu) + var;
+          lik_ve += lik_c0 - 0.5 * q / lik_s2;
+          lik_dl += -0.5 / lik_s2 + 0.5 * q / (lik_s2 * lik_s2);
+          a.lik_MB[(int64_t)d * a.lik_ld + orow] = -a.lik_w * (y - mu) / lik_s2;
+          a.lik_VB[(int64_t)d * a.lik_ld + orow] = 0.5 * a.lik_w / lik_s2;
+        }
       }
+    }
+  }
+  if (a.lik_Y) {     // this workgroup's share of the variational expectations (fixed-order sums: waves, then the NW wave totals)
+    lik_ve = sum_wave(lik_ve);
+    lik_dl = sum_wave(lik_dl);
+    __syncthreads();
+    if (lane == 0) {
+      red_s1[2 * wave] = lik_ve;
+      red_s1[2 * wave + 1] = lik_dl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sv = 0.0, sd2 = 0.0;
+      for (int w = 0; w < NW; ++w) {
+        sv += red_s1[2 * w];
+        sd2 += red_s1[2 * w + 1];
+      }
+      const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      a.lik_part[2 * wg] = sv;
+      a.lik_part[2 * wg + 1] = sd2;
     }
   }
   FWD_STAMP(5);      // per-output products and epilogue

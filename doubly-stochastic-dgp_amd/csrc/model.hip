@@ -161,7 +161,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -188,6 +188,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "ns_cap") m->force.ns_cap = v;
       else if (k == "adj_fuse") m->force.adj_fuse = v;
       else if (k == "ext_ev") m->force.ext_ev = v;
+      else if (k == "lik_fuse") m->force.lik_fuse = v;
     }
     pos = end + 1;
   }
@@ -251,7 +252,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   m->lik_const = b.take<double>(8);
   m->scal4 = b.take<double>(8);
   const int64_t Rlast = (int64_t)m->s_max * m->n_max;
-  m->lik_blocks_max = ceil_div((Rlast + 16) * D.layers[D.L - 1].D_out, 256) + 1;   // + the 16-row padding written by the fused adjoint path
+  m->lik_blocks_max = std::max(ceil_div((Rlast + 16) * D.layers[D.L - 1].D_out, 256) + 1,   // + the 16-row padding written by the fused adjoint path
+                               4 * ceil_div(Rlast, 16) + 4);                                 // likelihood inside the last chain: one pair per workgroup
   m->lik_part = b.take<double>((size_t)m->lik_blocks_max * 2);
   m->Xmb = b.take<double>((size_t)m->n_max * D.layers[0].D_in);
   m->Ymb = b.take<double>((size_t)m->n_max * D.layers[D.L - 1].D_out);
@@ -1717,7 +1719,8 @@ static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t c
 // dgp.py:61-76 propagate
 static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, const double* const* zs,
                           const int64_t* zstride, uint64_t seed, bool save, bool need_last_F, double* const* Fs,
-                          double* const* Fmeans, double* const* Fvars, bool z_ready = false) {
+                          double* const* Fmeans, double* const* Fvars, bool z_ready = false, const double* lik_Y = nullptr,
+                          double lik_w = 0.0, int* lik_nblocks = nullptr) {
   dsdgp_ctx* ctx = m->ctx;
   const int L = m->desc.L;
   DS_CHECK_ARG(n > 0 && n <= m->n_max && S > 0 && S <= m->s_max);
@@ -1763,6 +1766,11 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     {
       const int64_t nblk = (Rin + 15) / 16;
       a.d_split = chain_d_split(nblk, v.D_out);
+      if (last && lik_Y) {      // Gaussian variational expectations + adjoints in this chain's epilogue
+        a.lik_Y = lik_Y; a.lik_const = m->lik_const; a.lik_w = lik_w; a.lik_part = m->lik_part;
+        a.lik_MB = St.MB; a.lik_VB = St.VB; a.lik_ld = round_up(Rin, 16);
+        *lik_nblocks = (int)nblk * a.d_split;
+      }
     }
     DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
@@ -2132,17 +2140,23 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
   }
   DS_TRY(prepare_async(m, with_grad != 0, ovl, z_head ? &hr : nullptr, (gs && m->head_ok) ? &hg : nullptr));
   if (z_side) DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_z, 0));
-  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side || z_head));
   LayerState& last = m->L[L - 1];
   const int DY = last.dev.D_out;
   const int64_t total = (int64_t)S * n * DY;
   int nblocks = ceil_div(total, 256);
   const double w = data_scale / (double)S;
   // the last layer of a deep model has one output row per input row: its transposed adjoints come straight from the
-  // likelihood kernel (no k_adj_prep launch on the critical path)
+  // likelihood kernel (no k_adj_prep launch on the critical path) — or, Gaussian likelihood without quadrature weights, from the
+  // last forward chain's own epilogue (no likelihood launch either)
   const bool elementwise = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN || m->desc.lik_kind == DSDGP_LIK_BERNOULLI;
   m->fused_last = with_grad && L > 1 && elementwise;
-  if (elementwise) {
+  const bool lik_in_chain = m->fused_last && m->desc.lik_kind == DSDGP_LIK_GAUSSIAN && !m->sample_w && m->force.lik_fuse != 0;
+  int lik_nb = 0;
+  DS_TRY(forward_layers(m, X, n, S, zs, zstride, seed, with_grad != 0, false, nullptr, nullptr, nullptr, z_side || z_head,
+                        lik_in_chain ? Y : nullptr, w, &lik_nb));
+  if (lik_in_chain) {
+    nblocks = lik_nb;
+  } else if (elementwise) {
     const int64_t ldt = round_up((int64_t)S * n, 16);
     if (m->fused_last) nblocks = ceil_div(ldt * DY, 256);
     double* dm = (with_grad && !m->fused_last) ? m->lik_dmean : nullptr;
