@@ -176,7 +176,43 @@ def sub_rooflines(ctx):
                                        note="one matrix; latency-bound launch sequence" if M >= 512 else
                                             "one LDS-resident workgroup; latency-bound"))
     ctx.prof_enable(False)
+    # K4: the blocked triangular solve at the two right-hand-side shapes north_star names (Kuu^-1/2 Kuf: M x S N), n^2 nrhs flops
+    import torch
+    out["trsm"] = []
+    for (M, R) in ((128, 20000), (1024, 50000)):
+        L = np.tril(rng.standard_normal((M, M))) / np.sqrt(M) + 2.0 * np.eye(M)
+        dL, dB = ctx.to_device(L), ctx.to_device(rng.standard_normal((M, R)))
+
+        def solve():
+            _lib.check(ctx.lib.dsdgp_trsm(ctx.handle, 0, M, R, C.c_void_p(dL.data_ptr()), M, C.c_void_p(dB.data_ptr()), R))
+        for _ in range(2):
+            solve()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # ctx stream == torch's current stream
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            solve()                 # (in place: the iterates shrink towards 0, the flop count does not depend on the values)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        fl = float(M) * M * R
+        tf = fl / (us * 1e-6) / 1e12
+        out["trsm"].append(dict(n=M, nrhs=R, us=round(us, 1), algorithmic_gflop=round(fl / 1e9, 3), bound="mfma", achieved=round(tf, 3),
+                                peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                note="16 x 16 diagonal inverses + 128-row panels (one wave per 16 columns) + MFMA GEMM updates"))
     return out
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: ties a committed PMC traffic profile to the build it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "doubly-stochastic-dgp_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")) or name == "Makefile":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -232,7 +268,7 @@ def main():
         model.train_step(0.01)
     torch.cuda.synchronize()
 
-    evals_per_s = predict_rows_per_s = None
+    evals_per_s = predict_rows_per_s = predict_fwd = None
     prof = {}
     sub = {}
     steady = None
@@ -254,6 +290,15 @@ def main():
             eng.propagate(Xs, 100, seed=i, want=("mean", "var"))
         torch.cuda.synchronize()
         predict_rows_per_s = 20 * 100 * 1000 / (time.perf_counter() - t1)
+        # the forward chains of predict_f alone (HIP events on the launch stream): roofline entry of the second named metric
+        ctx.prof_enable(True)
+        ctx.prof_read("layer_fwd")
+        for i in range(10):
+            eng.propagate(Xs, 100, seed=i, want=("mean", "var"))
+        torch.cuda.synchronize()
+        pf_ms, pf_cnt = ctx.prof_read("layer_fwd")
+        ctx.prof_enable(False)
+        predict_fwd = dict(ms_per_call=pf_ms / 10, launches_per_call=pf_cnt / 10)
 
         # per-kernel HIP-event timing on the launch streams (events perturb the pipeline slightly, hence a separate loop); the
         # wgrad/backward side-stream overlap is switched off here so that each duration is the kernel's own
@@ -266,6 +311,8 @@ def main():
         for name in ("layer_fwd", "layer_bwd", "wgrad", "gemm", "potrf"):
             ms, cnt = ctx.prof_read(name)
             prof[name] = dict(ms_per_step=ms / nprof, launches_per_step=cnt / nprof)
+        prof["potrf"]["note"] = ("the fused head launch k_head: parameter transforms + Ku + Cholesky + inverse factor + N(0,1) draws + "
+                                 "minibatch gather")
         ctx.prof_enable(False)
         os.environ["DSDGP_NO_OVERLAP"] = "0"
         if rank == 0:
@@ -307,10 +354,13 @@ def main():
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (2*FETCH + WRITE, the gfx950
     # correction of MI355X_MICROARCH.md) and labelled with its source; null when no current profile is shipped
     traffic, traffic_source = {}, None
-    for cand in ("r02_pmc_traffic.json",):
+    for cand in ("r03_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)
+            if pmc.pop("csrc_sha256_16", None) != csrc_hash():
+                traffic_source = f"profiles/{cand} was taken from other kernel sources than this build: traffic not reported"
+                break
             for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("wgrad", "k_wgrad")):
                 hit = [v for k, v in pmc.items() if k.startswith(key)]
                 if hit:
@@ -330,9 +380,19 @@ def main():
                               frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name), traffic_source=traffic_source,
                               ms_per_step=round(ms, 4), launches_per_step=prof[name]["launches_per_step"],
                               algorithmic_gflop_per_step=round(fl[name] / 1e9, 3))
+    if predict_fwd is not None:
+        # predict_f(S = 100, 1000 test points): forward chains only, layer 0 on 1000 rows, layers 1.. on 100 000
+        cfgp = dict(cfg, S=100, mb=1000)
+        flp = algorithmic_flops(cfgp)["layer_fwd"]
+        ach = flp / (predict_fwd["ms_per_call"] * 1e-3) / 1e12
+        roof_all["predict_f_fwd"] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                         frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=None, traffic_source=None,
+                                         ms_per_step=round(predict_fwd["ms_per_call"], 4),
+                                         launches_per_step=predict_fwd["launches_per_call"],
+                                         algorithmic_gflop_per_step=round(flp / 1e9, 3))
     roofline = None
     if roof_all:
-        dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])
+        dominant = max((k for k in roof_all if k != "predict_f_fwd"), key=lambda k: roof_all[k]["ms_per_step"])
         roofline = dict(roof_all[dominant], kernel=dominant)
 
     if rank == 0:

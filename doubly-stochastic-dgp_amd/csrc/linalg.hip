@@ -847,8 +847,7 @@ extern "C" int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, 
   return gemm_launch(ctx, (const GemmProblem*)scr, 1, total);
 }
 
-// B <- L^{-1} B (trans=0) or L^{-T} B (trans=1): explicit blocked inverse of L (k_potrf_trtri's second half would need
-// the factor; here L is given, so pad it, invert it with the same blocked recurrence, then one MFMA GEMM).
+// inverse of padded lower-triangular matrices by the blocked recurrence of k_potrf_trtri (natural-gradient step: T^-1 of q_sqrt)
 __global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ Wb, double* __restrict__ Linvb, int n, int64_t stride) {
   // W: padded lower-triangular L (n multiple of 16, identity pad), one matrix per workgroup. Recurrence of k_potrf_trtri.
   double* __restrict__ W = Wb + (int64_t)blockIdx.x * stride;
@@ -899,50 +898,6 @@ __global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ Wb, dou
     const int i = idx / n, j = idx % n;
     if (j > i) Linv[(int64_t)i * ld + j] = 0.0;
   }
-}
-
-__global__ void k_pad_tril(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ P, int np) {
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < np * np; idx += gridDim.x * blockDim.x) {
-    const int i = idx / np, j = idx % np;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < n && j < n) v = (j <= i) ? L[(int64_t)i * ldl + j] : 0.0;
-    P[idx] = v;
-  }
-}
-__global__ void k_copy2d(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int rows,
-                         int64_t cols) {
-  const int64_t total = (int64_t)rows * cols;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = idx / cols, j = idx % cols;
-    dst[i * ldd + j] = src[i * lds_ + j];
-  }
-}
-
-extern "C" int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const double* L, int64_t ldl, double* B,
-                          int64_t ldb) {
-  DS_CHECK_ARG(ctx && L && B && n > 0 && nrhs > 0 && ldl >= n && ldb >= nrhs);
-  const int np = (int)round_up(n, 16);
-  const size_t mat = (size_t)np * np * sizeof(double);
-  const size_t rhs = round_up((size_t)n * nrhs * sizeof(double), 256);
-  void* scr;
-  DS_TRY(ctx_scratch(ctx, 2 * mat + rhs + 256, &scr));
-  double* Lp = (double*)scr;
-  double* Li = (double*)((char*)scr + mat);
-  double* Bc = (double*)((char*)scr + 2 * mat);
-  GemmProblem* Pd = (GemmProblem*)((char*)scr + 2 * mat + rhs);
-  hipLaunchKernelGGL(k_pad_tril, dim3(ceil_div(np * np, 256)), dim3(256), 0, ctx->stream, L, ldl, n, Lp, np);
-  hipLaunchKernelGGL(k_trtri_only, dim3(1), dim3(256), 0, ctx->stream, Lp, Li, np, (int64_t)0);
-  const int nblk = (int)std::min<int64_t>(4096, ceil_div((int64_t)n * nrhs, 256));
-  hipLaunchKernelGGL(k_copy2d, dim3(nblk), dim3(256), 0, ctx->stream, B, ldb, Bc, nrhs, n, nrhs);
-  GemmProblem P{};
-  P.A = Li; P.B = Bc; P.C = B;
-  P.lda = np; P.ldb = nrhs; P.ldc = ldb;
-  P.m = n; P.n = (int)nrhs; P.k = n;
-  P.transA = trans ? 1 : 0; P.transB = 0;
-  P.batch = 1; P.alpha = 1.0; P.beta = 0.0;
-  const int total = gemm_plan(&P, 1);
-  DS_TRY(ctx_upload(ctx, Pd, &P, sizeof(P)));
-  return gemm_launch(ctx, Pd, 1, total);
 }
 
 int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch) {

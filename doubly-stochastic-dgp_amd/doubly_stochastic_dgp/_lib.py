@@ -67,6 +67,8 @@ _PROTOS = {
                              C.c_double, C.c_void_p, C.c_int64]),
     "dsdgp_potrf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int)]),
     "dsdgp_trsm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "dsdgp_trsm_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_int64]),
     "dsdgp_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                              C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64]),
     "dsdgp_model_workspace_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),

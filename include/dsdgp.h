@@ -85,9 +85,16 @@ int dsdgp_gram(dsdgp_ctx* ctx, const dsdgp_kernel* kern, const double* X, int64_
  * Blocked right-looking factorisation; the trailing update is an fp64-MFMA syrk/gemm. */
 int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t lda, int64_t stride, int* info);
 
-/* K4 — tf.matrix_triangular_solve(L, B, lower=True) and its transposed form (layers.py:186,188,239):
- *   trans=0: B <- L^{-1} B ;  trans=1: B <- L^{-T} B.   L: n x n lower, B: n x nrhs. */
+/* K4 — tf.matrix_triangular_solve(L, B, lower=True) and its transposed form (layers.py:186,188):
+ *   trans=0: B <- L^{-1} B ;  trans=1: B <- L^{-T} B.   L: n x n lower (only the lower triangle is read), B: n x nrhs, in place.
+ * Blocked: 16 x 16 diagonal-block inverses, 128-row panels solved one wave per 16 right-hand-side columns (MFMA products chained in
+ * registers), MFMA GEMM updates of the rows below / above a panel.  n^2 nrhs flops; any n, any nrhs; asynchronous. */
 int dsdgp_trsm(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const double* L, int64_t ldl, double* B, int64_t ldb);
+/* The batched form of layers.py:239, tf.matrix_triangular_solve(self.Lu_tiled, self.q_sqrt): `batch` right-hand-side matrices
+ * strideB doubles apart, their L matrices strideL apart — strideL = 0: ONE L shared by the batch (the reference tiles Lu D_out
+ * times, layers.py:173; nothing is tiled here). */
+int dsdgp_trsm_batched(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, int batch, const double* L, int64_t ldl, int64_t strideL,
+                       double* B, int64_t ldb, int64_t strideB);
 
 /* plain fp64-MFMA GEMM used by the M x M algebra: C = alpha op(A) op(B) + beta C (row-major). */
 int dsdgp_gemm(dsdgp_ctx* ctx, int transA, int transB, int m, int n, int k, double alpha, const double* A,

@@ -84,3 +84,43 @@ def test_early_wgrad_with_pruned_reverse_pass(monkeypatch):
         outs.append((e, g["l2.q_mu"].copy(), g["l2.q_sqrt"].copy()))
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+# ---------------------------------------------------------------- blocked / batched triangular solve (K4)
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("n,nrhs,batch,shared", [(128, 257, 8, True), (100, 64, 3, False), (300, 50, 2, True), (17, 5, 4, False)])
+def test_trsm_batched(ctx, trans, n, nrhs, batch, shared):
+    """layers.py:239: tf.matrix_triangular_solve(Lu_tiled, q_sqrt) — `batch` right-hand sides against one shared L (strideL = 0) or
+    their own; ragged n and nrhs (partial 16-blocks, partial 64-column workgroups, several 128-row panels)."""
+    import scipy.linalg as sla
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n + batch)
+    nL = 1 if shared else batch
+    L = np.tril(rng.randn(nL, n, n)) + 4 * np.eye(n)
+    L = L + np.triu(rng.randn(nL, n, n), 1) * 0 + np.triu(np.full((nL, n, n), 7.0), 1)      # garbage above the diagonal: never read
+    B = rng.randn(batch, n, nrhs)
+    dL, dB = _dev(ctx, L), _dev(ctx, B)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_trsm_batched(ctx.handle, trans, n, nrhs, batch, _p(dL), n, 0 if shared else n * n, _p(dB), nrhs, n * nrhs))
+    ctx.sync()
+    got = dB.cpu().numpy()
+    for b in range(batch):
+        ref = sla.solve_triangular(np.tril(L[0 if shared else b]), B[b], lower=True, trans=trans)
+        assert_allclose(got[b], ref, rtol=1e-10, atol=1e-11)
+
+
+def test_trsm_strided_views(ctx):
+    """leading dimensions larger than the matrices (sub-matrix views), as a caller holding padded buffers passes them"""
+    import scipy.linalg as sla
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(0)
+    n, nrhs, ldl, ldb = 200, 90, 256, 128
+    Lbuf, Bbuf = rng.randn(n, ldl), rng.randn(n, ldb)
+    Lbuf[:, :n] = np.tril(Lbuf[:, :n]) + 5 * np.eye(n)
+    dL, dB = _dev(ctx, Lbuf), _dev(ctx, Bbuf)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_trsm(ctx.handle, 0, n, nrhs, _p(dL), ldl, _p(dB), ldb))
+    ctx.sync()
+    got = dB.cpu().numpy()
+    assert_allclose(got[:, :nrhs], sla.solve_triangular(Lbuf[:, :n], Bbuf[:, :nrhs], lower=True), rtol=1e-10, atol=1e-11)
+    assert np.array_equal(got[:, nrhs:], Bbuf[:, nrhs:])          # columns beyond nrhs untouched

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM traffic per launch from two rocprofv3 PMC passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; values in KB).
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced reads, so
-traffic = 2*FETCH + WRITE (an upper bound for 8-byte-per-lane reads).  Usage: pmc_traffic.py <fetch.db> <write.db> <out-prefix> <title>"""
+traffic = 2*FETCH + WRITE (an upper bound for 8-byte-per-lane reads).  Usage: pmc_traffic.py <fetch.db> <write.db> <out-prefix> <title> [csrc-hash]"""
 import collections
 import json
 import sqlite3
@@ -33,6 +33,8 @@ def main(fdb, wdb, prefix, title):
                  "eval/predict loops of bench.py); values in KB per launch; traffic = 2*FETCH + WRITE (gfx950 correction).\n\n"
                  "| kernel | launches | FETCH avg | FETCH max | WRITE avg | WRITE max | traffic/launch (MB, avg) |\n|---|---|---|---|---|---|---|\n")
         fh.write("\n".join(rows) + "\n")
+    if len(sys.argv) > 5:
+        js["csrc_sha256_16"] = sys.argv[5]          # bench.csrc_hash() of the build the counters were taken from
     with open(prefix + ".json", "w") as fh:
         json.dump(js, fh, indent=1)
 
