@@ -249,8 +249,10 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
 }
 
 #define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-__global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
+// LIK: the Gaussian variational expectations + adjoints in the epilogue (LayerFwdArgs::lik_Y) — its own instance: carried by every
+// instance the extra live values cost the 4-wave forward chain an occupancy step (85 -> 111 VGPRs, 5 -> 4 waves per SIMD: +30 us per step)
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool LIK>
+__global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   constexpr bool D4 = (MPB > 16);
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
   FWD_STAMP(4);      // mean partials
 
   const double kdiag = a.hyp[HYP_KDIAG];
-  const double lik_s2 = a.lik_Y ? a.lik_const[0] : 1.0;
+  const double lik_s2 = LIK ? a.lik_const[0] : 1.0;
   const double lik_c0 = -0.91893853320467274178 - 0.5 * log(lik_s2);
   double lik_ve = 0.0, lik_dl = 0.0;
   // small launches (the N-row first layer) spread their D_out products over gridDim.y workgroups per row block
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       const int cc = e2 / gs, dd = e2 % gs, d = d0 + dd;
       const int64_t r = r0 + cc;
       if (r >= a.Rin) {
-        if (a.lik_Y && r < a.lik_ld && s0 == 0) {          // rows of the 16-row padding of the transposed adjoints
+        if (LIK && r < a.lik_ld && s0 == 0) {          // rows of the 16-row padding of the transposed adjoints
           a.lik_MB[(int64_t)d * a.lik_ld + r] = 0.0;
           a.lik_VB[(int64_t)d * a.lik_ld + r] = 0.0;
         }
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
           const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
           a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
         }
-        if (a.lik_Y) {
+        if constexpr (LIK) {
           const double y = a.lik_Y[(orow % a.n_inner) * Dout + d];
           const double q = (y - mu) * (y - mu) + var;
           lik_ve += lik_c0 - 0.5 * q / lik_s2;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(NW * 64) void k_layer_fwd_sm(const LayerFwdArgs a, 
       }
     }
   }
-  if (a.lik_Y) {     // this workgroup's share of the variational expectations (fixed-order sums: waves, then the NW wave totals)
+  if constexpr (LIK) {     // this workgroup's share of the variational expectations (fixed-order sums: waves, then the NW wave totals)
     lik_ve = sum_wave(lik_ve);
     lik_dl = sum_wave(lik_dl);
     __syncthreads();
@@ -1085,8 +1087,8 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
 
 
 // ---- launch helpers (one instance per template combination) and dispatch macros shared by the layer_sm_*.hip parts
-template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
-static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool LIK>
+static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   const SmLds L = sm_lds(MPB * 16, a.D_in, a.D_out, NW, WIDE);
   const size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) {
@@ -1097,7 +1099,7 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     {
       static int lds_set = 0;   // the attribute is sticky: one driver call per instance and size
       if ((int)lds > lds_set) {
-        DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DS_HIP(hipFuncSetAttribute((const void*)k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = (int)lds;
       }
     }
@@ -1111,7 +1113,7 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     DS_HIP(hipMalloc(&clk, (size_t)nrow * 8 * sizeof(unsigned long long)));
     LayerFwdArgs b = a;
     b.phase_clk = clk;
-    hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, b, L);
+    hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, b, L);
     DS_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<unsigned long long> h((size_t)nrow * 8);
     DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1124,9 +1126,14 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
             ph[5] / nrow, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / nrow);
     return DSDGP_OK;
   }
-  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
+}
+template <int MPB, int NW, int KIND, bool WHITE, bool WIDE>
+static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
+  if (a.lik_Y) return fwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, true>(ctx, a);
+  return fwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, false>(ctx, a);
 }
 // DSDGP_BWD_TIMING=1 (debug aid, synchronous): per-phase shader clocks of every backward-chain launch, averaged over its workgroups
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>

@@ -139,6 +139,9 @@ struct dsdgp_model {
   bool tail_ok = false;         // non-white, every D_in <= WIDE_DIN: gradient assembly in k_asm_rows + k_tail (one wave per inducing row)
   struct { int on; double lr_t, b1, b2, eps; } fuse_adam = {0, 0, 0, 0, 0};   // dsdgp_model_train_step: Adam applied inside k_tail
   int mp_max_all = 0, m_max_all = 0;
+  // data-parallel buckets (dsdgp_model_set_bucket_callback): one per layer in reverse order, then the likelihood / result scalars
+  dsdgp_bucket_fn bucket_fn = nullptr;
+  void* bucket_user = nullptr;
   double *Xmb = nullptr, *Ymb = nullptr;   // gathered minibatch of dsdgp_model_train_step_minibatch (n_max x D_in of layer 0 / x DY)
   bool head_ok = false;         // every layer has Mp <= 128 and D_in <= 16: parameter transforms, Ku, its factorisation and inverse
                                 // factor (and the inner layers' N(0,1) draws) in ONE launch (k_head, head_impl.hpp)
@@ -1218,6 +1221,7 @@ __device__ __forceinline__ void adam_one(const AdamArgs& A, int64_t i, double g)
 }
 struct FinArgs {
   const double* part; int nblocks; double w, kl_weight; const double* lik_const; int64_t off_lik; double* out; int L;
+  int do_fin;      // 0: no ELBO-value block in this launch (per-layer launches of the bucketed data-parallel tail)
 };
 // blocks 0 .. La-1: kernel hyper-parameter gradients of layer first + b from the row partials (asm_hyp_final);
 // block La: ELBO value + likelihood-variance gradient (k_finalize's job);  blocks > La (only with A.on): Adam on every entry those
@@ -1242,7 +1246,8 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
     }
     return;
   }
-  if (b == La) {
+  const int nf = F.do_fin ? 1 : 0;
+  if (b == La && nf) {
     double a = 0.0, c = 0.0;
     for (int i = threadIdx.x; i < F.nblocks; i += 256) {
       a += F.part[2 * i];
@@ -1268,8 +1273,8 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
     }
     return;
   }
-  const int64_t nth = (int64_t)(gridDim.x - La - 1) * 256;
-  for (int64_t i = (int64_t)(b - La - 1) * 256 + threadIdx.x; i < A.n; i += nth)
+  const int64_t nth = (int64_t)(gridDim.x - La - nf) * 256;
+  for (int64_t i = (int64_t)(b - La - nf) * 256 + threadIdx.x; i < A.n; i += nth)
     if (A.mask[i] == 1.0) adam_one(A, i, grad[i]);
 }
 
@@ -1941,12 +1946,33 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
   const bool early = overlap && m->force.early_wgrad != 0;
-  const bool pipelined = overlap && m->force.pipe_tail != 0 && !m->desc.white;
+  // data-parallel buckets: every layer's reduction, products, assembly and hyper-parameter gradients right behind its weight-gradient
+  // products, then the caller's collective on that layer's segment of the gradient, on the stream the segment was produced on — the
+  // exchange of the upper layers runs under the lower layers' backward chains (dsdgp_model_set_bucket_callback)
+  const bool bucketed = m->bucket_fn != nullptr && m->tail_ok && gfirst == 0 && !m->fuse_adam.on;
+  const bool pipelined = bucketed || (overlap && m->force.pipe_tail != 0 && !m->desc.white);
   // split-K reduction + P_d T_d / GS_d products of one layer right behind its weight-gradient products (pipelined tail)
   auto layer_tail = [&](LayerState& St, hipStream_t st) -> int {
     hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
     DS_HIP(hipGetLastError());
-    return gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st);
+    DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st));
+    if (bucketed) {
+      const int l = (int)(&St - m->L);
+      const LayerDev* lay1 = m->layers_dev + l;
+      hipLaunchKernelGGL(k_asm_rows, dim3(St.dev.M, 1), dim3(256), (size_t)m->mp_max_all * sizeof(double), st, lay1, m->grad, kl_weight,
+                         m->mp_max_all);
+      FinArgs F{};
+      AdamArgs A{};
+      hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, st, m->layers_dev, l, 1, m->grad, F, A);
+      DS_HIP(hipGetLastError());
+      // this layer's parameters are one contiguous segment of theta: [off_Z, next layer's off_Z) (the last layer's ends where the
+      // likelihood variance or the vector ends)
+      const int64_t lo = St.d.off_Z;
+      const int64_t hi = (l + 1 < L) ? m->L[l + 1].d.off_Z
+                                     : (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta);
+      m->bucket_fn(m->bucket_user, l, m->grad + lo, hi - lo, (void*)st);
+    }
+    return DSDGP_OK;
   };
   bool a_done[DSDGP_MAX_LAYERS] = {false};
   // which: 1 = A jobs, 2 = B jobs, 3 = all
@@ -2065,11 +2091,26 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   // the assembly of the layers that took part (their gradient entries; those of the layers below gfirst keep their old content)
   const LayerDev* lay = m->layers_dev + gfirst;
   const int La = L - gfirst;
+  if (bucketed) {
+    // last bucket: likelihood-variance gradient and the four result scalars (contiguous behind the layers' segments when `out`
+    // is grad + n_theta, as the contract of dsdgp_allreduce asks)
+    FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
+              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
+    AdamArgs A{};
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, 0, 0, m->grad, F, A);
+    DS_HIP(hipGetLastError());
+    m->fin.done = true;
+    const int64_t lo = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta;
+    const bool tail_scalars = m->fin.out == m->grad + m->desc.n_theta;
+    m->bucket_fn(m->bucket_user, L, m->grad + lo, (m->desc.n_theta - lo) + (tail_scalars ? 4 : 0), (void*)ctx->stream);
+    if (!tail_scalars) m->bucket_fn(m->bucket_user, L + 1, m->fin.out, 4, (void*)ctx->stream);
+    return DSDGP_OK;
+  }
   if (m->tail_ok) {
     hipLaunchKernelGGL(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
                        kl_weight, m->mp_max_all);
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
-              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L};
+              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
                m->fuse_adam.eps, (m->fuse_adam.on && gfirst == 0) ? 1 : 0};
     const int nadam = A.on ? (int)std::min<int64_t>(512, ceil_div(m->desc.n_theta, 256)) : 0;
@@ -2270,6 +2311,13 @@ extern "C" int dsdgp_model_train_step_minibatch(dsdgp_model* m, const double* X_
   DS_CHECK_ARG(X_all && Y_all && idx && idx_offset >= 0);
   const GatherSrc gs{X_all, Y_all, idx + idx_offset};
   return train_step_impl(m, nullptr, nullptr, n, S, nullptr, nullptr, seed, data_scale, kl_weight, lr, beta1, beta2, eps, t, out, &gs);
+}
+
+extern "C" int dsdgp_model_set_bucket_callback(dsdgp_model* m, dsdgp_bucket_fn fn, void* user) {
+  DS_CHECK_ARG(m != nullptr);
+  m->bucket_fn = fn;
+  m->bucket_user = user;
+  return DSDGP_OK;
 }
 
 extern "C" int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first) {

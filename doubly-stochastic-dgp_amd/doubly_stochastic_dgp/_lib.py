@@ -88,6 +88,7 @@ _PROTOS = {
     "dsdgp_model_train_step_minibatch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                                    C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                                    C.c_int64, C.c_void_p]),
+    "dsdgp_model_set_bucket_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsdgp_model_set_sample_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "dsdgp_model_natgrad_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int)]),
     "dsdgp_model_layer_kl": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -116,6 +117,8 @@ _PROTOS = {
     "dsdgp_model_theta_changed": (C.c_int, [C.c_void_p]),
     "dsdgp_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
 }
+
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 

@@ -193,6 +193,10 @@ class DGP_Base(Parameterized):
         n_local = X.shape[0]
         rank, world, allreduce = self._dist if self._dist else (0, 1, None)
         scale, klw = shard_terms(self.num_data, n_local, world)                 # dgp.py:96-97
+        hook = getattr(self, "_dist_before_elbo", None)
+        if hook is not None and allreduce is not None:
+            eng._ensure(n_local, self.num_samples)
+            hook(eng)
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
                        kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer)
         if allreduce is not None:
@@ -230,6 +234,10 @@ class DGP_Base(Parameterized):
                            beta2=beta2, eps=eps)
             out = None
         else:
+            hook = getattr(self, "_dist_before_elbo", None)
+            if hook is not None:
+                eng._ensure(n_local, self.num_samples)
+                hook(eng)
             out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
                            kl_weight=klw, with_grad=True, sync=False)
             out = allreduce(eng, True, sync=sync)

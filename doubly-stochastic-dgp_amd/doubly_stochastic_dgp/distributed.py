@@ -33,15 +33,68 @@ def allreduce_flat(buf, world):
     return buf
 
 
-def attach(model, rank, world):
+class _Buckets:
+    """Per-layer gradient buckets (dsdgp_model_set_bucket_callback): the library calls `self._cb` from inside dsdgp_model_elbo as soon
+    as a bucket's producers are enqueued; the all-reduce of that segment goes out at once, on the producing stream, and runs under
+    the backward chains of the layers below.  `finish()` makes the engine's stream wait for every collective before the Adam step."""
+
+    def __init__(self, eng, world):
+        from . import _lib
+        self.eng, self.world, self.works, self.count = eng, world, [], 0
+        self._cb = _lib.BUCKET_FN(self._on_bucket)          # keep the ctypes thunk alive as long as the model
+
+    def install(self):
+        import ctypes as C
+        from . import _lib
+        _lib.check(self.eng.lib.dsdgp_model_set_bucket_callback(self.eng.model, C.cast(self._cb, C.c_void_p), None))
+        self._model = self.eng.model.value
+
+    def _on_bucket(self, user, bucket, ptr, count, stream):
+        import torch
+        import torch.distributed as dist
+        eng = self.eng
+        off = (ptr - eng.gradbuf.data_ptr()) // 8
+        if 0 <= off and off + count <= eng.gradbuf.numel():
+            view = eng.gradbuf[off:off + count]
+        else:                                           # (result scalars outside the gradient buffer: not the engine's layout)
+            raise RuntimeError("bucket outside Engine.gradbuf")
+        self.count += 1
+        ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+        if dist.get_backend() == "gloo":
+            # test rig (two processes on one GPU, no RCCL peer): stage through the host, synchronously
+            ext.synchronize()
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            view.copy_(host)
+            return
+        with torch.cuda.stream(ext):
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()                                    # the current (engine) stream waits for the collective's stream
+        self.works = []
+
+
+def attach(model, rank, world, bucketed=None):
     """Make `model` (DGP_Base) a data-parallel replica: rank-specific minibatch stream and Philox stream, gradient
-    all-reduce before the Adam step.  Requires torch.distributed to be initialised (backend 'nccl' == RCCL on ROCm)."""
+    all-reduce before the Adam step.  Requires torch.distributed to be initialised (backend 'nccl' == RCCL on ROCm).
+    bucketed (default: on for world > 1 where the library supports it): one all-reduce per layer, issued from inside the reverse pass
+    on the stream that produced the layer's gradient — it overlaps the lower layers' backward chains — instead of one flat
+    all-reduce after the pass."""
     from .dgp import Minibatch
     if model.minibatch_size:
         model._minibatch = Minibatch(model.X_data.shape[0], model.minibatch_size, seed=rank)
+    state = {"buckets": None, "model": None}
+    want_buckets = (world > 1) if bucketed is None else bool(bucketed)
 
     def allreduce(eng, with_grad, sync=True):
-        allreduce_flat(eng.gradbuf, world)
+        b = state["buckets"]
+        if b is not None and with_grad and b.count > 0:
+            b.finish()                                  # the reverse pass already exchanged every bucket
+            b.count = 0
+        else:
+            allreduce_flat(eng.gradbuf, world)
         if not sync:
             return None
         eng.ctx.sync()
@@ -49,5 +102,17 @@ def attach(model, rank, world):
         out[3] /= world          # every rank factorises the same Kuu: the summed info is world x the failing pivot index
         return out
 
+    def before_elbo(eng):
+        """(re)install the callback on the engine's current device model (a model re-creation drops it)"""
+        if not want_buckets:
+            return
+        b = state["buckets"]
+        if b is None or b.eng is not eng or getattr(b, "_model", None) != eng.model.value:
+            b = _Buckets(eng, world)
+            b.install()
+            state["buckets"] = b
+        b.count = 0
+
     object.__setattr__(model, "_dist", (rank, world, allreduce))
+    object.__setattr__(model, "_dist_before_elbo", before_elbo)
     return model

@@ -237,6 +237,18 @@ int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const double* var, 
 /* N(0,1) float64 draws (Philox4x32-10 + Box–Muller), replaces tf.random_normal (layers.py:101-102). */
 int dsdgp_randn(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out);
 
+/* Bucketed exchange of the row-sharded ELBO's gradient.  With a callback set, dsdgp_model_elbo(with_grad = 1) finishes
+ * every layer's gradient right behind that layer's weight-gradient products — reduction, products, assembly, hyper-parameter sums —
+ * and calls `fn(user, bucket, ptr, count, stream)` on the calling host thread as soon as the kernels that produce the bucket are
+ * ENQUEUED: bucket = L-1, L-2, ..., 0 (layer l's contiguous segment of `grad`), then bucket = L (likelihood-variance entry + the four
+ * result scalars when `out` = grad + n_theta; else the entry, then bucket L+1 = the scalars).  `stream` is the HIP stream the segment is
+ * produced on: a collective enqueued there (ncclAllReduce(ptr, ptr, count, ncclDouble, ncclSum, comm, stream), or a torch.distributed
+ * call under torch.cuda.ExternalStream(stream)) is ordered behind its producers and runs UNDER the backward chains of the layers
+ * below.  The caller makes its optimiser step wait for the collectives it issued.  fn = NULL restores the single flat buffer
+ * (one dsdgp_allreduce).  Ignored for white=True / wide-input models and while dsdgp_model_set_grad_first_layer restricts the pass. */
+typedef void (*dsdgp_bucket_fn)(void* user, int32_t bucket, double* ptr, int64_t count, void* stream);
+int dsdgp_model_set_bucket_callback(dsdgp_model* m, dsdgp_bucket_fn fn, void* user);
+
 /* Multi-GPU exchange step of the row-sharded ELBO (the step being sharded is dgp.py:92-98): in-place SUM of
  * `count` doubles of `buf` over the ranks of `comm` on the ctx stream — ONE call per training step on the flat
  * [gradient (n_theta) | elbo, data term, kl_weight * KL, potrf_info] buffer (`grad` of dsdgp_model_create with `out` of

@@ -30,7 +30,7 @@ def _model(X, Y, Z, S, D):
     return make_case(X, Y, Z, [kern_spec("rbf", D, 1.1, 0.9), kern_spec("matern52", D, 0.8, 1.2)], S=S, num_data=5000, seed=1)[2]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, bucketed=False):
     import torch
     import torch.distributed as dist
     from doubly_stochastic_dgp.distributed import attach
@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_path):
     n_local = X.shape[0] // world
     sl = slice(rank * n_local, (rank + 1) * n_local)
     model = _model(X, Y, Z, S, D)
-    attach(model, rank, world)
+    attach(model, rank, world, bucketed=bucketed)
     zl = [z[:, sl, :] for z in zs]
     elbo = model._build_likelihood(X[sl], Y[sl], zs=zl, with_grad=True)       # all-reduced value: the GLOBAL elbo
     out = model.engine().out4.cpu().numpy().copy()
@@ -50,25 +50,41 @@ def _worker(rank, world, port, out_path):
         model.train_step(0.01, X=X[sl], Y=Y[sl], zs=zl)
     last = model.train_step(0.01, X=X[sl], Y=Y[sl], zs=zl, sync=True)
     if rank == 0:
+        eng = model.engine()
+        eng.ctx.sync()
         np.savez(out_path, elbo=elbo, out=out, last=last, q_mu0=model.layers[0].q_mu.value, q_sqrt1=model.layers[1].q_sqrt.value,
-                 Z0=model.layers[0].feature.Z.value, lik=model.likelihood.likelihood.variance.value)
+                 Z0=model.layers[0].feature.Z.value, lik=model.likelihood.likelihood.variance.value,
+                 theta=eng.theta.cpu().numpy(), grad=eng.gradbuf.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_ranks_equal_single_process(tmp_path):
+def _run_two_ranks(tmp_path, bucketed):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    out_path = str(tmp_path / "rank0.npz")
+    out_path = str(tmp_path / f"rank0_{int(bucketed)}.npz")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "doubly-stochastic-dgp_amd")]))
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), out_path], env=env, cwd=ROOT)
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), out_path, str(int(bucketed))], env=env,
+                              cwd=ROOT) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=500) == 0
-    got = np.load(out_path)
+    return np.load(out_path)
+
+
+@pytest.mark.timeout(900)
+def test_bucketed_exchange_equals_flat_exchange_bitwise(tmp_path):
+    """One all-reduce per layer issued from inside the reverse pass (dsdgp_model_set_bucket_callback) against the single flat
+    all-reduce after it: identical parameters, gradient buffer and result scalars after four optimiser steps (two ranks: a + b)."""
+    flat, buck = _run_two_ranks(tmp_path, False), _run_two_ranks(tmp_path, True)
+    for k in ("theta", "grad", "out", "elbo", "last"):
+        assert np.array_equal(flat[k], buck[k]), k
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_equal_single_process(tmp_path):
+    got = _run_two_ranks(tmp_path, True)
     X, Y, Z, zs, S, D = _problem()
     ref = _model(X, Y, Z, S, D)
     e = ref._build_likelihood(X, Y, zs=zs, with_grad=True)
@@ -87,4 +103,4 @@ def test_two_ranks_equal_single_process(tmp_path):
 
 
 if __name__ == "__main__":
-    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])) if len(sys.argv) > 5 else False)

@@ -106,7 +106,7 @@ def test_trsm_batched(ctx, trans, n, nrhs, batch, shared):
     got = dB.cpu().numpy()
     for b in range(batch):
         ref = sla.solve_triangular(np.tril(L[0 if shared else b]), B[b], lower=True, trans=trans)
-        assert_allclose(got[b], ref, rtol=1e-10, atol=1e-11)
+        assert_allclose(got[b], ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())      # random L: the solutions grow to 1e4
 
 
 def test_trsm_strided_views(ctx):
