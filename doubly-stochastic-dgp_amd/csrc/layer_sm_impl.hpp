@@ -684,6 +684,10 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   const int d_lo = (int)blockIdx.y * dchunk, d_hi = (d_lo + dchunk < Dout) ? d_lo + dchunk : Dout;
   __shared__ int s_ticket;
   // T: this wave's accumulator tiles, row block of tile q = ib_of(q) (negative: none).  Returns false in the workgroups that are done.
+  // hand-over without fences: the partial tiles go out as 8-byte agent-scope (sc1, write-through) stores and come back as sc1 loads —
+  // valid across XCDs on their own (MI355X_MICROARCH.md, inter-workgroup visibility: "8-B agent atomics both sides").  The
+  // __threadfence() pair of rounds 1-2 wrote back / invalidated a whole L2 per workgroup: +57 us on the 63-row-block first layer
+  // of config 2, which kept the split off below Mp = 512.
   auto merge_split = [&](auto& T, auto ib_of) -> bool {
     if (n_split == 1) return true;
     constexpr int NT = sizeof(T) / sizeof(T[0]);
@@ -694,30 +698,29 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
       const int ib = ib_of(q);
       if (ib < 0) continue;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mine[(16 * ib + g + 4 * t) * 16 + c] = T[q][t];
+      for (int t = 0; t < 4; ++t) __hip_atomic_store(&mine[(16 * ib + g + 4 * t) * 16 + c], T[q][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wave == 0 && g == 0) mine[Mp * 16 + c] = gsum;
-    __threadfence();
+    if (wave == 0 && g == 0) __hip_atomic_store(&mine[Mp * 16 + c], gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores have left before the ticket is drawn
     __syncthreads();
-    if (tid == 0) s_ticket = atomicAdd(a.part_cnt + blockIdx.x, 1);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.part_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != n_split - 1) return false;
-    if (tid == 0) a.part_cnt[blockIdx.x] = 0;          // every split has arrived: ready for the next launch
-    __threadfence();
+    if (tid == 0) __hip_atomic_store(a.part_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has arrived: ready for the next launch
     const double* base = a.part + (int64_t)blockIdx.x * n_split * pstride;
 #pragma unroll
     for (int q = 0; q < NT; ++q) T[q] = (d4){0, 0, 0, 0};
     gsum = 0.0;
-    for (int y = 0; y < n_split; ++y) {
-      const double* __restrict__ p = base + y * pstride;
+    for (int y = 0; y < n_split; ++y) {                    // fixed order: the sum does not depend on which workgroup arrives last
+      const double* p = base + y * pstride;
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
         const int ib = ib_of(q);
         if (ib < 0) continue;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) T[q][t] += p[(16 * ib + g + 4 * t) * 16 + c];
+        for (int t = 0; t < 4; ++t) T[q][t] += __hip_atomic_load(&p[(16 * ib + g + 4 * t) * 16 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      gsum += p[Mp * 16 + c];
+      gsum += __hip_atomic_load(&p[Mp * 16 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return true;
   };

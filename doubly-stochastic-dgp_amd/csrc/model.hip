@@ -814,8 +814,48 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     if (threadIdx.x == 0) J.out[i] = s;
     return;
   }
-  const bool four = J.ways == 4;
   const int rwave = threadIdx.x >> 6;
+  if (J.ways == 8) {
+    // the 4-way form with TWO adjacent outputs per lane: 16-byte loads (8-byte lanes moved ~2 TB/s of the ~50 MB of partials that
+    // config 2 reduces per step).  Same summation order per output as ways = 4: the result is bit-identical.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ d2 sh2[4][64];
+    const int lane = threadIdx.x & 63;
+    const int64_t i0 = (int64_t)(bx - J.blk_start) * 128 + 2 * lane;
+    const bool live = i0 < J.count;
+    int64_t i = live ? i0 : 0, o = i, ostep = 1;
+    if (live && J.out_ld > 0) {
+      const int64_t r = i0 / J.out_ld, cc = i0 % J.out_ld;
+      i = r * J.in_ld + cc;
+      if (J.sym_n > 0) {
+        const int64_t ti = r / J.sym_tile, tj = cc / J.sym_tile;
+        if (tj > ti) {                       // see the scalar form below: read the lower tile's local element, store transposed
+          const int64_t lr = r % J.sym_tile, lc = cc % J.sym_tile;
+          i = (tj * J.sym_tile + lr) * J.in_ld + ti * J.sym_tile + lc;
+          o = (ti * J.sym_tile + lc) * J.out_ld + tj * J.sym_tile + lr;
+          ostep = J.out_ld;
+        }
+      }
+    }
+    d2 s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = (d2){0, 0};
+    int sp = rwave;
+    for (; sp + 28 < J.nsplit; sp += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += *reinterpret_cast<const d2*>(J.part + (int64_t)(sp + u * 4) * J.pstride + i);
+    }
+    for (; sp < J.nsplit; sp += 4) s[0] += *reinterpret_cast<const d2*>(J.part + (int64_t)sp * J.pstride + i);
+    sh2[rwave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (rwave == 0 && live) {
+      const d2 t = (sh2[0][lane] + sh2[1][lane]) + (sh2[2][lane] + sh2[3][lane]);
+      J.out[o] = t[0];
+      J.out[o + ostep] = t[1];
+    }
+    return;
+  }
+  const bool four = J.ways == 4;
   const int64_t i0 = four ? (int64_t)(bx - J.blk_start) * 64 + (threadIdx.x & 63) : (int64_t)(bx - J.blk_start) * 256 + threadIdx.x;
   if (!four && i0 >= J.count) return;
   const bool live = i0 < J.count;
@@ -1898,8 +1938,11 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
   int blocks = 0;
   for (auto& r : red) {
     r.ways = (!r.wide && r.nsplit >= 12) ? 4 : 0;
+    const bool even = r.count % 2 == 0 && r.pstride % 2 == 0 && r.in_ld % 2 == 0 && r.out_ld % 2 == 0 && r.sym_tile % 2 == 0 &&
+                      ((uintptr_t)r.part & 15) == 0;
+    if (r.ways == 4 && even) r.ways = 8;
     r.blk_start = blocks;
-    blocks += r.wide ? (int)r.count : ceil_div(r.count, r.ways == 4 ? 64 : 256);
+    blocks += r.wide ? (int)r.count : ceil_div(r.count, r.ways == 8 ? 128 : (r.ways == 4 ? 64 : 256));
   }
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
@@ -2026,9 +2069,11 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       b.up_var = St.var; b.up_jitter = m->desc.jitter; b.MBw = St.MB; b.VBw = St.VB;
     }
     {   // few row blocks (the N-row first layer, small shards): spread the d-loop over up to four workgroups per row block.
-        // Only from Mp = 512 (bwd_split = 2 forces it everywhere, 0 disables): the hand-over needs two device-scope fences
-        // per workgroup, which on this multi-XCD part write back / invalidate a whole L2 — measured +57 us on the 63-row-block
-        // first layer of config 2 (M = 128) against -0.9 ms on the 32-row-block, 30-output first layer of config 4 (M = 512)
+        // Only from Mp = 512 (bwd_split = 2 forces it everywhere, 0 disables): every workgroup of a split repeats the chain's prologue
+        // and epilogue phases.  63-row-block first layer of config 2 (M = 128): +57 us with the __threadfence() hand-over of
+        // round 2, still +6 us per step with the fence-free sc1 hand-over of round 3 (cutting the upper layer's weight-gradient
+        // task list over both streams to use the shortened chain: +10..+20 us); -0.9 ms on the 32-row-block, 30-output first
+        // layer of config 4 (M = 512)
       const int64_t nblk = ld / 16;
       const bool want = m->force.bwd_split >= 2 || (m->force.bwd_split == 1 && v.Mp > 256);
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
