@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "doubly-stochastic-dgp_amd")):
 
 from oracle import dgp_oracle as O  # noqa: E402
 from oracle import model as OM  # noqa: E402
-from tests.golden import cases  # noqa: E402
+from tests.golden import cases, extras  # noqa: E402
 
 
 def outputs(name):
@@ -36,6 +36,7 @@ def outputs(name):
         else:                     # large q_sqrt gradients: Frobenius norm + leading 16x16 block of every output
             out["gradnorm." + k] = np.array(np.linalg.norm(v))
             out["gradblock." + k] = v[:, :16, :16].copy()
+    out.update(extras.oracle_extras(spec, state, X, Y, zs, c))      # predict_y / density, full_cov, 3 Adam steps, natgrad step
     return out
 
 

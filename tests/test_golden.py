@@ -7,7 +7,7 @@ import pytest
 from numpy.testing import assert_allclose
 
 from oracle import model as OM
-from tests.golden import cases
+from tests.golden import cases, extras
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -54,3 +54,66 @@ def test_hip_reproduces_golden(name):
             assert_allclose(np.linalg.norm(grads[k]), g[key], rtol=gtol)
             ref = -g["gradblock." + k]
             assert np.max(np.abs(grads[k][:, :16, :16] - ref)) <= gtol * (np.max(np.abs(ref)) + 1e-12), k
+
+
+# ---------------------------------------------------------------- the wider set (tests/golden/extras.py): predict_y / density, full_cov,
+# three Adam steps, one natural-gradient step
+@pytest.mark.parametrize("name", ["svgp_matern52", "two_layer_1d", "ard_white_sum", "multiclass", "bernoulli"])
+def test_oracle_reproduces_golden_extras(name):
+    g = _load(name)
+    spec, state, _, X, Y, zs, c = cases.build(name)
+    got = extras.oracle_extras(spec, state, X, Y, zs, c)
+    assert sorted(k for k in g.files if k.startswith("x.")) == sorted(got)
+    for k, v in got.items():
+        assert_allclose(v, g[k], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+def test_every_fixture_holds_the_extras():
+    for name in cases.CASES:
+        g = _load(name)
+        need = {"x.predy_mean", "x.predy_var", "x.preddens", "x.fc_Fmean", "x.fc_Fvar", "x.adam3_elbo", "x.adam3_q_mu"}
+        assert need <= set(g.files), name
+        if extras._is_gaussian(cases.CASES[name]):
+            assert "x.ng_q_mu" in g.files and ("x.ng_q_sqrt" in g.files or "x.ng_q_sqrt_norm" in g.files), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_hip_reproduces_golden_extras(name):
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    g = _load(name)
+    spec, state, model, X, Y, zs, c = cases.build(name)
+    S, L = c["S"], c["L"]
+    tol = 1e-6 if c.get("demo_scale") else 1e-8
+
+    def close(a, key, t=tol):
+        ref = g[key]
+        assert np.max(np.abs(np.asarray(a) - ref)) <= t * (np.max(np.abs(ref)) + 1e-12), key
+
+    Fmean, Fvar = model._build_predict(X, S=S, zs=zs)
+    pm, pv = model.likelihood.predict_mean_and_var(Fmean, Fvar)                       # dgp.py:117-119
+    close(pm, "x.predy_mean"); close(pv, "x.predy_var")
+    dens = model.likelihood.predict_density_logmeanexp(Fmean, Fvar, np.asarray(Y, dtype=np.float64))   # dgp.py:121-126
+    close(dens, "x.preddens")
+    _, Fmc, Fvc = model.propagate(X, full_cov=True, S=S, zs=zs)                        # dgp.py:113-114
+    close(Fmc[-1], "x.fc_Fmean", 10 * tol); close(Fvc[-1], "x.fc_Fvar", 10 * tol)
+    if extras._is_gaussian(c):                                                        # one natural-gradient step, gamma = 0.1
+        last = model.layers[-1]
+        NatGradOptimizer(extras.NG_GAMMA).minimize(model, var_list=[(last.q_mu, last.q_sqrt)], maxiter=1, X=X, Y=Y, zs=zs)
+        model.engine().sync_to_host()
+        ngt = 1e-4 if c.get("demo_scale") else 1e-6
+        close(last.q_mu.value, "x.ng_q_mu", ngt)
+        sq = np.asarray(last.q_sqrt.value)
+        if "x.ng_q_sqrt" in g.files:
+            close(sq, "x.ng_q_sqrt", ngt)
+        else:
+            assert_allclose(np.linalg.norm(sq), g["x.ng_q_sqrt_norm"], rtol=ngt)
+            close(sq[:, :16, :16], "x.ng_q_sqrt_block", ngt)
+    # three Adam(0.01) steps on -ELBO with the same draws (a fresh model: the natural-gradient step above moved the last layer)
+    spec, state, model, X, Y, zs, c = cases.build(name)
+    for _ in range(extras.ADAM_STEPS):
+        model.train_step(extras.ADAM_LR, X=X, Y=Y, zs=zs)
+    elbo = model._build_likelihood(X, Y, zs=zs)
+    assert_allclose(elbo, g["x.adam3_elbo"], rtol=1e-5 if c.get("demo_scale") else 1e-7)
+    model.engine().sync_to_host()
+    close(model.layers[-1].q_mu.value, "x.adam3_q_mu", 1e-5 if c.get("demo_scale") else 1e-6)
