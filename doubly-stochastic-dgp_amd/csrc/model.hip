@@ -416,11 +416,27 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
     v.Zp[idx] = z;
     v.Zs[idx] = z / (softplus_d(rl) + SOFTPLUS_LOWER);
   }
-  for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
-    const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
-    const double t = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
-    v.Tp[idx] = t;
-    if (v.need_tpt) v.TpT[((int64_t)d * Mp + j) * Mp + i] = t;   // same (coalesced) read; the strided side is the store
+  if (v.need_tpt) {
+    // padded factor and its transpose, 16 x 16 tiles through LDS: both stores run along rows (the element-wise form stored the
+    // transpose with stride Mp — 8 M scattered 8-byte stores per layer at M = 1024, D_out = 8: most of this launch's 195 us)
+    __shared__ double tt[16][17];
+    const int nt = Mp / 16, ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    for (int tile = bx; tile < v.D_out * nt * nt; tile += nprep) {
+      const int d = tile / (nt * nt), rem = tile % (nt * nt), i0 = (rem / nt) * 16, j0 = (rem % nt) * 16;
+      const int i = i0 + ti, j = j0 + tj;
+      const bool on = threadIdx.x < 256;          // (the head launch runs this body with 512 threads per block)
+      const double t = (on && i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+      if (on) v.Tp[((int64_t)d * Mp + i) * Mp + j] = t;
+      __syncthreads();
+      if (on) tt[ti][tj] = t;
+      __syncthreads();
+      if (on) v.TpT[((int64_t)d * Mp + j0 + ti) * Mp + i0 + tj] = tt[tj][ti];
+    }
+  } else {
+    for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
+      const int d = idx / (Mp * Mp), rem = idx % (Mp * Mp), i = rem / Mp, j = rem % Mp;
+      v.Tp[idx] = (i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+    }
   }
   for (int idx = tid0; idx < Mp * v.D_out; idx += nth)
     v.qmu[idx] = (idx / v.D_out < M) ? theta[v.off_q_mu + idx] : 0.0;
@@ -815,6 +831,48 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     return;
   }
   const int rwave = threadIdx.x >> 6;
+  if (J.ways == 16) {
+    // symmetric result, one 16 x 16 tile on or below the diagonal per workgroup: each wave sums a quarter of the splits for the whole
+    // tile (lane = (row g + 4 e, column c): 128-byte row segments), the four partial tiles meet in LDS, and the tile goes out twice —
+    // as it is and transposed to its mirror position — BOTH along rows.  (The element-wise form stored the mirror with stride
+    // out_ld: 64 cache lines per store instruction for ~47 % of the outputs.)
+    __shared__ double tl[4][16][17];
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    int t = bx - J.blk_start, ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const double* __restrict__ src = J.part + (int64_t)(16 * ti + g) * J.in_ld + 16 * tj + c;
+    const int64_t estep = (int64_t)4 * J.in_ld;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    int sp = rwave;
+    for (; sp + 4 < J.nsplit; sp += 8) {          // two splits = eight loads in flight
+      const double* __restrict__ p0 = src + (int64_t)sp * J.pstride;
+      const double* __restrict__ p1 = p0 + (int64_t)4 * J.pstride;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] += p0[e * estep];
+        s1[e] += p1[e * estep];
+      }
+    }
+    if (sp < J.nsplit) {
+      const double* __restrict__ p0 = src + (int64_t)sp * J.pstride;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s0[e] += p0[e * estep];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tl[rwave][g + 4 * e][c] = s0[e] + s1[e];
+    __syncthreads();
+    const int r = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    const double v = (tl[0][r][cc] + tl[1][r][cc]) + (tl[2][r][cc] + tl[3][r][cc]);
+    J.out[(int64_t)(16 * ti + r) * J.out_ld + 16 * tj + cc] = v;
+    if (ti != tj) {
+      __syncthreads();
+      tl[0][r][cc] = v;
+      __syncthreads();
+      J.out[(int64_t)(16 * tj + r) * J.out_ld + 16 * ti + cc] = tl[0][cc][r];
+    }
+    return;
+  }
   if (J.ways == 8) {
     // the 4-way form with TWO adjacent outputs per lane: 16-byte loads (8-byte lanes moved ~2 TB/s of the ~50 MB of partials that
     // config 2 reduces per step).  Same summation order per output as ways = 4: the result is bit-identical.
@@ -1941,8 +1999,12 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const bool even = r.count % 2 == 0 && r.pstride % 2 == 0 && r.in_ld % 2 == 0 && r.out_ld % 2 == 0 && r.sym_tile % 2 == 0 &&
                       ((uintptr_t)r.part & 15) == 0;
     if (r.ways == 4 && even) r.ways = 8;
+    const int64_t rows = r.out_ld > 0 ? r.count / r.out_ld : 0;
+    const bool tiled = !r.wide && r.sym_n > 0 && r.sym_tile == 16 && r.out_ld > 0 && rows == r.out_ld && rows % 16 == 0;
+    if (tiled) r.ways = 16;
     r.blk_start = blocks;
-    blocks += r.wide ? (int)r.count : ceil_div(r.count, r.ways == 8 ? 128 : (r.ways == 4 ? 64 : 256));
+    blocks += r.wide ? (int)r.count
+                     : (tiled ? (int)((rows / 16) * (rows / 16 + 1) / 2) : ceil_div(r.count, r.ways == 8 ? 128 : (r.ways == 4 ? 64 : 256)));
   }
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
@@ -2468,32 +2530,37 @@ __global__ void k_ng_assemble(const LayerDev* __restrict__ layers, int l, double
     v.ngA[idx] = a;
   }
 }
-__global__ void k_ng_theta1(const LayerDev* __restrict__ layers, int l, const double* __restrict__ grad, double gamma) {
+// matrix-vector products of the natural-gradient step: ONE WAVE PER ROW (the lanes walk the row: coalesced; a thread per row read
+// M strided doubles one after the other — 275 us / 159 us at M = 1024).  blocks of 256 threads = 4 rows.
+__global__ __launch_bounds__(256) void k_ng_theta1(const LayerDev* __restrict__ layers, int l, const double* __restrict__ grad, double gamma) {
   const LayerDev v = layers[l];
   const int Mp = v.Mp, M = v.M;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= v.D_out * M) return;
-  const int d = idx / M, i = idx % M;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= v.D_out * M) return;
+  const int d = row / M, i = row % M;
   const double* Sinv = v.ngSinv + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
   const double* Sbar = v.ngY + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
   double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < M; ++j) {
+  for (int j = lane; j < M; j += 64) {
     const double mj = v.qmu[j * v.D_out + d];
     s1 = fma(Sinv[j], mj, s1);
     s2 = fma(Sbar[j], mj, s2);
   }
-  v.ngTheta1[d * Mp + i] = s1 - gamma * (grad[v.off_q_mu + (int64_t)i * v.D_out + d] - 2.0 * s2);
+  s1 = sum_wave(s1);
+  s2 = sum_wave(s2);
+  if (lane == 0) v.ngTheta1[d * Mp + i] = s1 - gamma * (grad[v.off_q_mu + (int64_t)i * v.D_out + d] - 2.0 * s2);
 }
-__global__ void k_ng_mu(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
+__global__ __launch_bounds__(256) void k_ng_mu(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
   const LayerDev v = layers[l];
   const int Mp = v.Mp, M = v.M;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= v.D_out * M) return;
-  const int d = idx / M, i = idx % M;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= v.D_out * M) return;
+  const int d = row / M, i = row % M;
   const double* Sp = v.ngSplus + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
   double s = 0.0;
-  for (int j = 0; j < M; ++j) s = fma(Sp[j], v.ngTheta1[d * Mp + j], s);
-  theta[v.off_q_mu + (int64_t)i * v.D_out + d] = s;
+  for (int j = lane; j < M; j += 64) s = fma(Sp[j], v.ngTheta1[d * Mp + j], s);
+  s = sum_wave(s);
+  if (lane == 0) theta[v.off_q_mu + (int64_t)i * v.D_out + d] = s;
 }
 __global__ void k_ng_write(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
   const LayerDev v = layers[l];
@@ -2523,13 +2590,13 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   DS_TRY(gemm_launch(ctx, St.ng_gp + 2, 1, St.ng_t2));
   DS_TRY(gemm_launch(ctx, St.ng_gp + 3, 1, St.ng_t3));
   hipLaunchKernelGGL(k_ng_assemble, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, gamma);
-  hipLaunchKernelGGL(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
+  hipLaunchKernelGGL(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
                      gamma);
   DS_HIP(hipGetLastError());
   if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngA));
   else DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
   DS_TRY(gemm_launch(ctx, St.ng_gp + 4, 1, St.ng_t4));
-  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 256)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
+  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
   if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngS));
   else DS_TRY(potrf_launch(ctx, St.ng_items + v.D_out, v.D_out, v.Mp));

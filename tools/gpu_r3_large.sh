@@ -1,12 +1,11 @@
 #!/bin/bash
-# per-kernel event times of the large-M config shapes (cfg 4: M = 512, cfg 5: M = 1024 + natgrad) + rocprof kernel stats of cfg 5
+# rocprof kernel stats of the large-M config shapes (cfg 4: M = 512, cfg 5: M = 1024 + natgrad), serial schedule
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r3large; mkdir -p $O; export TMPDIR=/tmp; rm -f $O/ab.log
-for c in 4 5; do timeout 300 python tools/ab_kernels.py $c 2>&1 | grep "^{" >> $O/ab.log; done
-for c in 4 5; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/../../$O/prof$c -o p -- python $GRAFT_REPO_ROOT/tools/ab_kernels.py $c > /dev/null 2>&1)
-  f=$(find $O/prof$c -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && head -25 "$f" | cut -c1-200 > $O/stats$c.csv
-  rm -rf $O/prof$c
+R=$PWD; O=$R/gpurun_out/r3large; mkdir -p $O; export TMPDIR=/tmp
+for c in ${CFGS:-4 5}; do
+  rm -rf /tmp/prof$c
+  (cd /tmp && DSDGP_NO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$c -o p -- python $R/tools/ab_kernels.py $c > $O/run$c.log 2>&1)
+  DB=$(find /tmp/prof$c -name "*results.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $O/stats$c.md "cfg $c shape, tools/ab_kernels.py under rocprofv3 --kernel-trace --stats, serial schedule" > /dev/null
 done
-cat $O/ab.log
+ls $O
