@@ -62,6 +62,11 @@ struct dsdgp_ctx {
   // GEMM / factorisation descriptors): the copy is enqueued from pinned memory and the call returns — no stream synchronisation
   char* pin = nullptr;
   size_t pin_bytes = 0, pin_off = 0;
+  // dsdgp_potrf, n >= 512: the blocked factorisation's plan (descriptor arrays + scratch on the device) of the last call, reused
+  // while matrix order, batch and scratch address repeat (a plan build costs two hipMallocs and a synchronous upload: ~150 us)
+  void* potrf_plan = nullptr;
+  void (*potrf_plan_free)(void*) = nullptr;
+  int64_t potrf_key[4] = {0, 0, 0, 0};
 };
 
 int ctx_scratch(dsdgp_ctx* ctx, size_t bytes, void** out);

@@ -49,6 +49,7 @@ extern "C" int dsdgp_ctx_destroy(dsdgp_ctx* ctx) {
       hipEventDestroy(ev.first);
       hipEventDestroy(ev.second);
     }
+  if (ctx->potrf_plan && ctx->potrf_plan_free) ctx->potrf_plan_free(ctx->potrf_plan);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->side) {

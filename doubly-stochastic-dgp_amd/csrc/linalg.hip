@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "linalg.hpp"
+#include "chol_lds.hpp"
 
 #define GT 64
 #define GK 16
@@ -386,9 +387,9 @@ static bool gemm_small_ok(const GemmProblem& P) {
   return true;
 }
 
-int gemm_plan(GemmProblem* host, int nprob, bool allow_big) {
-  int big = 0, small = nprob > 0;
-  if (allow_big)
+int gemm_plan(GemmProblem* host, int nprob, int allow_big) {
+  int big = allow_big == 2, small = nprob > 0;          // 2: the 128 x 128 kernel whatever the sizes (in-place 128-column panels)
+  if (allow_big == 1)
     for (int i = 0; i < nprob; ++i)
       if (host[i].m >= GEMM_BIG_MIN && host[i].n >= GEMM_BIG_MIN && host[i].k >= 64) big = 1;
   for (int i = 0; i < nprob; ++i) small = small && gemm_small_ok(host[i]);
@@ -803,13 +804,24 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   DS_TRY(ctx_upload(ctx, items_d, items.data(), batch * sizeof(PotrfItem)));   // asynchronous (pinned staging ring)
   hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
   if (np >= 512 && np % 64 == 0) {
-    // large matrices: multi-workgroup blocked path (temporary plan; the model path pre-builds its plans)
-    BigChol plan;
-    int rc = bigchol_build(ctx, plan, P, nullptr, nullptr, scal_d, batch, (int64_t)np * np, 2, np, n, nullptr, false);
-    if (rc == DSDGP_OK) rc = bigchol_run(ctx, plan);
-    hipStreamSynchronize(ctx->stream);
-    bigchol_free(plan);
-    DS_TRY(rc);
+    // large matrices: multi-workgroup blocked path; the plan of the last call is kept in the context (the model path pre-builds its plans)
+    const int64_t key[4] = {(int64_t)(uintptr_t)P, np, batch, n};
+    if (!ctx->potrf_plan || memcmp(key, ctx->potrf_key, sizeof(key)) != 0) {
+      DS_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->potrf_plan) ctx->potrf_plan_free(ctx->potrf_plan);
+      ctx->potrf_plan = nullptr;
+      BigChol* plan = new BigChol();
+      const int rc = bigchol_build(ctx, *plan, P, nullptr, nullptr, scal_d, batch, (int64_t)np * np, 2, np, n, nullptr, false);
+      if (rc != DSDGP_OK) {
+        bigchol_free(*plan);
+        delete plan;
+        return rc;
+      }
+      ctx->potrf_plan = plan;
+      ctx->potrf_plan_free = [](void* p) { bigchol_free(*(BigChol*)p); delete (BigChol*)p; };
+      memcpy(ctx->potrf_key, key, sizeof(key));
+    }
+    DS_TRY(bigchol_run(ctx, *(BigChol*)ctx->potrf_plan));
   } else {
     DS_TRY(potrf_launch(ctx, items_d, batch, np));
   }
@@ -910,11 +922,20 @@ int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride,
 // multi-workgroup blocked Cholesky / triangular inverse (see linalg.hpp)
 // ------------------------------------------------------------------------------------------------------
 // zero the 64x64 blocks strictly above the block diagonal (the blocked factorisation only maintains the lower blocks)
-__global__ void k_zero_upper_blocks(double* __restrict__ W, int n, int64_t stride) {
+// end of the blocked factorisation: the panels parked transposed above the block diagonal (BCB x BCB blocks) go to their places below
+// it and the upper blocks are zeroed.  One 16 x 16 tile per workgroup pass, through LDS: both sides run along rows.  grid (x, batch)
+__global__ __launch_bounds__(256) void k_mirror_panels(double* __restrict__ W, int n, int64_t stride, int bs) {
+  __shared__ double tt[16][17];
   double* Wb = W + (int64_t)blockIdx.y * stride;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / n), j = (int)(idx % n);
-    if ((j >> 6) > (i >> 6)) Wb[idx] = 0.0;
+  const int nt = n / 16, ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  for (int t = blockIdx.x; t < nt * nt; t += gridDim.x) {
+    const int i0 = (t / nt) * 16, j0 = (t % nt) * 16;          // tile of the UPPER part: rows i0.., columns j0..
+    if (j0 / bs <= i0 / bs) continue;                           // (uniform per workgroup)
+    __syncthreads();
+    tt[ti][tj] = Wb[(int64_t)(i0 + ti) * n + j0 + tj];
+    Wb[(int64_t)(i0 + ti) * n + j0 + tj] = 0.0;
+    __syncthreads();
+    Wb[(int64_t)(j0 + ti) * n + i0 + tj] = tt[tj][ti];
   }
 }
 __global__ void k_transpose_lower(const double* __restrict__ X, double* __restrict__ XT, int n, int64_t stride) {
@@ -951,17 +972,76 @@ __global__ __launch_bounds__(256) void k_trtri_diag64(const PotrfItem* __restric
   }
 }
 
+// factor + inverse of ONE diagonal block (n = 128, or 64 at a ragged end) of the blocked factorisation, LDS-resident (chol_lds.hpp):
+// ~25 us for 128 columns where k_potrf_trtri took 23 us for 64.  PotrfItem as for k_potrf_trtri (pad bit 16: accumulate into scal).
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_block(const PotrfItem* __restrict__ items) {
+  extern __shared__ __attribute__((aligned(16))) double chol_dyn[];
+  __shared__ int s_info;
+  const PotrfItem it = items[blockIdx.x];
+  const int n = it.n, ld = n + 5, nb = n >> 4, nreal = it.nreal;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  lptr W = (lptr)chol_dyn;
+  lptr Xd = (lptr)(chol_dyn + n * ld);
+  lptr red = (lptr)(chol_dyn + n * ld + nb * 16 * 17);
+  gptr Wg = (gptr)it.W;
+  if (tid == 0) s_info = 0;
+  // lower block triangle, the 16 x 16 diagonal blocks whole (mirrored from their lower halves); identity beyond the real order
+  // (eight unconditional loads in flight per thread: a guarded element-per-iteration loop walked 32 dependent round trips)
+  for (int u0 = 0; u0 < n * n; u0 += 8 * CHOL_THREADS) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int idx = u0 + u * CHOL_THREADS + tid;
+      idx = idx < n * n ? idx : 0;
+      const int i = idx / n, j = idx - i * n;
+      v[u] = Wg[(j <= i) ? (int64_t)i * it.ld + j : (int64_t)j * it.ld + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u0 + u * CHOL_THREADS + tid;
+      const int i = idx / n, j = idx - i * n;
+      if (idx < n * n && (j >> 4) <= (i >> 4)) W[i * ld + j] = (i < nreal && j < nreal) ? v[u] : ((i == j) ? 1.0 : 0.0);
+    }
+  }
+  __syncthreads();
+  long long tl = 0;
+  lds_chol_inverse<false>(W, Xd, n, ld, (gptr)it.Linv, (gptr) nullptr, (int64_t)it.ld, &s_info, nullptr, tl);
+  if (!(it.pad & 8))
+    for (int idx = tid; idx < n * n; idx += CHOL_THREADS) {
+      const int i = idx / n, j = idx - i * n;
+      Wg[(int64_t)i * it.ld + j] = (j <= i) ? W[i * ld + j] : 0.0;
+    }
+  double s = 0.0;
+  for (int i = tid; i < nreal; i += CHOL_THREADS) s += 2.0 * log(W[i * ld + i]);
+  s = sum_wave(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0 && it.scal) {
+    double ldv = 0.0;
+    for (int w = 0; w < CHOL_NW; ++w) ldv += red[w];
+    if (it.pad & 16) {
+      it.scal[0] += ldv;
+      if (s_info && it.scal[1] == 0.0) it.scal[1] = (double)(it.info_offset + s_info);
+    } else {
+      it.scal[0] = ldv;
+      it.scal[1] = s_info ? (double)(it.info_offset + s_info) : 0.0;
+    }
+  }
+}
+
+#define BCB 128     // diagonal block of the blocked factorisation
 int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* LinvT, double* scal, int batch, int64_t stride,
                   int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri) {
   DS_CHECK_ARG(n % 64 == 0 && n >= 128 && batch >= 1);
-  P.n = n; P.batch = batch; P.nb = n / 64;
+  P.n = n; P.batch = batch; P.nb = from_tri ? n / 64 : ceil_div(n, BCB);
   P.W = W; P.Linv = Linv; P.LinvT = LinvT; P.scal = scal; P.Tbuf = Tbuf;
   P.stride = stride; P.scal_stride = scal_stride;
   P.want_inverse = Linv != nullptr;
   P.from_tri = from_tri;
   const int nb = P.nb;
-  // plan-owned scratch (64 x n per matrix) unless the caller supplies one
-  const size_t tb = Tbuf ? 0 : (size_t)batch * 64 * n * sizeof(double);
+  // plan-owned scratch (BCB x n per matrix) unless the caller supplies one
+  const int bs = from_tri ? 64 : BCB;
+  const size_t tb = Tbuf ? 0 : (size_t)batch * bs * n * sizeof(double);
   void* tblock = nullptr;
   if (tb) {
     DS_HIP(hipMalloc(&tblock, tb));
@@ -973,28 +1053,29 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
   std::vector<PotrfItem> items((size_t)nb * batch);
   for (int p = 0; p < nb; ++p)
     for (int b = 0; b < batch; ++b) {
-      const int64_t off = (int64_t)b * stride + (int64_t)p * 64 * n + p * 64;
-      int nr = nreal - p * 64;
-      nr = nr < 0 ? 0 : (nr > 64 ? 64 : nr);
-      // without a requested inverse the 64x64 diagonal inverses (needed by the panel solve) live in Tbuf
-      double* dinv = Linv ? Linv + off : Tbuf + (int64_t)b * 64 * n + p * 64;
+      const int64_t off = (int64_t)b * stride + (int64_t)p * bs * n + p * bs;
+      const int bn = std::min(bs, n - p * bs);                // 64 at a ragged end (n a multiple of 64)
+      int nr = nreal - p * bs;
+      nr = nr < 0 ? 0 : (nr > bn ? bn : nr);
+      // without a requested inverse the inverses of the diagonal blocks (needed by the panel solve) live in Tbuf
+      double* dinv = Linv ? Linv + off : Tbuf + (int64_t)b * bs * n + p * bs;
       items[(size_t)p * batch + b] = PotrfItem{W + off, dinv, nullptr, scal ? scal + b * scal_stride : nullptr,
-                                               64, n, nr, 16, p * 64, 0};
+                                               bn, n, nr, 16, p * bs, 0};
     }
   std::vector<GemmProblem> gp;
   P.tiles.clear();
   P.nprob.clear();
   P.first.clear();
   // one launch = a list of problems planned together (tile_start relative to the launch)
-  auto add_launch = [&](std::vector<GemmProblem>& list, bool allow_big) {
+  auto add_launch = [&](std::vector<GemmProblem>& list, int allow_big) {
     P.tiles.push_back(gemm_plan(list.data(), (int)list.size(), allow_big));
     P.nprob.push_back((int)list.size());
     P.first.push_back((int)gp.size());
     for (auto& g : list) gp.push_back(g);
   };
-  auto add = [&](GemmProblem& g) {
+  auto add = [&](GemmProblem& g, int mode) {
     std::vector<GemmProblem> one{g};
-    add_launch(one, false);    // the blocked factorisation's K = 64 panels stay on the 64 x 64 kernel
+    add_launch(one, mode);
   };
   auto mk = [&](const double* A, const double* B, double* C, int m, int nn, int k, int tA, int tB, double alpha, double beta, int lower) {
     GemmProblem g;
@@ -1006,16 +1087,21 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     return g;
   };
   if (!from_tri) {
-    for (int p = 0; p + 1 < nb; ++p) {
-      const int rem = n - (p + 1) * 64;
-      double* panel = W + (int64_t)(p + 1) * 64 * n + p * 64;
-      // L_ip = A_ip * L_pp^{-T}   (in place: one 64-wide output tile per row block)
-      GemmProblem g1 = mk(panel, Linv ? Linv + (int64_t)p * 64 * n + p * 64 : Tbuf + p * 64, panel, rem, 64, 64, 0, 1, 1.0, 0.0, 0);
-      if (!Linv) g1.sB = (int64_t)64 * n;
-      add(g1);
-      // A_ij -= L_ip L_jp^T  (lower tiles only)
-      GemmProblem g2 = mk(panel, panel, W + (int64_t)(p + 1) * 64 * n + (p + 1) * 64, rem, rem, 64, 0, 1, -1.0, 1.0, 1);
-      add(g2);
+    for (int p = 0; p + 1 < P.nb; ++p) {
+      const int rem = n - (p + 1) * BCB;
+      double* panel = W + (int64_t)(p + 1) * BCB * n + p * BCB;
+      // the panel, TRANSPOSED, into the mirror blocks above the diagonal (unused by the factorisation):  L_ip^T = L_pp^-1 A_ip^T.
+      // Out of place, so the LDS-free 64 x 64 kernel can take it (16 us; in place only a kernel whose workgroup owns all 128 columns
+      // of its rows is safe — the 128 x 128 kernel at 8 barrier-separated k-steps: 26 us).  k_mirror_panels moves the panels
+      // back below the diagonal at the end.
+      double* mirror = W + (int64_t)p * BCB * n + (p + 1) * BCB;
+      GemmProblem g1 = mk(Linv ? Linv + (int64_t)p * BCB * n + p * BCB : Tbuf + p * BCB, panel, mirror, BCB, rem, BCB, 0, 1, 1.0, 0.0, 0);
+      if (!Linv) g1.sA = (int64_t)BCB * n;
+      g1.tri = 2;                                        // L_pp^-1 lower-triangular
+      add(g1, 0);
+      // A_ij -= L_ip L_jp^T  (lower tiles only), both operands read from the transposed panel
+      GemmProblem g2 = mk(mirror, mirror, W + (int64_t)(p + 1) * BCB * n + (p + 1) * BCB, rem, rem, BCB, 1, 0, -1.0, 1.0, 1);
+      add(g2, 0);
     }
   }
   if (P.want_inverse) {
@@ -1031,7 +1117,7 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
       S = (double*)P.inv_block;
     }
     const int64_t sS = LinvT ? stride : (int64_t)n * n;
-    for (int sblk = 64; sblk < n; sblk *= 2) {
+    for (int sblk = from_tri ? 64 : BCB; sblk < n; sblk *= 2) {
       std::vector<GemmProblem> l1, l2;
       for (int r0 = sblk; r0 < n; r0 += 2 * sblk) {
         const int c0 = r0 - sblk;
@@ -1045,8 +1131,8 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
         g2.sB = sS; g2.tri = 2;                                 // X22 lower-triangular: k <= m
         l2.push_back(g2);
       }
-      add_launch(l1, true);
-      add_launch(l2, true);
+      add_launch(l1, sblk <= 256 ? 0 : 1);      // short K: as above
+      add_launch(l2, sblk <= 256 ? 0 : 1);
     }
   }
   const size_t ib = round_up(items.size() * sizeof(PotrfItem), 256), gb = round_up(gp.size() * sizeof(GemmProblem) + 256, 256);
@@ -1075,15 +1161,20 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
   if (!P.from_tri) {
     if (P.scal)
       for (int b = 0; b < batch; ++b) DS_HIP(hipMemsetAsync(P.scal + b * P.scal_stride, 0, 2 * sizeof(double), ctx->stream));
-    const size_t lds = (16 * 17 + 8 + (size_t)4 * 16 * 17 + (size_t)64 * 68) * sizeof(double);
+    const size_t lds = chol_lds_bytes(BCB);
+    static bool lds_set = false;      // the attribute is sticky: one driver call
+    if (!lds_set) {
+      DS_HIP(hipFuncSetAttribute((const void*)k_chol_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set = true;
+    }
     for (int p = 0; p < nb; ++p) {
-      hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(batch), dim3(256), lds, ctx->stream, P.diag_items + (size_t)p * batch, 4);
+      hipLaunchKernelGGL(k_chol_block, dim3(batch), dim3(CHOL_THREADS), lds, ctx->stream, P.diag_items + (size_t)p * batch);
       if (p + 1 < nb) {
         launch(gi++);
         launch(gi++);
       }
     }
-    hipLaunchKernelGGL(k_zero_upper_blocks, dim3(256, batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride);
+    hipLaunchKernelGGL(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);
   } else if (P.want_inverse) {
     hipLaunchKernelGGL(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
   }

@@ -33,7 +33,7 @@ struct PotrfItem {
 
 // Fills tile_start/tiles_* of `host` problems, returns the total number of tiles (64 x 64, or 128 x 128 with the large-tile
 // kernel flagged in bit 30 when the launch holds a problem of at least 512 x 512 and allow_big): pass it to gemm_launch as is.
-int gemm_plan(GemmProblem* host, int nprob, bool allow_big = true);
+int gemm_plan(GemmProblem* host, int nprob, int allow_big = 1);     // 0: 64 x 64 kernels only, 1: by size, 2: the 128 x 128 kernel
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream = nullptr);
 // n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant

@@ -1535,12 +1535,17 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       GemmProblem ng[5];
       fill_gemm(ng[0], v.ngTI, v.ngTbar, v.ngH, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);        // T^T Tbar
       fill_gemm(ng[1], v.ngTinv, v.ngTinv, v.ngSinv, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);   // S^-1
+      ng[0].lower_only = 1; ng[0].tri = 8 | 1;          // upper x lower; k_ng_phi keeps tril(H) only
+      ng[1].lower_only = 1; ng[1].tri = 8 | 1 | 16;     // upper x lower, symmetric (as Ku^-1)
       St.ng_t1 = gemm_plan(ng, 2);
       fill_gemm(ng[2], v.ngH, v.ngTinv, v.ngY, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);         // Phi T^-1
+      ng[2].tri = 2 | 1;                                // lower x lower = lower (the tiles above the diagonal come out as zeros: ng[3] reads them)
       St.ng_t2 = gemm_plan(ng + 2, 1);
       fill_gemm(ng[3], v.ngTinv, v.ngY, v.ngX, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);         // T^-T Phi T^-1
+      ng[3].tri = 8 | 1;                                // upper x lower
       St.ng_t3 = gemm_plan(ng + 3, 1);
       fill_gemm(ng[4], v.ngLAinvT, v.ngLAinv, v.ngSplus, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);  // S+
+      ng[4].lower_only = 1; ng[4].tri = 8 | 1 | 16;     // upper x lower, symmetric
       St.ng_t4 = gemm_plan(ng + 4, 1);
       DS_HIP(hipMemcpyAsync(St.ng_gp, ng, sizeof(ng), hipMemcpyHostToDevice, st));
       std::vector<PotrfItem> it(2 * v.D_out);
