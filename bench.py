@@ -77,7 +77,7 @@ def default_Z(X, M, seed=0):
         return X[rng.permutation(X.shape[0])[:M]].copy()
 
 
-def build_model(cfg, rank, world, mb_local):
+def build_model(cfg, rank, world, mb_local, bucketed=None):
     from doubly_stochastic_dgp.dgp import DGP
     from doubly_stochastic_dgp.gpflow_compat import RBF, Gaussian
     X, Y = make_synthetic(cfg["n_data"], cfg["D"], seed=0)
@@ -88,7 +88,7 @@ def build_model(cfg, rank, world, mb_local):
         layer.q_sqrt = layer.q_sqrt.value * 1e-5                      # demo_regression_UCI.ipynb:183
     if world > 1:
         from doubly_stochastic_dgp.distributed import attach
-        attach(model, rank, world)
+        attach(model, rank, world, bucketed=bucketed)      # None: by gradient size (distributed.BUCKET_MIN_BYTES: flat at config 2)
     return model, X, Y, Z
 
 
@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = global minibatch fixed at 1000 (BASELINE's metric), weak = 1000 rows per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiler runs)")
+    ap.add_argument("--allreduce", choices=["auto", "flat", "bucketed"], default="auto",
+                    help="N > 1: one flat gradient all-reduce per step, or one per layer from inside the reverse pass; auto = by gradient size")
     args = ap.parse_args()
 
     import torch
@@ -253,7 +255,7 @@ def main():
         mb_local = cfg["mb"] // world
     else:
         mb_local = cfg["mb"]
-    model, X, Y, Z = build_model(cfg, rank, world, mb_local)
+    model, X, Y, Z = build_model(cfg, rank, world, mb_local, {"auto": None, "flat": False, "bucketed": True}[args.allreduce])
     eng = model.engine()
     ctx = eng.ctx
     cfg_local = dict(cfg, mb=mb_local)        # per-GPU shard: what one launch of this rank processes
@@ -409,7 +411,9 @@ def main():
             "config": {"workload": "3-layer DS-DGP, kin8nm-shaped (7372x8), RBF, M=128, S=20, global minibatch "
                                    f"{mb_local * world} ({mb_local} rows per GPU), fp64, white=False (BASELINE.json configs[1])",
                        "per_gpu_minibatch": mb_local, "global_batch": mb_local * world, "num_samples": cfg["S"],
-                       "inducing": cfg["M"], "layers": cfg["L"], "parallelism": f"row-sharded dp{world}"},
+                       "inducing": cfg["M"], "layers": cfg["L"], "parallelism": f"row-sharded dp{world}",
+                       "gradient_exchange": ("none" if world == 1 else
+                                             ("one all-reduce per layer (bucketed)" if model._dist_buckets()["on"] else "one flat all-reduce"))},
             "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "kernel_ms_per_step": prof,
             "step_time": steady,
             "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world

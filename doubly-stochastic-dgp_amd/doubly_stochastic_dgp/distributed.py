@@ -76,20 +76,28 @@ class _Buckets:
         self.works = []
 
 
+# gradient bytes from which the per-layer exchange is the default.  Measured on one MI355X with a one-rank RCCL group (the collectives
+# are identities: everything AROUND them is what is timed, tools/bench_shards.py, profiles/r03_strong_scaling_shards.jsonl): the
+# bucketed step costs 0.07 .. 0.13 ms more than the flat one at config 2 (four callbacks into Python, per-layer assembly launches,
+# four collectives instead of one) — more than the whole 2.3 MB all-reduce it could hide.  From tens of MB of gradient (configs 3 / 5:
+# 24 / 200 MB) the exchange is milliseconds and the per-layer form hides all but the lowest layer's.
+BUCKET_MIN_BYTES = 16 << 20
+
+
 def attach(model, rank, world, bucketed=None):
     """Make `model` (DGP_Base) a data-parallel replica: rank-specific minibatch stream and Philox stream, gradient
     all-reduce before the Adam step.  Requires torch.distributed to be initialised (backend 'nccl' == RCCL on ROCm).
-    bucketed (default: on for world > 1 where the library supports it): one all-reduce per layer, issued from inside the reverse pass
-    on the stream that produced the layer's gradient — it overlaps the lower layers' backward chains — instead of one flat
-    all-reduce after the pass."""
+    bucketed: one all-reduce per layer, issued from inside the reverse pass on the stream that produced the layer's gradient — it
+    overlaps the lower layers' backward chains — instead of one flat all-reduce after the pass.  Default (None): on for world > 1
+    when the gradient is at least BUCKET_MIN_BYTES (see above) and the library supports it for the model."""
     from .dgp import Minibatch
     if model.minibatch_size:
         model._minibatch = Minibatch(model.X_data.shape[0], model.minibatch_size, seed=rank)
-    state = {"buckets": None, "model": None}
-    want_buckets = (world > 1) if bucketed is None else bool(bucketed)
+    state = {"buckets": None, "model": None, "last_count": 0}
 
     def allreduce(eng, with_grad, sync=True):
         b = state["buckets"]
+        state["last_count"] = b.count if b is not None else 0
         if b is not None and with_grad and b.count > 0:
             b.finish()                                  # the reverse pass already exchanged every bucket
             b.count = 0
@@ -104,7 +112,8 @@ def attach(model, rank, world, bucketed=None):
 
     def before_elbo(eng):
         """(re)install the callback on the engine's current device model (a model re-creation drops it)"""
-        if not want_buckets:
+        want = (world > 1 and eng.n_theta * 8 >= BUCKET_MIN_BYTES) if bucketed is None else bool(bucketed)
+        if not want:
             return
         b = state["buckets"]
         if b is None or b.eng is not eng or getattr(b, "_model", None) != eng.model.value:
@@ -115,4 +124,6 @@ def attach(model, rank, world, bucketed=None):
 
     object.__setattr__(model, "_dist", (rank, world, allreduce))
     object.__setattr__(model, "_dist_before_elbo", before_elbo)
+    # (tests) how many buckets the last reverse pass handed out
+    object.__setattr__(model, "_dist_buckets", lambda: {"count": state["last_count"], "on": state["buckets"] is not None})
     return model

@@ -46,6 +46,28 @@ def test_attach_allreduce_single_rank_nccl():
         dist.all_reduce(t)
         dist.barrier()
         assert float(t.sum().item()) == 4.0
+        # the BUCKETED exchange (one RCCL all-reduce per layer, issued from the library's callback on the stream that produced the
+        # layer's gradient: torch.cuda.ExternalStream + async_op) — small model: every bucket on the main stream; large model
+        # (n S Mp >= 2^20): the upper layers' buckets on the side stream, under the lower layers' backward chains
+        for (N2, D2, M2, S2, L2) in ((200, 4, 32, 3, 2), (1000, 5, 96, 14, 3)):
+            rng = np.random.RandomState(1)
+            X2, Y2 = rng.randn(N2, D2), rng.randn(N2, 1)
+            Z2 = X2[:M2] + 0.05 * rng.randn(M2, D2)
+            zs2 = [rng.randn(S2, N2, D2)] * (L2 - 1) + [rng.randn(S2, N2, 1)]
+            _, _, ref2 = make_case(X2, Y2, Z2, [kern_spec("rbf", D2)] * L2, S=S2, num_data=5000)
+            _, _, dpb = make_case(X2, Y2, Z2, [kern_spec("rbf", D2)] * L2, S=S2, num_data=5000)
+            attach(dpb, 0, 1, bucketed=True)
+            e_ref = ref2._build_likelihood(X2, Y2, zs=zs2, with_grad=True)
+            e_b = dpb._build_likelihood(X2, Y2, zs=zs2, with_grad=True)
+            assert dpb._dist_buckets()["count"] >= L2 + 1, "the bucket callback did not run"
+            assert_allclose(e_b, e_ref, rtol=1e-13)
+            assert_allclose(dpb.engine().grad.cpu().numpy(), ref2.engine().grad.cpu().numpy(), rtol=1e-12, atol=1e-14)
+            for _ in range(3):
+                ref2.train_step(0.01, X=X2, Y=Y2, zs=zs2)
+                dpb.train_step(0.01, X=X2, Y=Y2, zs=zs2)
+            ref2.engine().sync_to_host(); dpb.engine().sync_to_host()
+            assert_allclose(dpb.layers[0].q_mu.value, ref2.layers[0].q_mu.value, rtol=1e-10, atol=1e-13)
+            assert_allclose(dpb.layers[-1].q_sqrt.value, ref2.layers[-1].q_sqrt.value, rtol=1e-10, atol=1e-13)
     finally:
         dist.destroy_process_group()
 
