@@ -30,5 +30,17 @@ DSDGP_POTRF_TIMING=1 timeout 300 python tools/potrf_timing.py 2>&1 | grep cycles
 timeout 900 python tools/bench_configs.py 1 2 3 4 5 > $P/r03_all_config_shapes.jsonl 2> $O/all.err
 timeout 600 python tools/bench_shards.py > $P/r03_strong_scaling_shards.jsonl 2> $O/shards.err
 timeout 120 tools/bin/chol16_bench > $P/r03_chol16_bench.txt 2>&1
+timeout 300 python tools/gemm_bench.py > $P/r03_gemm_bench.txt 2> $O/gemm.err
+# large-M shapes: kernel stats of configs 4 / 5 (serial schedule) and of dsdgp_potrf at n = 1024
+for c in 4 5; do
+  rm -rf /tmp/prof$c
+  (cd /tmp && DSDGP_NO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$c -o p -- python $R/tools/ab_kernels.py $c > $O/run$c.log 2>&1)
+  DB=$(find /tmp/prof$c -name "*results.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $P/r03_kernel_stats_cfg$c.md "round 3: config-$c shape (tools/ab_kernels.py $c) under rocprofv3 --kernel-trace --stats, serial schedule" > /dev/null
+done
+rm -rf /tmp/pp; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp -o p -- python $R/tools/potrf_prof.py 1024 > $O/potrf.log 2>&1)
+DB=$(find /tmp/pp -name "*results.db" | head -1)
+[ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $P/r03_potrf_n1024_stats.md "round 3: dsdgp_potrf n = 1024, 6 calls, then torch.linalg.cholesky (rocSOLVER) of the same matrix once" > /dev/null
+grep "potrf n=\|relerr" $O/potrf.log > $P/r03_potrf_n1024_wall.txt
 rm -rf $O
 cat $P/summary.log; cat $P/r03_all_config_shapes.jsonl | cut -c1-160; cat $P/r03_strong_scaling_shards.jsonl
