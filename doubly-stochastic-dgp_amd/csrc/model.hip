@@ -833,34 +833,40 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
   const int rwave = threadIdx.x >> 6;
   if (J.ways == 16) {
     // symmetric result, one 16 x 16 tile on or below the diagonal per workgroup: each wave sums a quarter of the splits for the whole
-    // tile (lane = (row g + 4 e, column c): 128-byte row segments), the four partial tiles meet in LDS, and the tile goes out twice —
+    // tile (16-byte loads, four splits in flight per wave), the four partial tiles meet in LDS, and the tile goes out twice —
     // as it is and transposed to its mirror position — BOTH along rows.  (The element-wise form stored the mirror with stride
     // out_ld: 64 cache lines per store instruction for ~47 % of the outputs.)
     __shared__ double tl[4][16][17];
-    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, rr = lane >> 3, cp = (lane & 7) * 2;      // lane = (row rr + 8 e, column pair cp): 16-byte loads
     int t = bx - J.blk_start, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
-    const double* __restrict__ src = J.part + (int64_t)(16 * ti + g) * J.in_ld + 16 * tj + c;
-    const int64_t estep = (int64_t)4 * J.in_ld;
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    int sp = rwave;
-    for (; sp + 4 < J.nsplit; sp += 8) {          // two splits = eight loads in flight
-      const double* __restrict__ p0 = src + (int64_t)sp * J.pstride;
-      const double* __restrict__ p1 = p0 + (int64_t)4 * J.pstride;
+    const double* __restrict__ src = J.part + (int64_t)(16 * ti + rr) * J.in_ld + 16 * tj + cp;
+    const int64_t estep = (int64_t)8 * J.in_ld;
+    d2 s[4][2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s0[e] += p0[e * estep];
-        s1[e] += p1[e * estep];
+    for (int u = 0; u < 4; ++u) s[u][0] = s[u][1] = (d2){0, 0};
+    int sp = rwave;
+    for (; sp + 12 < J.nsplit; sp += 16) {          // four splits = eight 16-byte loads in flight per lane
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* __restrict__ p = src + (int64_t)(sp + 4 * u) * J.pstride;
+        s[u][0] += *reinterpret_cast<const d2*>(p);
+        s[u][1] += *reinterpret_cast<const d2*>(p + estep);
       }
     }
-    if (sp < J.nsplit) {
-      const double* __restrict__ p0 = src + (int64_t)sp * J.pstride;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s0[e] += p0[e * estep];
+    for (int u = 0; sp < J.nsplit; sp += 4, ++u) {   // at most three more: into the accumulator their position in a full group would use
+      const double* __restrict__ p = src + (int64_t)sp * J.pstride;
+      s[u][0] += *reinterpret_cast<const d2*>(p);
+      s[u][1] += *reinterpret_cast<const d2*>(p + estep);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tl[rwave][g + 4 * e][c] = s0[e] + s1[e];
+    for (int e = 0; e < 2; ++e) {
+      const d2 v2 = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+      tl[rwave][rr + 8 * e][cp] = v2[0];
+      tl[rwave][rr + 8 * e][cp + 1] = v2[1];
+    }
     __syncthreads();
     const int r = threadIdx.x >> 4, cc = threadIdx.x & 15;
     const double v = (tl[0][r][cc] + tl[1][r][cc]) + (tl[2][r][cc] + tl[3][r][cc]);
@@ -2005,7 +2011,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
                       ((uintptr_t)r.part & 15) == 0;
     if (r.ways == 4 && even) r.ways = 8;
     const int64_t rows = r.out_ld > 0 ? r.count / r.out_ld : 0;
-    const bool tiled = !r.wide && r.sym_n > 0 && r.sym_tile == 16 && r.out_ld > 0 && rows == r.out_ld && rows % 16 == 0;
+    const bool tiled = !r.wide && r.sym_n > 0 && r.sym_tile == 16 && r.out_ld > 0 && rows == r.out_ld && rows % 16 == 0 && even;
     if (tiled) r.ways = 16;
     r.blk_start = blocks;
     blocks += r.wide ? (int)r.count
