@@ -164,7 +164,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -184,6 +184,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "cs_min_dout") m->force.cs_min_dout = v;
       else if (k == "alg_g") m->force.alg_g = v;
       else if (k == "bwd_split") m->force.bwd_split = v;
+      else if (k == "red_ahead") m->force.red_ahead = v;
       else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
       else if (k == "head") m->force.head = v;
@@ -1242,19 +1243,28 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
   for (int j = tid; j < M; j += 256) {
     const int64_t idx = (int64_t)i * Mp + j, idt = (int64_t)j * Mp + i;
     double nn = 0.0, uu = 0.0, gsym;
-    for (int d = 0; d < Dout; ++d) {
-      nn = fma(v.n4[i * v.DP4 + d], v.n4[j * v.DP4 + d], nn);
-      uu += v.UU[d * MM + idx];
-    }
     if (v.alg_g) {
       // sym(sum_r e a^T) = sum_d (GS_d + GS_d^T - P_d) + 1/2 (n t^T + t n^T),  t = A mbar^T (thinq)
+      // ONE loop over the outputs, unrolled: every load of four outputs is in flight before the first use (two loops of
+      // one output per iteration walked 2 D_out dependent round trips)
       double gs = 0.0, nt = 0.0;
+#pragma unroll 4
       for (int d = 0; d < Dout; ++d) {
-        gs += (v.GS[d * MM + idx] + v.GS[d * MM + idt]) - v.bigred[MM + d * MM + idx];
-        nt += v.n4[i * v.DP4 + d] * v.thinq[j * v.DP16 + d] + v.n4[j * v.DP4 + d] * v.thinq[i * v.DP16 + d];
+        const double ni = v.n4[i * v.DP4 + d], nj = v.n4[j * v.DP4 + d];
+        const double g1 = v.GS[d * MM + idx], g2 = v.GS[d * MM + idt], pd = v.bigred[MM + d * MM + idx];
+        const double tj = v.thinq[j * v.DP16 + d], ti2 = v.thinq[i * v.DP16 + d];
+        nn = fma(ni, nj, nn);
+        uu += v.UU[d * MM + idx];
+        gs += (g1 + g2) - pd;
+        nt += ni * tj + nj * ti2;
       }
       gsym = gs + 0.5 * nt;
     } else {
+#pragma unroll 4
+      for (int d = 0; d < Dout; ++d) {
+        nn = fma(v.n4[i * v.DP4 + d], v.n4[j * v.DP4 + d], nn);
+        uu += v.UU[d * MM + idx];
+      }
       gsym = 0.5 * (v.bigred[idx] + v.bigred[idt]);
     }
     const double kb = -gsym + kl_w * (0.5 * Dout * v.Kinv[idx] - 0.5 * uu - 0.5 * nn);
@@ -2179,6 +2189,14 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     side_marked = side_marked || last_side;
     if (pipelined) DS_TRY(layer_tail(St, ss));
   }
+  // the lowest layer's products ran on the main stream: its split-K reduction goes ahead of the join, so that the side stream's
+  // completion signal (a just-in-time cross-stream wait costs ~12 us of idle time) travels while the main stream works
+  const bool red_ahead = overlap && !pipelined && gfirst == 0 && L > 1 && m->force.red_ahead != 0;
+  if (red_ahead) {
+    LayerState& S0 = m->L[0];
+    hipLaunchKernelGGL(k_reduce_grouped, dim3(S0.red_blkn), dim3(256), 0, ctx->stream, m->rjobs + S0.red_off, S0.red_n, S0.red_blk0);
+    DS_HIP(hipGetLastError());
+  }
   if (overlap) {
     // value + likelihood-variance gradient: needs the likelihood partials (main, before ev_bwd) and KL (side).  AFTER the
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
@@ -2189,7 +2207,13 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
 
   }
   if (!pipelined) {
-    hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
+    if (red_ahead) {
+      LayerState& S1 = m->L[1];
+      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + S1.red_off,
+                         m->n_red - S1.red_off, S1.red_blk0);
+    } else {
+      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
+    }
     DS_HIP(hipGetLastError());
     if (m->desc.white) {
       hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
