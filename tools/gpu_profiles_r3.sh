@@ -7,9 +7,15 @@ O=$R/gpurun_out/prof_r3; rm -rf $O; mkdir -p $O
 P=$R/gpurun_out/profiles_r3; rm -rf $P; mkdir -p $P
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q -x > $P/pytest.log 2>&1; echo "pytest rc=$?" > $P/summary.log; tail -3 $P/pytest.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" >> $P/summary.log
-timeout 900 python bench.py > $P/r03_bench.json 2> $O/bench.err; tail -c 600 $P/r03_bench.json >> $P/summary.log
 H=$(python -c "import bench; print(bench.csrc_hash())")
 cd /tmp
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  DSDGP_NO_OVERLAP=1 timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_$ctr.json 2> $O/pmc_$ctr.err
+done
+python $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $P/r03_pmc_traffic "round 3 — HBM traffic per launch (rocprofv3 --pmc, cfg 2)" $H
+# the bench line AFTER the counters of this build are in place (bench.py reports traffic only when the source hashes match)
+cp $P/r03_pmc_traffic.json $R/profiles/r03_pmc_traffic.json
+(cd $R && timeout 900 python bench.py > $P/r03_bench.json 2> $O/bench.err; tail -c 600 $P/r03_bench.json >> $P/summary.log)
 DSDGP_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/serial -o t -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $O/serial.json 2> $O/serial.err
 DB=$(find $O/serial -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $P/r03_kernel_stats_serial.md "round 3: bench.py --steps 40 --warmup 5 --no-extras under rocprofv3 --kernel-trace --stats, DSDGP_NO_OVERLAP=1 (overlap-free: every duration is the kernel's own)" > /dev/null
@@ -20,10 +26,6 @@ DB=$(find $O/prod -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $P/r03_kernel_stats.md "round 3: bench.py --steps 40 --warmup 5 --no-extras under rocprofv3 --kernel-trace --stats (production: side-stream overlap on, durations of co-running kernels stretch)" > /dev/null
 python $R/tools/gap_analysis.py $DB k_tail > $P/r03_timeline_gaps.txt
 python $R/tools/timeline_dump.py $DB k_tail 3 > $P/r03_timeline_step.txt
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  DSDGP_NO_OVERLAP=1 timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_$ctr.json 2> $O/pmc_$ctr.err
-done
-python $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $P/r03_pmc_traffic "round 3 — HBM traffic per launch (rocprofv3 --pmc, cfg 2)" $H
 cd $R
 DSDGP_FWD_TIMING=1 DSDGP_BWD_TIMING=1 DSDGP_NO_OVERLAP=1 timeout 600 python tools/bwd_phases.py 2 3 > $P/r03_chain_phases.txt 2>&1
 DSDGP_POTRF_TIMING=1 timeout 300 python tools/potrf_timing.py 2>&1 | grep cycles > $P/r03_head_phases.txt
