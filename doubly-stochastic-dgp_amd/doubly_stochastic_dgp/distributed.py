@@ -40,7 +40,7 @@ class _Buckets:
 
     def __init__(self, eng, world):
         from . import _lib
-        self.eng, self.world, self.works, self.count = eng, world, [], 0
+        self.eng, self.world, self.works, self.count, self.error = eng, world, [], 0, None
         self._cb = _lib.BUCKET_FN(self._on_bucket)          # keep the ctypes thunk alive as long as the model
 
     def install(self):
@@ -50,6 +50,14 @@ class _Buckets:
         self._model = self.eng.model.value
 
     def _on_bucket(self, user, bucket, ptr, count, stream):
+        # (called from inside a ctypes call: an exception raised here would only be printed — keep it for finish())
+        try:
+            self._exchange(bucket, ptr, count, stream)
+        except BaseException as e:  # noqa: BLE001
+            if self.error is None:
+                self.error = e
+
+    def _exchange(self, bucket, ptr, count, stream):
         import torch
         import torch.distributed as dist
         eng = self.eng
@@ -74,6 +82,9 @@ class _Buckets:
         for w in self.works:
             w.wait()                                    # the current (engine) stream waits for the collective's stream
         self.works = []
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError("gradient bucket exchange failed") from err
 
 
 # gradient bytes from which the per-layer exchange is the default.  Measured on one MI355X with a one-rank RCCL group (the collectives
@@ -98,6 +109,8 @@ def attach(model, rank, world, bucketed=None):
     def allreduce(eng, with_grad, sync=True):
         b = state["buckets"]
         state["last_count"] = b.count if b is not None else 0
+        if b is not None and b.error is not None and b.count == 0:
+            b.finish()                                  # raises: the first bucket already failed
         if b is not None and with_grad and b.count > 0:
             b.finish()                                  # the reverse pass already exchanged every bucket
             b.count = 0
