@@ -48,7 +48,7 @@ def test_gemm(ctx, tA, tB, m, n, k):
     assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
 
 
-@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256, 300, 512, 600, 1024])
+@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256, 300, 512, 570, 600, 1024])      # 570 -> 576 = 4 x 128 + 64: ragged last diagonal block
 def test_potrf(ctx, n):
     from doubly_stochastic_dgp import _lib
     rng = np.random.RandomState(n)

@@ -60,7 +60,8 @@ def test_reverse_pass_schedules_are_bitwise_neutral(monkeypatch, white):
     """serial (one stream) == weight-gradient products behind their chain == A jobs under their chain == + pipelined tail."""
     ref = _train_state(monkeypatch, "early_wgrad=0,pipe_tail=0", True, white=white)
     assert np.isfinite(ref[0])
-    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=0", "early_wgrad=1,pipe_tail=1", "early_wgrad=0,pipe_tail=1"):
+    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=0", "early_wgrad=1,pipe_tail=1", "early_wgrad=0,pipe_tail=1",
+                  "red_ahead=0", "red_ahead=1,ext_ev=0"):
         got = _train_state(monkeypatch, force, False, white=white)
         assert got[0] == ref[0], force
         assert np.array_equal(got[1], ref[1]), force
@@ -124,3 +125,52 @@ def test_trsm_strided_views(ctx):
     got = dB.cpu().numpy()
     assert_allclose(got[:, :nrhs], sla.solve_triangular(Lbuf[:, :n], Bbuf[:, :nrhs], lower=True), rtol=1e-10, atol=1e-11)
     assert np.array_equal(got[:, nrhs:], Bbuf[:, nrhs:])          # columns beyond nrhs untouched
+
+
+# ---------------------------------------------------------------- materialised Gram matrices: the MFMA form (D <= 32) and its edges
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("n,n2,D", [(5, 33, 1), (64, 1000, 8), (65, 999, 16), (130, 515, 17), (40, 2049, 32), (70, 300, 33)])
+def test_gram_mfma_shapes(ctx, kind, n, n2, D):
+    """k_gram_mfma: one / two / four / eight k-steps (D = 1 .. 32), rows and columns that do not fill the 16 x 32 tiles, odd leading
+    dimensions (scalar stores), and D = 33 (falls back to the direct-difference kernel); the symmetric call is EXACTLY symmetric with
+    the jitter on its diagonal and nothing else there."""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(n + n2 + D)
+    X, X2 = rng.randn(n, D), rng.randn(n2, D)
+    ls = 0.7 + rng.rand(D)
+    k = O.Kern(kind, D, variance=1.4, lengthscales=ls, ARD=True)
+    spec = _lib.KernelSpec(kind={"rbf": 0, "matern52": 1}[kind], input_dim=D, ard=1, has_white=0, variance=1.4, white_variance=0.0,
+                           lengthscales=ls.ctypes.data_as(_lib.c_double_p))
+    dX, dX2 = _dev(ctx, X), _dev(ctx, X2)
+    out, outs = ctx.empty(n, n2), ctx.empty(n, n)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, _p(dX2), n2, 0.0, _p(out), n2))
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, None, 0, 1e-6, _p(outs), n))
+    ctx.sync()
+    assert_allclose(out.cpu().numpy(), k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
+    Ks = outs.cpu().numpy()
+    assert_allclose(Ks, k.K(O.NP, X) + 1e-6 * np.eye(n), rtol=1e-11, atol=1e-13)
+    assert np.array_equal(Ks, Ks.T)
+    dg = np.diag(Ks)                                  # r2 is exactly 0 on the diagonal: one value, k(0) + jitter
+    assert np.all(dg == dg[0])
+    if kind == "rbf":
+        assert abs(dg[0] - (1.4 + 1e-6)) <= 4e-16     # (Matern-5/2: r = sqrt(r2 + 1e-12) upstream, k(0) is not the variance exactly)
+
+
+def test_gram_into_a_wider_buffer(ctx):
+    """ld_out > n2: the columns beyond n2 stay untouched (16-byte pair stores must not spill over a row's end)"""
+    from doubly_stochastic_dgp import _lib
+    rng = np.random.RandomState(0)
+    n, n2, D, ld = 50, 101, 8, 128
+    X, X2 = rng.randn(n, D), rng.randn(n2, D)
+    ls = np.array([0.9])
+    k = O.Kern("rbf", D, variance=1.0, lengthscales=0.9, ARD=False)
+    spec = _lib.KernelSpec(kind=0, input_dim=D, ard=0, has_white=0, variance=1.0, white_variance=0.0, lengthscales=ls.ctypes.data_as(_lib.c_double_p))
+    buf = np.full((n, ld), 7.0)
+    dX, dX2, dout = _dev(ctx, X), _dev(ctx, X2), _dev(ctx, buf)
+    ctx.torch.cuda.current_stream().synchronize()
+    _lib.check(ctx.lib.dsdgp_gram(ctx.handle, C.byref(spec), _p(dX), n, _p(dX2), n2, 0.0, _p(dout), ld))
+    ctx.sync()
+    got = dout.cpu().numpy()
+    assert_allclose(got[:, :n2], k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
+    assert np.all(got[:, n2:] == 7.0)
