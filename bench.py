@@ -419,8 +419,9 @@ def main():
             "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world
                                                 / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
             "elbo_evals_per_s": None if evals_per_s is None else round(evals_per_s, 2),
-            "elbo_evals_note": "forward-only ELBO at FIXED parameters: the factorisation of Ku is kept between evaluations "
-                               "(dsdgp_model_track_theta); the training step above refactorises every step",
+            "elbo_evals_note": "forward-only ELBO at FIXED parameters: the factorisation of Ku and the parameter-side products are "
+                               "kept between evaluations (dsdgp_model_track_theta) and the chains run in whitened coordinates; the "
+                               "training step above refactorises every step",
             "predict_f_rows_per_s": None if predict_rows_per_s is None else round(predict_rows_per_s, 1),
             "final_elbo": elbo,
         }

@@ -16,6 +16,7 @@ struct LayerFwdArgs {
   const double* Tp;     // (D_out x Mp x Mp) lower-triangular q_sqrt, zero padded
   const double* TpT;    // (D_out x Mp x Mp) its transpose (split-M kernels read every weight as rows [i][k])
   const double* qmu;    // (Mp x D_out)
+  int32_t qmu_ld;       // row stride of qmu (0: D_out)
   int32_t mean_kind;
   const double* mean_A; // (D_in x D_out) of the Linear mean function
   const double* mean_b; // (D_out) bias of the Linear mean function or NULL

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
   constexpr bool D4 = (MPB > 16);
   constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
+  const int qld = a.qmu_ld ? a.qmu_ld : Dout;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   double* xs = smem + L.xs;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
           if (Own<MPB, NW>::skip(ib)) continue;
           double qv[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) qv[t] = a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + dc];       // layers.py:190
+          for (int t = 0; t < 4; ++t) qv[t] = a.qmu[(int64_t)(16 * ib + g + 4 * t) * qld + dc];       // layers.py:190
 #pragma unroll
           for (int t = 0; t < 4; ++t) mu4 = mfma_f64(din ? qv[t] : 0.0, acc[q][t], mu4);
         }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             p = fma(cacc[q][t], cacc[q][t], p);
-            if constexpr (!MU_EARLY) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * Dout + d], mu);   // layers.py:190
+            if constexpr (!MU_EARLY) mu = fma(acc[q][t], a.qmu[(int64_t)(16 * ib + g + 4 * t) * qld + d], mu);   // layers.py:190
           }
         }
       }

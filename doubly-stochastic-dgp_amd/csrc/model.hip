@@ -164,7 +164,7 @@ struct dsdgp_model {
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
   // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -185,6 +185,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "alg_g") m->force.alg_g = v;
       else if (k == "bwd_split") m->force.bwd_split = v;
       else if (k == "red_ahead") m->force.red_ahead = v;
+      else if (k == "white_fwd") m->force.white_fwd = v;
       else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
       else if (k == "head") m->force.head = v;
@@ -1708,6 +1709,9 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   const int L = m->desc.L;
   DS_TRY(join_prep(m));
   const bool keep_kuu = m->track_theta && m->kuu_valid;
+  // dsdgp_model_track_theta and no change since an evaluation that produced everything this one needs: the factor AND the
+  // parameter-side products (Ku^-1, Lu^-1 q_sqrt, KL, ...) stay — a forward-only evaluation at fixed parameters is the chains alone
+  const bool unchanged = keep_kuu && m->q_dirty == -1 && (m->prepared_grad || !with_grad);
   int mp_max = 0;
   for (int l = 0; l < L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
   bool head_event = false;
@@ -1732,7 +1736,7 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
                           (int64_t)m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep,
                           keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r, gq);
     DS_HIP(hipGetLastError());
-  } else {
+  } else if (!unchanged) {
     hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
                        m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
                        m->prep_blocks, keep_kuu ? 1 : 0);
@@ -1751,6 +1755,10 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     }
   } else {
     DS_TRY(potrf_launch(ctx, m->potrf_items, L, mp_max));
+  }
+  if (unchanged) {
+    m->prepared = true;
+    return DSDGP_OK;
   }
   hipStream_t st = ctx->stream;
   if (side) {
@@ -1849,6 +1857,13 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
   const int L = m->desc.L;
   DS_CHECK_ARG(n > 0 && n <= m->n_max && S > 0 && S <= m->s_max);
   const double* Xin = X;
+  // Forward-only evaluations of a non-white model (predict_f, ELBO values) run in WHITENED coordinates: with V_d = Lu^-1 q_sqrt_d and
+  // nL = Lu^-1 q_mu — both formed for the KL term anyway — mean = a1^T nL and var = kdiag - |a1|^2 + |V_d^T a1|^2 (V_d is
+  // lower-triangular like q_sqrt_d), so the chain skips a = Lu^-T a1 (layers.py:188): one of 2 + D_out triangular products per row
+  // block, a third of the MFMA work of a D_out = 1 layer.  The training pass keeps `a` (the reverse pass is written in terms of it).
+  // Mp <= 256: the larger instances read the factor transposed, which exists for q_sqrt only.
+  const bool wf_ok = !m->desc.white && !save && m->force.white_fwd != 0;
+  if (wf_ok) DS_TRY(join_prep(m));          // V, nL come from the parameter products (side stream in the overlapped schedule)
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -1856,10 +1871,12 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     const int rep = (l == 0) ? S : 1;
     const bool last = (l == L - 1);
     const bool want_F = !last || need_last_F;
+    const bool wf = wf_ok && v.Mp <= 256;
     LayerFwdArgs a{};
     a.X = Xin; a.Rin = Rin; a.rep = rep;
     a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
     a.Zp = v.Zp; a.Zs = v.Zs; a.hyp = v.hyp; a.LinvT = v.LinvT; a.Linv = v.Linv; a.Tp = v.Tp; a.TpT = v.TpT; a.qmu = v.qmu;
+    if (wf) { a.Tp = v.V; a.qmu = v.nL; a.qmu_ld = v.DP4; }
     a.mean_kind = St.d.mean_kind; a.mean_A = St.meanA; a.mean_b = St.meanb;
     a.jitter = m->desc.jitter;
     a.n_inner = n;
@@ -1896,7 +1913,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
         *lik_nblocks = (int)nblk * a.d_split;
       }
     }
-    DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white));
+    DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white || wf));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
     if (St.prop && !last) {

@@ -174,3 +174,31 @@ def test_gram_into_a_wider_buffer(ctx):
     got = dout.cpu().numpy()
     assert_allclose(got[:, :n2], k.K(O.NP, X, X2), rtol=1e-11, atol=1e-13)
     assert np.all(got[:, n2:] == 7.0)
+
+
+# ---------------------------------------------------------------- forward-only evaluations in whitened coordinates
+@pytest.mark.parametrize("M,L", [(24, 2), (128, 3), (200, 2)])
+def test_forward_only_whitened_form_equals_plain_form(monkeypatch, M, L):
+    """predict / ELBO-value evaluations of a non-white model skip a = Lu^-T a1 (mean = a1^T Lu^-1 q_mu, var through Lu^-1 q_sqrt_d);
+    DSDGP_FORCE=white_fwd=0 keeps the plain form: same layer outputs to rounding, and both equal the oracle."""
+    rng = np.random.RandomState(M)
+    N, D, S = 150, 4, 3
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[rng.permutation(N)[:min(M, N)]] + 0.05 * rng.randn(min(M, N), D) if M <= N else rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.2, 0.9)] + [kern_spec("matern52", D, 0.9, 1.1)] * (L - 1)
+    zs = [rng.randn(S, N, D)] * (L - 1) + [rng.randn(S, N, 2)]
+    outs = []
+    for force in ("white_fwd=1", "white_fwd=0"):
+        monkeypatch.setenv("DSDGP_FORCE", force)
+        spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=N)
+        Fs, Fm, Fv = model.propagate(X, S=S, zs=zs)
+        e = model._build_likelihood(X, Y, zs=zs)
+        outs.append((Fs, Fm, Fv, e))
+    for l in range(L):
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert_allclose(a[l], b[l], rtol=1e-11, atol=1e-12)
+    assert_allclose(outs[0][3], outs[1][3], rtol=1e-12)
+    _, Fm_o, Fv_o = OM.propagate(spec, state, X, zs, S)
+    assert_allclose(outs[0][1][-1], Fm_o[-1], rtol=1e-9, atol=1e-11)
+    assert_allclose(outs[0][2][-1], Fv_o[-1], rtol=1e-9, atol=1e-11)
+    assert_allclose(outs[0][3], OM.elbo(spec, state, X, Y, zs, S, num_data=N), rtol=1e-10)
