@@ -98,7 +98,6 @@ struct LayerBwdArgs {
   const double* up_var;        // this layer's variances (Rin x D_out)
   double up_jitter;
   double *MBw, *VBw;           // = MB / VB, writable
-  hipEvent_t done_event;       // host side only: event attached to this launch's completion (hipExtLaunchKernel), or NULL
 };
 // whether the backward chain of this shape can take the adjoint prologue (its LDS reduction scratch holds 2 x 16 x D_out partials)
 int sm_adj_fusable(int Mp, int64_t nblk, int D_in, int D_out);
@@ -120,7 +119,7 @@ struct WgradJob {
 
 // jobs_dev: device copy of `njobs` jobs with task_start filled (64 x 64 tiles, one workgroup per (job, split, tile) task)
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                 hipStream_t stream = nullptr, hipEvent_t done = nullptr);
+                 hipStream_t stream = nullptr);
 // chain kernels (layer_sm.hip): the NW waves of a workgroup cooperate on one block of 16 rows
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);

@@ -12,7 +12,6 @@
 // Wide inputs (D_in > 64, e.g. the 784-pixel first MNIST layer) stage x/l through LDS in 64-column chunks.
 #pragma once
 #include <stdlib.h>
-#include <hip/hip_ext.h>
 
 #include "layer.hpp"
 
@@ -1184,12 +1183,8 @@ static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
   ProfScope ps(ctx, "layer_bwd");
   static const bool timing = getenv("DSDGP_BWD_TIMING") != nullptr;
   if (timing) return bwd_phase_timing<MPB, NW, KIND, WHITE, WIDE, CS>(ctx, a, L, lds);
-  if (a.done_event)
-    hipExtLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64),
-                          (uint32_t)lds, ctx->stream, nullptr, a.done_event, 0, a, L);
-  else
-    hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds,
-                       ctx->stream, a, L);
+  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds,
+                     ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

@@ -89,8 +89,7 @@ struct LayerState {
   // product) read only what the FORWARD chain and the producer of this layer's upstream adjoints left, so they can start before this
   // layer's backward chain; the B jobs (E A^T, GW [X|1]^T) read the backward chain's outputs.  wjB = the B jobs with their own task
   // numbering (launched alone when A went ahead).
-  WgradJob *wj, *wjB;
-  int njobsA = 0, totA = 0, njobsB = 0, totB = 0;
+  WgradJob* wj;
   int ns_big, ns_thin, tot_big, tot_thin;
   // z actually used by the last forward (for the backward pass)
   const double* z_used;
@@ -162,9 +161,11 @@ struct dsdgp_model {
   // DSDGP_FORCE="key=value,...": test hooks that force the large-launch variants onto small, oracle-checkable shapes (read when
   // the model is created).  save_c: Csave backward chain 0 never / 1 for Mp > 256 / 2 every size with an instance (thresholds
   // cs_min_blocks, cs_min_dout); alg_g: algebraic dl/dKu assembly -1 heuristic / 0 never / 1 always; bwd_split: d-split of the
-  // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; early_wgrad: A jobs ahead of the backward chain 0 / 1;
-  // pipe_tail: per-layer reduction + P_d T_d products behind each layer's weight-gradient products 0 / 1.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, early_wgrad = 0, pipe_tail = 0, head = 1, tail = 1, ns_cap = 4096, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1; } force;
+  // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; pipe_tail: per-layer reduction + P_d T_d products behind each layer's
+  // weight-gradient products 0 / 1; head / tail / adj_fuse / lik_fuse = 0: the unfused launches (parity tests of the fusions);
+  // ext_ev = 0: plain event record behind the head launch; red_ahead = 0: one split-K reduction after the stream join;
+  // white_fwd = 0: forward-only evaluations in plain coordinates.
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -186,11 +187,9 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "bwd_split") m->force.bwd_split = v;
       else if (k == "red_ahead") m->force.red_ahead = v;
       else if (k == "white_fwd") m->force.white_fwd = v;
-      else if (k == "early_wgrad") m->force.early_wgrad = v;
       else if (k == "pipe_tail") m->force.pipe_tail = v;
       else if (k == "head") m->force.head = v;
       else if (k == "tail") m->force.tail = v;
-      else if (k == "ns_cap") m->force.ns_cap = v;
       else if (k == "adj_fuse") m->force.adj_fuse = v;
       else if (k == "ext_ev") m->force.ext_ev = v;
       else if (k == "lik_fuse") m->force.lik_fuse = v;
@@ -367,7 +366,6 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.bcnt = b.take<int>(512);
     S.lq = b.take<GemmProblem>(12);
     S.wj = b.take<WgradJob>(d.D_out + 4);
-    S.wjB = b.take<WgradJob>(4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
   }
@@ -1961,7 +1959,6 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const double dfrac = (NI + 1) / (2.0 * NI);
     int ns = choose_nsplit((v.alg_g ? 0 : ti * ti) + v.D_out * n_off + (int)ceil(v.D_out * ti * dfrac), nch, 512);
     if (ns > St.nsplit_big_max) ns = St.nsplit_big_max;
-    if (ns > m->force.ns_cap) ns = m->force.ns_cap;
     St.ns_big = ns;
     St.ns_thin = ns;
     const int ns_diag = std::max(1, (int)ceil(ns * dfrac));
@@ -2009,9 +2006,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     startB += ns * ti * tjz;
     redB.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
     redB.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, (int)sm_hyp_parts(ld, v.Mp, v.D_in), 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
-    St.njobsA = (int)jobsA.size(); St.totA = startA;
-    St.njobsB = (int)jobsB.size(); St.totB = startB;
-    // combined list [A | B] with cumulative task numbers (one launch when nothing is overlapped)
+    // one list [A | B] with cumulative task numbers: one launch per layer
     std::vector<WgradJob> jobs(jobsA);
     for (WgradJob J : jobsB) {
       J.task_start += startA;
@@ -2028,7 +2023,6 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
-    DS_HIP(hipMemcpyAsync(St.wjB, jobsB.data(), jobsB.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
   int blocks = 0;
@@ -2088,7 +2082,6 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool overlap = overlap_on(m, n, S);
   DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
-  const bool early = overlap && m->force.early_wgrad != 0;
   // data-parallel buckets: every layer's reduction, products, assembly and hyper-parameter gradients right behind its weight-gradient
   // products, then the caller's collective on that layer's segment of the gradient, on the stream the segment was produced on — the
   // exchange of the upper layers runs under the lower layers' backward chains (dsdgp_model_set_bucket_callback)
@@ -2117,16 +2110,10 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     }
     return DSDGP_OK;
   };
-  bool a_done[DSDGP_MAX_LAYERS] = {false};
-  // which: 1 = A jobs, 2 = B jobs, 3 = all
-  auto launch_wgrad = [&](LayerState& Sx, int which, hipStream_t st, hipEvent_t done = nullptr) -> int {
+  auto launch_wgrad = [&](LayerState& Sx, hipStream_t st) -> int {
     const int64_t ldx = Sx.ld_used;
-    if (which == 1) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st, done);
-    if (which == 2) return wgrad_launch(ctx, Sx.wjB, Sx.njobsB, Sx.totB, Sx.ns_big, ldx, ldx, st, done);
-    return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st, done);
+    return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st);
   };
-  const bool ext = m->force.ext_ev >= 2;      // (measured: +3 us when the chain / weight-gradient launches carry their events; -2.5 us for k_head alone)
-  bool side_marked = false;      // ev_side already rides on the side stream's last launch
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -2179,31 +2166,20 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
-    const bool to_side = overlap && !on_main;
-    b.done_event = (to_side && ext) ? m->ev_bwd[l] : nullptr;
     DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
-      DS_TRY(launch_wgrad(St, 3, ctx->stream));
+      DS_TRY(launch_wgrad(St, ctx->stream));
       if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
       continue;
     }
-    // ONE event per chain boundary (an event record costs the recording stream a few microseconds): behind it the side stream takes
-    // the A jobs of the NEXT layer first — its adjoints came out of this chain and its products are the large ones — then this
-    // layer's B jobs (or all of its jobs when its A jobs did not go ahead)
+    // ONE event per chain boundary (an event record costs the recording stream ~6 us): behind it the side stream takes this layer's
+    // products, which then run under the NEXT layer's backward chain.  Measured slower and removed in round 3: the products of a layer
+    // ahead of its own chain's end (they need only the upstream adjoints), completion events attached to the chain / product launches
+    // (hipExtLaunchKernelGGL: +3 us), a cap on the split count.
     hipStream_t ss = m->side;
-    if (!ext) DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
+    DS_HIP(hipEventRecord(m->ev_bwd[l], ctx->stream));
     DS_HIP(hipStreamWaitEvent(ss, m->ev_bwd[l], 0));
-    const int nl = l - 1;
-    if (early && nl >= gfirst && nl >= 1 && !(nl == gfirst && L - gfirst > 1)) {
-      LayerState& Sn = m->L[nl];
-      DS_TRY(launch_wgrad(Sn, 1, ss));
-      a_done[nl] = true;
-    }
-    // the side stream's last launch of the pass carries the join event
-    const bool last_side = ext && !pipelined && m->tail_ok && (l == gfirst || (l == gfirst + 1 && L - gfirst > 1));
-    if (a_done[l]) DS_TRY(launch_wgrad(St, 2, ss, last_side ? m->ev_side : nullptr));
-    else DS_TRY(launch_wgrad(St, 3, ss, last_side ? m->ev_side : nullptr));
-    side_marked = side_marked || last_side;
+    DS_TRY(launch_wgrad(St, ss));
     if (pipelined) DS_TRY(layer_tail(St, ss));
   }
   // the lowest layer's products ran on the main stream: its split-K reduction goes ahead of the join, so that the side stream's
@@ -2219,7 +2195,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // weight-gradient launches: its single workgroup was observed to sit for > 1 ms behind the co-running large-M chain, and
     // everything queued behind it on this stream waited with it
     if (!m->fin.done && !m->tail_ok) DS_TRY(launch_finalize(m, m->side));
-    if (!side_marked) DS_HIP(hipEventRecord(m->ev_side, m->side));
+    DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
 
   }

@@ -2,7 +2,6 @@
 // q_sqrt, q_mu, Z: sums over the rows of the minibatch x samples) on gfx950 fp64 MFMA.
 #include "layer.hpp"
 #include <stdlib.h>
-#include <hip/hip_ext.h>
 
 // out = P diag(scale) Q^T with P (rowsP x R), Q (rowsQ x R) both M-major.  Operands go straight from L2 / Infinity Cache to MFMA
 // registers: each lane loads 4 consecutive r (32 B) of one row, and the t-th of them is the k-operand of the t-th MFMA, so a
@@ -150,14 +149,11 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
 }
 
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,
-                 hipStream_t stream, hipEvent_t done) {
+                 hipStream_t stream) {
   if (total_tasks <= 0) return DSDGP_OK;
   hipStream_t st = stream ? stream : ctx->stream;
   ProfScope ps(ctx, "wgrad", st);
-  if (done)     // the event rides on this launch's completion signal (no marker packet behind it)
-    hipExtLaunchKernelGGL((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, nullptr, done, 0, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
-  else
-    hipLaunchKernelGGL((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
+  hipLaunchKernelGGL((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

@@ -1,5 +1,5 @@
-"""-m gpu tests added in round 3: the reverse pass's stream schedule (weight-gradient products of a layer launched UNDER that
-layer's backward chain, per-layer pipelined tail), the fused head kernel, the small-matrix GEMM path, the blocked / batched
+"""-m gpu tests added in round 3: the reverse pass's stream schedule (weight-gradient products of a layer under the next layer's
+backward chain, per-layer pipelined tail, reduction ahead of the join), the fused head kernel, the small-matrix GEMM path, the blocked / batched
 triangular solve and the fused tail.  Every schedule variant must reproduce the serial schedule bit for bit (all reductions on
 the path are fixed-order); values are compared with the oracle elsewhere (tests/test_gpu_parity.py).
 """
@@ -57,21 +57,21 @@ def _train_state(monkeypatch, force, no_overlap, steps=12, white=False):
 
 @pytest.mark.parametrize("white", [False, True])
 def test_reverse_pass_schedules_are_bitwise_neutral(monkeypatch, white):
-    """serial (one stream) == weight-gradient products behind their chain == A jobs under their chain == + pipelined tail."""
-    ref = _train_state(monkeypatch, "early_wgrad=0,pipe_tail=0", True, white=white)
+    """serial (one stream) == weight-gradient products under the next chain == + per-layer pipelined tail == reduction after / ahead
+    of the stream join == plain event record behind the head launch."""
+    ref = _train_state(monkeypatch, "pipe_tail=0", True, white=white)
     assert np.isfinite(ref[0])
-    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=0", "early_wgrad=1,pipe_tail=1", "early_wgrad=0,pipe_tail=1",
-                  "red_ahead=0", "red_ahead=1,ext_ev=0"):
+    for force in ("pipe_tail=0", "pipe_tail=1", "red_ahead=0", "red_ahead=1,ext_ev=0"):
         got = _train_state(monkeypatch, force, False, white=white)
         assert got[0] == ref[0], force
         assert np.array_equal(got[1], ref[1]), force
         assert np.array_equal(got[2], ref[2]), force
 
 
-def test_early_wgrad_with_pruned_reverse_pass(monkeypatch):
+def test_pipelined_tail_with_pruned_reverse_pass(monkeypatch):
     """grad_from_layer > 0 (NatGradOptimizer's var_list): the schedule variants agree on the entries of the participating layers."""
     outs = []
-    for force in ("early_wgrad=0,pipe_tail=0", "early_wgrad=1,pipe_tail=1"):
+    for force in ("pipe_tail=0", "pipe_tail=1"):
         monkeypatch.setenv("DSDGP_FORCE", force)
         rng = np.random.RandomState(9)
         N, D, M, S = 800, 4, 128, 12
@@ -202,3 +202,24 @@ def test_forward_only_whitened_form_equals_plain_form(monkeypatch, M, L):
     assert_allclose(outs[0][1][-1], Fm_o[-1], rtol=1e-9, atol=1e-11)
     assert_allclose(outs[0][2][-1], Fv_o[-1], rtol=1e-9, atol=1e-11)
     assert_allclose(outs[0][3], OM.elbo(spec, state, X, Y, zs, S, num_data=N), rtol=1e-10)
+
+
+def test_chain_prologue_and_epilogue_fusions_equal_their_kernels(monkeypatch):
+    """the first layer's upstream adjoints inside its backward chain's prologue (adj_fuse) and the Gaussian variational expectations
+    with their adjoints inside the last forward chain's epilogue (lik_fuse) against the separate launches k_adj_prep / k_lik_gauss:
+    same ELBO and gradient up to the order of a few sums."""
+    rng = np.random.RandomState(11)
+    N, D, M, S = 900, 5, 64, 16
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.05 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("matern52", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
+    outs = []
+    for force in ("adj_fuse=1,lik_fuse=1", "adj_fuse=0,lik_fuse=1", "adj_fuse=1,lik_fuse=0", "adj_fuse=0,lik_fuse=0"):
+        monkeypatch.setenv("DSDGP_FORCE", force)
+        _, _, model = make_case(X, Y, Z, specs, S=S, num_data=5 * N, q_sqrt_scale=1e-2)
+        e = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+        outs.append((e, model.engine().grad.cpu().numpy().copy()))
+    for e, g in outs[1:]:
+        assert_allclose(e, outs[0][0], rtol=1e-13)
+        assert np.max(np.abs(g - outs[0][1])) <= 1e-11 * np.max(np.abs(outs[0][1]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of DSDGP_FORCE settings (read when a model is created) on one BASELINE config shape, in ONE process:
-    python tools/ab_force.py 2 "early_wgrad=0" "early_wgrad=1" "early_wgrad=1,pipe_tail=1"
+    python tools/ab_force.py 2 "pipe_tail=0" "pipe_tail=1" "red_ahead=0"
 prints ms/step (best and all of three batches) per setting, interleaved twice so that clock drift shows."""
 import json
 import os
