@@ -18,6 +18,7 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
 // ------------------------------------------------------------------------------------------------------
 struct LayerDev {
   int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, hyp_parts;   // rows of hyp2part per backward: > 0 written by k_asm_kbar (folded), < 0: -NPART rows by k_asm_hyp_part
+  int32_t kl_parts, pad_kl;       // partial sums k_kl_part leaves in klpart (the launch's block columns)
   int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
   double *Zp, *Zs, *hyp, *Tp, *TpT, *qmu, *qmu4;
   double *Kp, *Linv, *LinvT, *Kinv, *scal;
@@ -592,14 +593,36 @@ __global__ __launch_bounds__(256) void k_kl_part(const LayerDev* __restrict__ la
   const double tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) v.klpart[blockIdx.x] = tot;
 }
-__global__ void k_kl_final(const LayerDev* __restrict__ layers, int L, int nparts) {
-  const int l = threadIdx.x;
-  if (l >= L) return;
-  const LayerDev v = layers[l];
-  double kl = -0.5 * v.D_out * v.M;                                     // layers.py:234
-  for (int b = 0; b < nparts; ++b) kl += v.klpart[b];
-  if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                        // layers.py:238 (sum log diag Lu = logdet/2)
-  v.klv[0] = kl;
+// KL of every layer from the partial sums of k_kl_part, by ALL 256 threads of the workgroup that forms the ELBO value (k_tail /
+// k_finalize): the loads of all layers first, then one fixed-order block reduction per layer.  (A launch of its own for this sat on
+// the side stream of every step: k_kl_final, 4.5 us + a launch boundary; one thread walking the partials serially cost the tail 7 us.)
+// Returns sum_l KL_l (valid in thread 0) and leaves KL_l in klv[0] of each layer.
+__device__ __forceinline__ double layers_kl_value(const LayerDev* __restrict__ layers, int L, double* sh) {
+  double tot = 0.0;
+  for (int l0 = 0; l0 < L; l0 += 4) {         // four layers' loads in flight, then their reductions
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = 0.0;
+      if (l0 + u < L)
+        for (int b = threadIdx.x; b < layers[l0 + u].kl_parts; b += 256) x[u] += layers[l0 + u].klpart[b];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (l0 + u < L) {
+        const LayerDev& v = layers[l0 + u];
+        double kl = block_sum_256(x[u], sh) - 0.5 * v.D_out * v.M;          // layers.py:234
+        if (!v.white) kl += 0.5 * v.D_out * v.scal[0];                      // layers.py:238 (sum log diag Lu = logdet/2)
+        if (threadIdx.x == 0) v.klv[0] = kl;
+        tot += kl;
+      }
+  }
+  return tot;
+}
+// (dsdgp_model_layer_kl only)
+__global__ __launch_bounds__(256) void k_kl_final(const LayerDev* __restrict__ layers, int L) {
+  __shared__ double sh[4];
+  layers_kl_value(layers, L, sh);
 }
 
 // [UPSTREAM] Gaussian.variational_expectations (dgp.py:89-90) and its adjoints w.r.t. the last layer's mean/var.
@@ -720,12 +743,11 @@ __global__ __launch_bounds__(256) void k_finalize(const LayerDev* __restrict__ l
   }
   a = block_sum_256(a, sh);
   b = block_sum_256(b, sh);
+  const double kl = layers_kl_value(layers, L, sh);
   if (threadIdx.x == 0) {
-    double kl = 0.0, info = 0.0;
-    for (int l = 0; l < L; ++l) {
-      kl += layers[l].klv[0];
+    double info = 0.0;
+    for (int l = 0; l < L; ++l)
       if (layers[l].scal[1] != 0.0 && info == 0.0) info = layers[l].scal[1];
-    }
     out[0] = w * a - kl_weight * kl;
     out[1] = w * a;
     out[2] = kl_weight * kl;   // weighted like out[0]: the data-parallel SUM over ranks (kl_weight = 1/world) is then KL itself
@@ -1368,12 +1390,11 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
     }
     a = block_sum_256(a, sh);
     c = block_sum_256(c, sh);
+    const double kl = layers_kl_value(layers_all, F.L, sh);
     if (threadIdx.x == 0) {
-      double kl = 0.0, info = 0.0;
-      for (int l = 0; l < F.L; ++l) {
-        kl += layers_all[l].klv[0];
+      double info = 0.0;
+      for (int l = 0; l < F.L; ++l)
         if (layers_all[l].scal[1] != 0.0 && info == 0.0) info = layers_all[l].scal[1];
-      }
       F.out[0] = F.w * a - F.kl_weight * kl;
       F.out[1] = F.w * a;
       F.out[2] = F.kl_weight * kl;
@@ -1591,6 +1612,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     const bool fold = v.D_in <= WIDE_DIN && (int64_t)m->kuu_blocks * 256 >= (int64_t)v.Mp * v.Mp;
     v.hyp_parts = m->tail_ok ? v.M : (fold ? m->kuu_blocks : -NPART);      // fused tail: one partial row per inducing row (k_asm_rows)
     ld[l].hyp_parts = v.hyp_parts;
+    v.kl_parts = ld[l].kl_parts = m->mp_max_all >= 512 ? 512 : NPART;       // = the grid of k_kl_part (prepare_async)
     if (!fold) m->need_hyp_part = true;
   }
   m->head_ok = m->force.head != 0 && !m->uniform_big;
@@ -1776,7 +1798,6 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
     hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
   }
-  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, st, m->layers_dev, L, klb);
   DS_HIP(hipGetLastError());
   if (with_grad && !m->desc.white) {
     if (lq >= 0) {
@@ -2478,6 +2499,8 @@ extern "C" int dsdgp_model_theta_changed(dsdgp_model* m) {
 extern "C" int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out) {
   DS_CHECK_ARG(m && out && l >= 0 && l < m->desc.L);
   if (!m->prepared) DS_TRY(prepare_async(m));
+  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(256), 0, m->ctx->stream, m->layers_dev, m->desc.L);
+  DS_HIP(hipGetLastError());
   DS_HIP(hipMemcpyAsync(out, m->L[l].dev.klv, sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
   return DSDGP_OK;
 }
