@@ -373,8 +373,12 @@ __global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restric
 
 // Launches whose largest problem is at least GEMM_BIG_MIN in both output dimensions take the 128 x 128 kernel; the planned
 // tile count carries the choice in GEMM_BIG_FLAG / GEMM_SMALL_FLAG so that every call site keeps passing plan -> launch unchanged.
+// Round 3 re-measured the threshold (512 since round 2): the 64 x 64 kernels win up to 1024 — a single 1024^3 product is 64 tiles of 128 x 128
+// on 256 CUs (200 us) against 256 tiles of 64 x 64 (93 us); batched D_out x 1024^3 products with triangular / symmetric hints lose less
+// to the hints' tile granularity (config 5: gemm 5.10 -> 4.30 ms per step, config 4: 1.74 -> 1.63); from 2048 the large tile leads
+// (2048^3: 43 TFLOP/s, 4096 x 4096 x 256: 49).
 #define GEMM_BIG_FLAG (1 << 30)
-#define GEMM_BIG_MIN 512
+#define GEMM_BIG_MIN 2048
 // Launches whose every problem is short in k (<= GEMM_SMALL_K, whole 16-blocks, 32-byte aligned rows) take the LDS-free kernel.
 #define GEMM_SMALL_FLAG (1 << 29)
 #define GEMM_SMALL_K 256

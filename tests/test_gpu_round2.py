@@ -299,10 +299,10 @@ def test_gram_paired_store_path(ctx, n, n2, D):
 
 
 @pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("m,n,k", [(512, 512, 512), (600, 520, 300), (1024, 513, 77), (700, 1030, 1024)])
+@pytest.mark.parametrize("m,n,k", [(512, 512, 512), (600, 520, 300), (1024, 513, 77), (700, 1030, 1024), (2048, 2100, 96), (2050, 2048, 130)])
 def test_gemm_large_tile_kernel(ctx, tA, tB, m, n, k):
-    """dsdgp_gemm with both output dimensions >= 512 runs the 128 x 128 double-buffered kernel (k_gemm_big): ragged edges,
-    every transpose combination, alpha / beta."""
+    """dsdgp_gemm around the kernel switch: up to 1024 the 64 x 64 kernels, with both output dimensions >= 2048 the 128 x 128
+    double-buffered kernel (k_gemm_big); ragged edges, every transpose combination, alpha / beta."""
     from doubly_stochastic_dgp import _lib
     rng = np.random.RandomState(m + n + k + tA + 2 * tB)
     A = rng.randn(*((k, m) if tA else (m, k)))
