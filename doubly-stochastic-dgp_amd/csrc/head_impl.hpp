@@ -162,7 +162,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const double* __restrict_
   }
   const LayerDev v = layers[l];
   if (bx > 0)
-    prep_body(v, theta, lik_const, off_lik, lik_gauss, bx - 1, nprep);
+    prep_body<false>(v, theta, lik_const, off_lik, lik_gauss, bx - 1, nprep);
   else if (!keep_kuu)                 // keep_kuu: the factor of the unchanged Ku stays in place (dsdgp_model_track_theta)
     head_factor(v, theta, jitter, white, timing, head_dyn);
 }

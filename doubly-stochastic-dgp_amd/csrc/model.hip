@@ -380,6 +380,9 @@ __device__ __forceinline__ double softplus_d(double x) { return x > 0 ? x + log1
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // parameter transforms + padding (LowerTriangular / positive transforms of layers.py:150 and [UPSTREAM] kernels)
+// WAVE_TILES: k_prep_kuu (256 threads, large models); the head launch (512 threads, M <= 128, its LDS is the factorisation's) takes
+// the one-tile-per-workgroup form with the small buffer
+template <bool WAVE_TILES>
 __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, double* __restrict__ lik_const, int64_t off_lik,
                           int lik_gauss, int bx, int nprep) {
   const int tid0 = bx * blockDim.x + threadIdx.x, nth = nprep * blockDim.x;
@@ -419,7 +422,36 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
   }
   if (v.need_tpt) {
     // padded factor and its transpose, 16 x 16 tiles through LDS: both stores run along rows (the element-wise form stored the
-    // transpose with stride Mp — 8 M scattered 8-byte stores per layer at M = 1024, D_out = 8: most of this launch's 195 us)
+    // transpose with stride Mp — 8 M scattered 8-byte stores per layer at M = 1024, D_out = 8: most of this launch's 195 us).
+    // ONE TILE PER WAVE (lane = row lane / 4, four columns): the transposition is wave-private, no workgroup barrier, and the
+    // loads of the next tile are in flight while this one is stored.
+    if constexpr (WAVE_TILES) {
+    __shared__ double tt[4][16][17];
+    const int nt = Mp / 16, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tr = lane >> 2, tc = (lane & 3) * 4;
+    const int64_t ntile = (int64_t)v.D_out * nt * nt;
+    for (int64_t tile = (int64_t)bx * 4 + wave; tile < ntile; tile += (int64_t)nprep * 4) {
+      const int d = (int)(tile / (nt * nt)), rem = (int)(tile % (nt * nt)), i0 = (rem / nt) * 16, j0 = (rem % nt) * 16;
+      const int i = i0 + tr;
+      double t4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + tc + u;
+        const bool in = i < M && j <= i;
+        t4[u] = in ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v.Tp[((int64_t)d * Mp + i) * Mp + j0 + tc + u] = t4[u];
+        tt[wave][tr][tc + u] = t4[u];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's LDS stores have landed (wave-private tile: no barrier)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v.TpT[((int64_t)d * Mp + j0 + tr) * Mp + i0 + tc + u] = tt[wave][tc + u][tr];
+      __builtin_amdgcn_wave_barrier();
+    }
+    } else {
     __shared__ double tt[16][17];
     const int nt = Mp / 16, ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
     for (int tile = bx; tile < v.D_out * nt * nt; tile += nprep) {
@@ -432,6 +464,7 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
       if (on) tt[ti][tj] = t;
       __syncthreads();
       if (on) v.TpT[((int64_t)d * Mp + j0 + ti) * Mp + i0 + tj] = tt[tj][ti];
+    }
     }
   } else {
     for (int idx = tid0; idx < v.D_out * Mp * Mp; idx += nth) {
@@ -493,7 +526,7 @@ __global__ __launch_bounds__(256) void k_prep_kuu(const double* __restrict__ the
                                                   int nprep, int keep_kuu) {
   const LayerDev v = layers[blockIdx.y];
   if ((int)blockIdx.x < nprep)
-    prep_body(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x, nprep);
+    prep_body<true>(v, theta, lik_const, off_lik, lik_gauss, blockIdx.x, nprep);
   else if (!keep_kuu)                 // keep_kuu: the factor of the unchanged Ku stays in place (dsdgp_model_track_theta)
     kuu_body(v, theta, jitter, blockIdx.x - nprep, gridDim.x - nprep);
 }
