@@ -93,3 +93,39 @@ def test_shard_terms_and_rank_streams():
     i0, i1 = models[0]._minibatch.next_indices(), models[1]._minibatch.next_indices()
     assert not np.array_equal(i0, i1)                  # ranks draw different minibatches
     assert models[0]._dist[0] == 0 and models[1]._dist[1] == 2
+
+
+def test_exchange_form_is_chosen_by_gradient_size():
+    """attach(bucketed=None): flat all-reduce below BUCKET_MIN_BYTES of gradient, per-layer buckets above (world > 1 only);
+    an explicit bucketed=True / False overrides.  Exercised with stand-ins for the engine: no GPU, no process group."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "doubly-stochastic-dgp_amd"))
+    from doubly_stochastic_dgp import distributed as D
+
+    class FakeLib:
+        def __init__(self):
+            self.installed = 0
+
+        def dsdgp_model_set_bucket_callback(self, model, fn, user):
+            self.installed += 1
+            return 0
+
+    class FakeEng:
+        def __init__(self, n_theta):
+            self.n_theta, self.lib, self.model = n_theta, FakeLib(), C.c_void_p(1234)
+
+    class FakeModel:
+        minibatch_size = None
+
+    small, big = (D.BUCKET_MIN_BYTES // 8) - 1, D.BUCKET_MIN_BYTES // 8
+    for world, bucketed, n_theta, want in [(2, None, small, 0), (2, None, big, 1), (1, None, big, 0), (2, True, small, 1),
+                                           (2, False, big, 0), (8, None, 283783, 0), (8, None, 25_000_000, 1)]:
+        m = FakeModel()
+        D.attach(m, 0, world, bucketed=bucketed)
+        eng = FakeEng(n_theta)
+        m._dist_before_elbo(eng)
+        assert eng.lib.installed == want, (world, bucketed, n_theta)
+        assert m._dist_buckets()["on"] == bool(want)
+        m._dist_before_elbo(eng)                       # a second evaluation on the same device model does not re-install
+        assert eng.lib.installed == want
