@@ -74,7 +74,6 @@ struct LayerState {
   int prop;
   double *part_big, *part_thin, *hyp_part;
   int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
-  int red_nA = 0, red_blknA = 0;                            //   of which the leading red_nA jobs / red_blknA blocks belong to the A jobs
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
@@ -86,10 +85,9 @@ struct LayerState {
   // step on this layer alone: the other layers' S_d / U_d / ... are still those of the previous evaluation)
   GemmProblem* lq = nullptr;
   int lq_nf = 0, lq_tf = 0, lq_n1 = 0, lq_t1 = 0, lq_n2 = 0, lq_t2 = 0, lq_np = 0, lq_tp = 0;   // forward / U, n, KS / U U^T / P_d T_d, GS_d
-  // weight-gradient jobs, rebuilt when (n, S) changes.  wj = [A | B]: the A jobs (P_d = A diag(vbar_d) A^T, A mbar^T, the mean-function
-  // product) read only what the FORWARD chain and the producer of this layer's upstream adjoints left, so they can start before this
-  // layer's backward chain; the B jobs (E A^T, GW [X|1]^T) read the backward chain's outputs.  wjB = the B jobs with their own task
-  // numbering (launched alone when A went ahead).
+  // weight-gradient jobs of ONE launch per layer, rebuilt when (n, S) changes: [A | B] — the A jobs (P_d = A diag(vbar_d) A^T, A mbar^T,
+  // the mean-function product) read what the forward chain and the producer of this layer's upstream adjoints left, the B jobs
+  // (E A^T, GW [X|1]^T) the backward chain's outputs
   WgradJob* wj;
   int ns_big, ns_thin, tot_big, tot_thin;
   // z actually used by the last forward (for the backward pass)
@@ -2070,7 +2068,6 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     St.tot_big = startA + startB;
     St.tot_thin = 0;
     St.red_off = (int)red.size();
-    St.red_nA = (int)redA.size();
     red.insert(red.end(), redA.begin(), redA.end());
     red.insert(red.end(), redB.begin(), redB.end());
     St.red_n = (int)red.size() - St.red_off;
@@ -2096,7 +2093,6 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     LayerState& St = m->L[l];
     auto blk_at = [&](int idx) { return idx < (int)red.size() ? red[idx].blk_start : blocks; };
     St.red_blk0 = blk_at(St.red_off);
-    St.red_blknA = blk_at(St.red_off + St.red_nA) - St.red_blk0;
     St.red_blkn = blk_at(St.red_off + St.red_n) - St.red_blk0;
   }
   if ((int)red.size() > m->rjobs_cap) {
@@ -2122,11 +2118,11 @@ static int launch_finalize(dsdgp_model* m, hipStream_t st) {
 }
 
 // Reverse pass.  Streams (when the launches are long enough to pay for cross-stream events, overlap_on):
-//   main : [adjoint prep] backward chain L-1, L-2, ..., gfirst | join | gradient assembly
-//   side : A jobs of layer l as soon as its upstream adjoints exist — i.e. UNDER the backward chain of layer l (the P_d products read
-//          the forward chain's A and the adjoints only; they are 95 % of the weight-gradient flops and fill the MFMA pipe while the
-//          chain's workgroups sit in their load / reduction phases and in the launch's tail) — then the B jobs behind that chain, then
-//          (pipelined tail) this layer's split-K reduction and its P_d T_d / GS_d products.
+//   main : backward chain L-1, L-2, ..., gfirst, the weight-gradient products of layer gfirst, its split-K reduction | join | the
+//          other layers' reduction, P_d T_d / GS_d products, gradient assembly, value + Adam
+//   side : the weight-gradient products of layer l behind an event at the end of ITS backward chain, i.e. under the chain of layer
+//          l - 1 (they fill the MFMA pipe while that chain's workgroups sit in their load / reduction phases and in the launch's
+//          tail); with the pipelined tail (data-parallel buckets) also that layer's reduction, products and assembly.
 // Every reduction is fixed-order, so the schedule does not change a bit of the result (tests/test_gpu_parity.py:
 // test_stream_overlap_is_bitwise_neutral, tests/test_gpu_round3.py).
 static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {

@@ -10,7 +10,7 @@
 //    the B-operand layout of the next, so nothing goes through LDS and no wave waits for another; thousands of waves in flight at
 //    the right-hand-side counts of the layer (nrhs = S N = 20 000 at config 2);
 //  * between panels the remaining rows take B_rest -= L_rest,panel X_panel as ONE grouped MFMA GEMM launch per panel (all matrices
-//    of the batch in it; 128 x 128 tiles from 512 rows) — for n > 128 that is where the n^2 nrhs flops are.
+//    of the batch in it; the LDS-free 64 x 64 kernel at K = 128) — for n > 128 that is where the n^2 nrhs flops are.
 // Flop count = n^2 nrhs per matrix (the triangular count; bench.py `sub_rooflines.trsm` quotes it against the 78.6 TFLOP/s peak).
 #include <vector>
 
