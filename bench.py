@@ -43,15 +43,16 @@ def layer_shapes(cfg):
     return [(mb, D, D), (S * mb, D, D), (S * mb, D, 1)]
 
 
-def algorithmic_flops(cfg):
+def algorithmic_flops(cfg, shapes=None):
     """SURVEY §8d contract figures, per kernel class and per step (non-white, w=2)."""
     M = cfg["M"]
     fwd, wg = [], []
-    for R, Din, Dout in layer_shapes(cfg):
+    shapes = shapes or layer_shapes(cfg)
+    for R, Din, Dout in shapes:
         f = M * R * (2 * Din + 4) + 2 * M * M * R + 2 * M * R * Dout + 2 * M * R + Dout * (M * M * R + 2 * M * R) + 4 * R * Dout
         fwd.append(f)
         wg.append((2 + Dout) * M * M * R)
-    small = sum(M * M * (Din + 2) + M ** 3 / 3 + Dout * M ** 3 / 3 + 2 * M * M * Dout for _, Din, Dout in layer_shapes(cfg))
+    small = sum(M * M * (Din + 2) + M ** 3 / 3 + Dout * M ** 3 / 3 + 2 * M * M * Dout for _, Din, Dout in shapes)
     return dict(layer_fwd=sum(fwd), layer_bwd=sum(fwd), wgrad=sum(wg), small=small,
                 step=3 * (sum(fwd) + small))
 
@@ -92,7 +93,7 @@ def build_model(cfg, rank, world, mb_local, bucketed=None):
     return model, X, Y, Z
 
 
-def cpu_baseline(cfg, X, Y, Z, budget_s=20.0):
+def cpu_baseline(cfg, X, Y, Z, budget_s=10.0):
     """CPU restatement of the reference op sequence (forward + autograd + Adam) on this box's host cores."""
     import torch
     from oracle import dgp_oracle as O, model as OM
@@ -203,6 +204,32 @@ def sub_rooflines(ctx):
     return out
 
 
+def all_configs():
+    """Throughput of the OTHER BASELINE.json configs on this one GPU (configs[0], [2] whole; [3], [4] as the per-GPU shard of their
+    8-GPU minibatch — tools/bench_configs.py): steps/s, ms/step and the fraction of the fp64 MFMA peak by SURVEY 8d's F_step of
+    that shape.  Secondary lines of the N = 1 JSON; the contract's `value` stays configs[1]."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as BC
+    out = []
+    for i, c in enumerate(BC.CONFIGS):
+        if i == 1:
+            continue
+        r = BC.run(dict(c, steps=max(3, c["steps"] // (1 if i == 0 else 2))))
+        widths = c["widths"]
+        douts = list(widths[1:]) + [c.get("classes") or 1]
+        shapes = [((c["mb"] if l == 0 else c["mb"] * c["S"]), widths[l], douts[l]) for l in range(len(widths))]
+        fstep = algorithmic_flops(dict(M=c["M"]), shapes)["step"]
+        tf = fstep * r["steps_per_s"] / 1e12
+        out.append(dict(config=r["config"], steps_per_s=r["steps_per_s"], ms_per_step=r["ms_per_step"],
+                        algorithmic_gflop_per_step=round(fstep / 1e9, 1), achieved_tflops=round(tf, 2),
+                        frac_of_fp64_peak=round(tf / FP64_MFMA_PEAK_TFLOPS, 4), elbo_finite=r["elbo_finite"],
+                        note=("one optimiser step = natural-gradient evaluation + step on the last layer, then an Adam step: two forward "
+                              "passes, F_step counts one" if c.get("natgrad") else None)))
+        torch.cuda.empty_cache()
+    return out
+
+
 def csrc_hash():
     """sha256 over the kernel sources: ties a committed PMC traffic profile to the build it was taken from"""
     import hashlib
@@ -213,6 +240,22 @@ def csrc_hash():
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def self_launch(n):
+    """Re-run this command line as `n` ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>.  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this platform
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -232,12 +275,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher of its own N ranks (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1 at a free port) and passes their exit status on; rank 0 prints the JSON line
+        sys.exit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it spawns its own ranks) or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    one_device = os.environ.get("DSDGP_BENCH_ONE_DEVICE") == "1"
+    if world > 1 and not one_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, this node shows {torch.cuda.device_count()} "
+                         f"(one process per GPU over RCCL; no oversubscription outside the DSDGP_BENCH_ONE_DEVICE test rig)")
     # test rig only (validating the N > 1 code path on a 1-GPU box): DSDGP_BENCH_BACKEND=gloo + DSDGP_BENCH_ONE_DEVICE=1 put
     # every rank on cuda:0 and stage the all-reduce through the host; the driver's runs use RCCL, one GPU per rank
     backend = os.environ.get("DSDGP_BENCH_BACKEND", "nccl")
-    if os.environ.get("DSDGP_BENCH_ONE_DEVICE") == "1":
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -273,6 +325,7 @@ def main():
     evals_per_s = predict_rows_per_s = predict_fwd = None
     prof = {}
     sub = {}
+    others = None
     steady = None
     if not args.no_extras:
         # secondary metrics: forward-only ELBO evals/s and predict_f rows/s (per rank)
@@ -319,6 +372,8 @@ def main():
         os.environ["DSDGP_NO_OVERLAP"] = "0"
         if rank == 0:
             sub = sub_rooflines(ctx)
+            if world == 1:
+                others = all_configs()
         # steady-state distribution: single steps bracketed by events on the launch stream (ctx stream == torch's current stream)
         nst = 300
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)]
@@ -349,6 +404,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo = model.train_step(0.01, sync=True)
+    rccl_ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+        rccl_ranks = dist.get_world_size()
 
     fl = algorithmic_flops(cfg_local)
     fl_global = algorithmic_flops(cfg)
@@ -405,7 +464,7 @@ def main():
             "metric": "ELBO-steps/sec", "value": round(value, 3),
             "unit": ("steps/s (minibatch-1000-per-GPU ELBO+grad+Adam steps x GPUs, whole job)" if weak else
                      "steps/s (global-minibatch-1000 ELBO+grad+Adam steps, whole job)"),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "visible_gpus": torch.cuda.device_count(), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "3-layer DS-DGP, kin8nm-shaped (7372x8), RBF, M=128, S=20, global minibatch "
@@ -414,7 +473,7 @@ def main():
                        "inducing": cfg["M"], "layers": cfg["L"], "parallelism": f"row-sharded dp{world}",
                        "gradient_exchange": ("none" if world == 1 else
                                              ("one all-reduce per layer (bucketed)" if model._dist_buckets()["on"] else "one flat all-reduce"))},
-            "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "kernel_ms_per_step": prof,
+            "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "all_configs": others, "kernel_ms_per_step": prof,
             "step_time": steady,
             "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world
                                                 / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int6
     }
   }
   if (j0 >= n2) return;
-  const bool pair = (j0 + 1 < n2) && ((ld & 1) == 0);       // 16-byte aligned pair store
+  const bool pair = (j0 + 1 < n2) && ((ld & 1) == 0) && (((uintptr_t)out & 15) == 0);       // 16-byte aligned pair store
 #pragma unroll
   for (int ii = 0; ii < GR_TI; ++ii) {          // values first (straight-line: the exps of all rows interleave) ...
     const int64_t i = i0 + ii;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const double* __restrict__ X,
 #pragma unroll
     for (int t = 0; t < 4; ++t) ni[t] = __shfl(nr, g + 4 * t);
   }
-  const bool even_ld = (ld & 1) == 0;
+  const bool even_ld = (ld & 1) == 0 && (((uintptr_t)out & 15) == 0);     // 16-byte stores need an aligned base as well (any double* is accepted)
   for (int jt = 0; jt < jtiles; ++jt) {
     const int64_t j0 = jbase + 32 * jt;
     if (j0 >= n2) break;

@@ -2500,6 +2500,25 @@ extern "C" int dsdgp_model_train_step_minibatch(dsdgp_model* m, const double* X_
 
 extern "C" int dsdgp_model_set_bucket_callback(dsdgp_model* m, dsdgp_bucket_fn fn, void* user) {
   DS_CHECK_ARG(m != nullptr);
+  if (fn) {
+    // the buckets are contiguous SEGMENTS of theta: layer l owns [off_Z_l, off_Z_{l+1}), the likelihood variance follows the last
+    // layer's segment.  A descriptor with another ordering would hand out segments that are incomplete or not yet produced.
+    const int L = m->desc.L;
+    const int64_t lik_lo = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta;
+    for (int l = 0; l < L; ++l) {
+      const dsdgp_layer_desc& d = m->L[l].d;
+      const int64_t lo = d.off_Z, hi = (l + 1 < L) ? m->L[l + 1].d.off_Z : lik_lo;
+      const int64_t offs[] = {d.off_q_mu, d.off_q_sqrt, d.off_kvar, d.off_kls, d.has_white ? d.off_wvar : lo,
+                              d.off_mean_A >= 0 ? d.off_mean_A : lo, d.off_mean_b >= 0 ? d.off_mean_b : lo};
+      bool ok = lo < hi;
+      for (int64_t o : offs) ok = ok && o >= lo && o < hi;
+      if (!ok) {
+        dsdgp_set_error("dsdgp_model_set_bucket_callback: the parameters of layer %d do not form one contiguous segment of theta "
+                        "ordered [layer 0 | layer 1 | ... | likelihood]", l);
+        return DSDGP_ERR_UNSUPPORTED;
+      }
+    }
+  }
   m->bucket_fn = fn;
   m->bucket_user = user;
   return DSDGP_OK;

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(const TrsmPanel P) {
 extern "C" int dsdgp_trsm_batched(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, int batch, const double* L, int64_t ldl,
                                   int64_t strideL, double* B, int64_t ldb, int64_t strideB) {
   DS_CHECK_ARG(ctx && L && B && n > 0 && nrhs > 0 && batch > 0 && ldl >= n && ldb >= nrhs);
+  DS_CHECK_ARG(nrhs <= 0x7fffffff && ldb <= 0x7fffffff && ldl <= 0x7fffffff);      // the update GEMMs carry 32-bit extents
   const int nb = ceil_div(n, 16);
   const int nL = strideL == 0 ? 1 : batch;
   const int npanel = ceil_div(n, TRSM_PANEL);

@@ -116,7 +116,10 @@ class DGP_Base(Parameterized):
             except RuntimeError:
                 pass
             self._idx_host = host                                  # alive until the copy has run
-            self._idx_dev = host.to(Xd.device, non_blocking=True)
+            # on the library's stream (ctx.tstream), whatever stream the caller has made current: the gather that reads the indices
+            # is ordered behind this copy only there
+            with ctx.torch.cuda.stream(ctx.tstream):
+                self._idx_dev = host.to(Xd.device, non_blocking=True)
             self._idx_src, self._idx_pos, self._idx_cnt = mb, 0, k
         off = self._idx_pos * mb.batch_size
         self._idx_pos += 1
@@ -196,6 +199,7 @@ class DGP_Base(Parameterized):
         hook = getattr(self, "_dist_before_elbo", None)
         if hook is not None and allreduce is not None:
             eng._ensure(n_local, self.num_samples)
+            eng._upload_if_needed()            # may re-create the device model (layout / jitter change): before the hook looks at it
             hook(eng)
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
                        kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer)
@@ -237,6 +241,7 @@ class DGP_Base(Parameterized):
             hook = getattr(self, "_dist_before_elbo", None)
             if hook is not None:
                 eng._ensure(n_local, self.num_samples)
+                eng._upload_if_needed()
                 hook(eng)
             out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
                            kl_weight=klw, with_grad=True, sync=False)

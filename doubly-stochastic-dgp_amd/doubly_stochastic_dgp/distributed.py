@@ -47,7 +47,17 @@ class _Buckets:
         import ctypes as C
         from . import _lib
         _lib.check(self.eng.lib.dsdgp_model_set_bucket_callback(self.eng.model, C.cast(self._cb, C.c_void_p), None))
-        self._model = self.eng.model.value
+        # keyed on the engine's model GENERATION, not on the handle's address: Engine._ensure / _upload_if_needed destroy and re-create
+        # the device model (a predict_* call with more rows than the training shape), and `new dsdgp_model` may get the freed address
+        # back — a pointer comparison would then skip the re-installation on some ranks and the ranks would issue different collectives
+        self._gen = self.eng.generation
+        hooks = self.eng.__dict__.setdefault("_post_create", [])
+        if self._reinstall not in hooks:
+            hooks.append(self._reinstall)          # the engine re-installs the callback right after every dsdgp_model_create
+
+    def _reinstall(self, eng):
+        if eng is self.eng and eng.model is not None:
+            self.install()
 
     def _on_bucket(self, user, bucket, ptr, count, stream):
         # (called from inside a ctypes call: an exception raised here would only be printed — keep it for finish())
@@ -129,10 +139,12 @@ def attach(model, rank, world, bucketed=None):
         if not want:
             return
         b = state["buckets"]
-        if b is None or b.eng is not eng or getattr(b, "_model", None) != eng.model.value:
+        if b is None or b.eng is not eng:
             b = _Buckets(eng, world)
             b.install()
             state["buckets"] = b
+        elif b._gen != eng.generation:                  # (belt and braces: the engine's post-create hook re-installs it already)
+            b.install()
         b.count = 0
 
     object.__setattr__(model, "_dist", (rank, world, allreduce))

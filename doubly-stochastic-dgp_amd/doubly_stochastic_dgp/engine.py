@@ -283,6 +283,7 @@ class Engine:
                                                ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v),
                                                C.c_void_p(self._ws_ptr), nbytes.value, C.byref(h)))
         self.model = h
+        self.generation = getattr(self, "generation", 0) + 1     # identifies THIS device model (a freed handle's address can come back)
         self._grad_first = 0
         # this engine is the only writer of theta besides the library's own optimiser steps and reports its uploads
         # (_upload_if_needed): an evaluation after a natural-gradient step alone keeps the factorisation of Ku
@@ -290,6 +291,8 @@ class Engine:
         self.n_max, self.s_max = n_max, s_max
         if getattr(self, "_sample_w", None) is not None:       # DGP_Quad weights survive a model re-creation
             self.set_sample_weights(self._sample_w)
+        for fn in getattr(self, "_post_create", ()):            # per-model settings owned by others (the data-parallel bucket callback)
+            fn(self)
         self._needs_prepare = True
 
     # ------------------------------------------------------------------ compute
@@ -402,6 +405,10 @@ class Engine:
                              beta2=0.999, eps=1e-8):
         """train_step on rows idx[idx_offset : idx_offset + n] of the device-resident data (gather inside the step's first launch)."""
         self._check_targets_shape(Yall, Yall.shape[0])
+        if Xall.shape[0] != Yall.shape[0]:
+            raise ValueError(f"X has {Xall.shape[0]} rows, Y {Yall.shape[0]}")
+        if idx_offset < 0 or idx_offset + n > idx.numel():
+            raise ValueError(f"index span [{idx_offset}, {idx_offset + n}) outside the index buffer of {idx.numel()} entries")
         self._ensure(n, S)
         self._upload_if_needed()
         if getattr(self, "_grad_first", 0) != 0:

@@ -27,7 +27,7 @@ def outputs(name):
     om = OM.build(O.NP, spec, state, S, c["num_data"])
     kls = np.array([float(l.KL(O.NP)) for l in om.layers])
     elbo, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=c["num_data"])
-    out = dict(elbo=np.array(elbo), kls=kls)
+    out = dict(elbo=np.array(elbo), kls=kls, source=np.array("oracle"))     # NOT the reference: see DESIGN.md section 3
     for l in range(c["L"]):
         out[f"Fmean{l}"], out[f"Fvar{l}"], out[f"F{l}"] = Fm[l], Fv[l], Fs[l]
     for k, v in g.items():

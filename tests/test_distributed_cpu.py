@@ -113,7 +113,7 @@ def test_exchange_form_is_chosen_by_gradient_size():
 
     class FakeEng:
         def __init__(self, n_theta):
-            self.n_theta, self.lib, self.model = n_theta, FakeLib(), C.c_void_p(1234)
+            self.n_theta, self.lib, self.model, self.generation = n_theta, FakeLib(), C.c_void_p(1234), 1
 
     class FakeModel:
         minibatch_size = None
@@ -129,3 +129,14 @@ def test_exchange_form_is_chosen_by_gradient_size():
         assert m._dist_buckets()["on"] == bool(want)
         m._dist_before_elbo(eng)                       # a second evaluation on the same device model does not re-install
         assert eng.lib.installed == want
+        # the device model is re-created at the SAME address (a freed handle coming back from the allocator): the callback must be
+        # installed again — keyed on the engine's generation counter, not on the pointer
+        eng.generation += 1
+        for fn in getattr(eng, "_post_create", ()):    # what Engine._ensure runs right after dsdgp_model_create
+            fn(eng)
+        assert eng.lib.installed == 2 * want
+        m._dist_before_elbo(eng)
+        assert eng.lib.installed == 2 * want
+        eng.generation += 1                            # ... and if the engine's hook list were bypassed, the evaluation hook catches it
+        m._dist_before_elbo(eng)
+        assert eng.lib.installed == 3 * want

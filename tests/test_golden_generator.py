@@ -22,7 +22,7 @@ def test_dry_run_writes_complete_fixtures_elsewhere(tmp_path, capsys):
         old = np.load(f"{G.HERE}/golden_{n}.npz")
         assert set(old.files) <= set(new.files) and str(new["source"]).startswith("oracle")
         for k in old.files:
-            assert np.array_equal(old[k], new[k]), k
+            assert k == "source" or np.array_equal(old[k], new[k]), k
 
 
 def test_dry_run_refuses_to_overwrite_the_committed_fixtures():
@@ -46,4 +46,6 @@ def test_reference_side_covers_every_key_of_the_oracle_side():
     for k in old.files:
         if k.startswith("x."):
             assert f'"{k}"' in src or f'"{k[:-5]}"' in src or f'"{k[:-6]}"' in src, k
-    assert set(cases.CASES) == {f[len("golden_"):-4] for f in __import__("os").listdir(G.HERE) if f.endswith(".npz")}
+    # (golden_full_*.npz are the full-size oracle fixtures of tests/golden/full_cases.py: their own generator and test)
+    assert set(cases.CASES) == {f[len("golden_"):-4] for f in __import__("os").listdir(G.HERE)
+                                if f.endswith(".npz") and not f.startswith("golden_full_")}

@@ -107,25 +107,32 @@ if __name__ == "__main__":
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["flat", "bucketed"])
-def test_bench_contract_two_ranks_one_device(tmp_path, mode):
-    """bench.py's N > 1 path exactly as the driver launches it (torch.distributed.run, one process per rank), on the test rig of a
-    1-GPU box: both ranks on cuda:0 over gloo.  One JSON line from rank 0, whole-job value, the exchange mode that was asked for."""
+@pytest.mark.parametrize("mode,launcher", [("flat", "self"), ("bucketed", "torchrun")])
+def test_bench_contract_two_ranks_one_device(tmp_path, mode, launcher):
+    """bench.py's N > 1 path both ways the driver may start it — plain `python bench.py --gpus 2` (bench.py spawns its own ranks
+    under torch.distributed.run) and an explicit torch.distributed.run launch — on the test rig of a 1-GPU box: both ranks on
+    cuda:0 over gloo.  One JSON line from rank 0, whole-job value, the rank count it observed, the exchange mode that was asked for."""
     import json
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, DSDGP_BENCH_BACKEND="gloo", DSDGP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--no-cpu-baseline", "--no-extras", "--allreduce", mode]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
+            "--allreduce", mode]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     b = json.loads(lines[0])
-    assert b["n_gpus"] == 2 and b["steps"] == 6 and b["value"] > 0 and b["scaling"] == "strong"
+    assert b["n_gpus"] == 2 and b["rccl_ranks"] == 2 and b["steps"] == 6 and b["value"] > 0 and b["scaling"] == "strong"
     assert b["config"]["per_gpu_minibatch"] == 500 and b["config"]["global_batch"] == 1000
     assert ("per layer" in b["config"]["gradient_exchange"]) == (mode == "bucketed")
     assert np.isfinite(b["final_elbo"])
