@@ -125,3 +125,33 @@ int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
 int sm_cs_built(int Mp);     // the split-M backward chain has a Csave instance for this padded inducing count
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in);   // number of hyp_part rows the split-M backward writes for ld padded rows
+
+// ------------------------------------------------------------------------------------------------------
+// GEMM-formulated layer passes for LARGE inducing counts (layer_gemm.hip; Mp >= 512 by default).
+// The fused chains keep one block of 16 data rows per workgroup, so every weight element fetched from L2 / Infinity Cache feeds 16
+// columns of one MFMA — at Mp >= 512 the weights of a layer (2 + D_out triangular M x M matrices, 10 - 40 MB) no longer sit in L1 / L2
+// and the chains run at 0.16 - 0.31 of the fp64 MFMA peak (profiles/r03_kernel_stats_cfg{4,5}.md).  Here each of the layer's products
+// is ONE LDS-tiled MFMA GEMM over the whole row range (128 x 128 output tiles: every weight and every activation element is used 128
+// times per fetch), with the per-row reductions (|a1|^2, |c_d|^2) taken in the GEMM epilogue; the intermediates (Kuf, a1, a, c_d:
+// Mp x R doubles each, 51 MB at config 5) live in HBM / Infinity Cache between the launches.
+// Same argument blocks and same outputs as the chains (A, C, mean / var / F, E, GW, hyp_part, dX / MBp / VBp), so the
+// weight-gradient products, the assembly and the optimiser are untouched.  C (c_d for the backward pass) is laid out [d][Mp][ldA].
+// ------------------------------------------------------------------------------------------------------
+struct GemmLayerWs {
+  double* T1;        // (Mp_max x ld_max)  forward: Kuf            backward: Ku^-1 abar
+  double* T2;        // (Mp_max x ld_max)  forward: a1 = Lu^-1 Kuf backward: abar
+  double* Pb;        // (GL_MAX_GROUPS + 1) x (Mp_max x ld_max): partial abar of the d-groups + the mean part
+  double* colsq;     // (1 + D_out_max) x tiles_m_max x ld_max: per-tile-row column sums of squares (|a1|^2, |c_d|^2)
+  double* MUT;       // (DP16_max x ld_max)  q_mu^T a
+  double* qmuT;      // (DP16_max x Mp_max)  q_mu^T, zero padded
+  double* ZZ;        // (Mp_max x nzz_max)   [Z/l | (Z/l)^2 | 1]
+  double* OUTt;      // (nzz_max x ld_max)   ZZ^T GW
+  double* svar;      // per block of the element-wise backward kernel: sum kbar k
+};
+#define GL_MAX_GROUPS 4
+// doubles of each GemmLayerWs array for a model whose gemm-path layers have at most these extents
+struct GemmLayerExtents { int64_t Mp, ld, D_out, D_in; };
+int layer_gemm_hyp_parts(int64_t ld, int Mp);
+int layer_gemm_lik_blocks(int64_t Rin, int D_out);
+int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, const GemmLayerWs& ws);
+int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, const GemmLayerWs& ws);

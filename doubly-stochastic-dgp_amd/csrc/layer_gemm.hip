@@ -1,0 +1,625 @@
+// SVGP_Layer.conditional_ND + reparameterize (layers.py:178-219, utils.py:40-41) and their reverse mode for LARGE inducing counts,
+// formulated as whole-layer MFMA GEMMs (see layer.hpp, "GEMM-formulated layer passes").  gfx950 only.
+//
+// forward (non-white, math of DESIGN.md section 2):
+//   K   = k(Z, X)                       k_kuf<KIND, false>            (Mp x ld, rows >= M and columns >= Rin are zero)
+//   a1  = Lu^-1 K                       k_pgemm, W lower-triangular   + column sums of squares per tile row  -> |a1|^2
+//   a   = Lu^-T a1                      k_pgemm, W upper-triangular   -> Asave
+//   c_d = q_sqrt_d^T a   (all d)        k_pgemm, batched, W upper     + column sums of squares -> |c_d|^2 ; stored only for the reverse pass
+//   mu  = q_mu^T a                      k_pgemm on the transposed, padded q_mu
+//   mean / var / F                      k_gl_epilogue  (var = kdiag - |a1|^2 + |c_d|^2, utils.py:41)
+// backward:
+//   abar = sum_d q_sqrt_d (2 vbar_d c_d) + q_mu mbar     k_pgemm, W lower-triangular, B scaled per column, the outputs split into
+//                                                        groups so that a launch has enough tiles; partial sums in Pb
+//          (no c_d kept: abar = sum_d S_d (2 vbar_d a), dense)
+//   b    = Ku^-1 abar                                    k_gl_sum (the partial buffers, fixed order), k_pgemm
+//   e = b - g a, kbar = e - g a, GW = kbar dk/dr2, E      k_kuf<KIND, true> (recomputes r2), sum kbar k per block
+//   ZZ^T GW with ZZ = [Z/l | (Z/l)^2 | 1]                k_pgemm (W = ZZ^T)  -> sums over the inducing rows for dX and the lengthscales
+//   dX / transposed adjoints of the layer below, hyp_part k_gl_bwd_rows
+#include "layer.hpp"
+
+#define PT 128     // output tile (both dimensions)
+#define PK 16      // k per staging step
+#define PLD 144    // LDS row stride in doubles: the g and g + 1 k-rows of a fragment read sit 32 banks apart (conflict-free ds_read_b64)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// One product of a layer pass.  INDEPENDENT mode (groups == 0): for every batch item b
+//     C[b] = alpha W[b] (m x k, row-major) (B'[b] (k x n, row-major))      B' = B with its columns scaled by bscale[b] (or as it is)
+// and colsq[(b tiles_m + tile row) ldq + col] = sum over the tile's rows of C^2.  REDUCE mode (groups > 0): the batch items are cut
+// into `groups` contiguous runs, run z is summed into C + z sCg.
+// tri = 2: W lower-triangular (k ranges over [0, tile row's last row]) ; 8: upper-triangular (k from the tile's first row) ; 0: dense.
+struct PGemm {
+  const double* W;
+  const double* B;
+  double* C;
+  const double* bscale;
+  double* colsq;
+  int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg;
+  int32_t m, n, k, batch, groups, tri, store, pad;
+  int32_t tiles_m, tiles_n;
+  double alpha;
+};
+
+__global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
+  __shared__ __attribute__((aligned(16))) double As[2][PK * PLD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][PK * PLD];
+  const int Z = P.groups > 0 ? P.groups : P.batch;
+  int t = blockIdx.x;
+  const int tn = t % P.tiles_n;
+  t /= P.tiles_n;
+  const int z = t % Z, tmi = t / Z;
+  // workgroups are dispatched in index order: the tile rows with the longest k range go first (longest-processing-time order)
+  const int tm = (P.tri == 2) ? P.tiles_m - 1 - tmi : tmi;
+  const int m0 = tm * PT, n0 = tn * PT;
+  int b0, b1;
+  if (P.groups > 0) {
+    const int bc = (P.batch + P.groups - 1) / P.groups;
+    b0 = z * bc;
+    b1 = min(P.batch, b0 + bc);
+    if (b1 < b0) b1 = b0;
+  } else {
+    b0 = z;
+    b1 = z + 1;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+  int kmin = 0, kmax = P.k;
+  if (P.tri == 2) kmax = min(kmax, m0 + PT);
+  if (P.tri == 8) kmin = m0;
+  const int ks_lo = kmin / PK;
+  const int ksteps = max(0, (kmax + PK - 1) / PK - ks_lo);
+  const int nsteps = (b1 - b0) * ksteps;
+  // staging roles: W rows (k contiguous): thread takes row m0 + tid / 2, k = 8 (tid & 1) .. + 7 ; B rows (n contiguous): k = tid / 16,
+  // n = n0 + 8 (tid & 15) .. + 7.  64 contiguous bytes per thread either way, as four 16-byte loads.
+  const int am = m0 + (tid >> 1), ak = 8 * (tid & 1);
+  const int bk = tid >> 4, bn = n0 + 8 * (tid & 15);
+  const bool a_row = am < P.m, b_col = bn + 8 <= P.n;
+  double ra[8], rb[8], sv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) sv[u] = 1.0;
+  int kq = 0;          // first k of the W chunk in flight (for the triangle mask applied when it is stored to LDS)
+  // gload only ISSUES the loads of a step; everything that consumes the loaded values (triangle mask, column scale) happens in lstore,
+  // i.e. after the MFMAs of the step that runs meanwhile — a use inside gload would put the memory round trip in front of them
+  auto gload = [&](int step) {
+    const int bi = step / ksteps;
+    const int b = b0 + bi, k0 = (ks_lo + step - bi * ksteps) * PK;
+    kq = k0 + ak;
+    {
+      gcptr src = (gcptr)(P.W + (int64_t)b * P.sW + (int64_t)am * P.ldw + k0 + ak);
+      if (a_row && k0 + ak + 8 <= P.k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
+          ra[2 * u] = v[0];
+          ra[2 * u + 1] = v[1];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ra[u] = (a_row && k0 + ak + u < P.k) ? src[u] : 0.0;
+      }
+    }
+    {
+      const bool ok = b_col && k0 + bk < P.k;
+      gcptr src = (gcptr)(P.B + (int64_t)b * P.sB + (int64_t)(k0 + bk) * P.ldb + bn);
+      if (ok) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
+          rb[2 * u] = v[0];
+          rb[2 * u + 1] = v[1];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rb[u] = 0.0;
+      }
+      if (P.bscale && step == bi * ksteps && b_col) {      // first k-step of batch item b: its column scales
+        gcptr sp = (gcptr)(P.bscale + (int64_t)b * P.sS + bn);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = sp[u];
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    const int mm = tid >> 1;
+    // entries of the other triangle inside the diagonal tile are not trusted to be zero in memory
+    if (P.tri == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ra[u] = (kq + u <= am) ? ra[u] : 0.0;
+    } else if (P.tri == 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ra[u] = (kq + u >= am) ? ra[u] : 0.0;
+    }
+    if (P.bscale) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rb[u] *= sv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) As[buf][(ak + u) * PLD + mm] = ra[u];
+    double* brow = &Bs[buf][bk * PLD + 8 * (tid & 15)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(brow + 2 * u) = (d2){rb[2 * u], rb[2 * u + 1]};
+  };
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+    for (int k4 = 0; k4 < PK; k4 += 4) {
+      double a[4], bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[buf][(k4 + g) * PLD + wr * 64 + 16 * i + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = Bs[buf][(k4 + g) * PLD + wc * 64 + 16 * j + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(a[i], bq[j], acc[i][j]);
+    }
+    if (step + 1 < nsteps) lstore(buf ^ 1);     // the other buffer: its last readers passed the previous barrier
+    __syncthreads();
+  }
+  if (P.store) {
+    gptr C = (gptr)(P.C + (P.groups > 0 ? (int64_t)z * P.sCg : (int64_t)b0 * P.sC));
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wr * 64 + ib * 16 + g + 4 * r;
+          const int col = n0 + wc * 64 + jb * 16 + c;
+          if (row < P.m && col < P.n) C[(int64_t)row * P.ldc + col] = P.alpha * acc[ib][jb][r];
+        }
+  }
+  if (P.colsq) {
+    // column sums of squares over this tile's rows: lanes fold their 16 rows, the four row groups fold through permlane swaps, the
+    // two waves that share the columns through LDS (fixed order).  Rows >= m hold zero (masked W rows).
+    double* cs = &As[0][0];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      double s = 0.0;
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = P.alpha * acc[ib][jb][r];
+          s = fma(v, v, s);
+        }
+      s = sum_groups(s);
+      if (g == 0) cs[wr * PT + wc * 64 + jb * 16 + c] = s;
+    }
+    __syncthreads();
+    if (tid < PT) {
+      const int col = n0 + tid;
+      if (col < P.n) P.colsq[((int64_t)b0 * P.tiles_m + tm) * P.ldq + col] = cs[tid] + cs[PT + tid];
+    }
+  }
+}
+
+static int pgemm_launch(dsdgp_ctx* ctx, PGemm P, const char* prof = "layer_gemm") {
+  P.tiles_m = ceil_div(P.m, PT);
+  P.tiles_n = ceil_div(P.n, PT);
+  const int Z = P.groups > 0 ? P.groups : P.batch;
+  const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * Z;
+  if (blocks <= 0) return DSDGP_OK;
+  hipLaunchKernelGGL(k_pgemm, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kuf tile kernel.  64 x 64 outputs per workgroup, thread (ty, tx) owns rows ty + 16 i, columns tx + 16 j; Z / l and x / l of the tile
+// staged through LDS in chunks of KD input dimensions ([dimension][64 + 1], Z reads broadcast over tx, x reads conflict-free);
+// squared distances by direct differences (D_in subtract + FMA pairs per output: fp64 VALU work that is < 1 % of the layer's MFMA flops).
+//   BWD = false: K[m][r] = k(r2) for m < M, r < Rin, zero in the padding.
+//   BWD = true : e = b - g a, kbar = e - g a, GW = kbar dk/dr2 (0 in the padding), E = e, svar[block] = sum kbar k.
+// ------------------------------------------------------------------------------------------------------
+#define KT 64
+#define KD 32
+struct KufArgs {
+  const double* Zs;     // (Mp x D_in) Z / lengthscale
+  const double* X;      // (Rin x D_in)
+  const double* hyp;
+  int64_t Rin, ld;
+  int32_t M, Mp, D_in, D_out;
+  double* K;            // forward out (Mp x ld)
+  const double* A;      // backward in: a (Mp x ld), b = Ku^-1 abar (Mp x ld)
+  const double* Bm;
+  const double* VB;     // (D_out x ld)
+  double* E;            // or NULL
+  double* GW;
+  double* svar;         // [blocks]
+};
+template <int KIND, bool BWD>
+__global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
+  __shared__ double zt[KD][KT + 1];
+  __shared__ double xt[KD][KT + 1];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * KT;
+  const int m0 = blockIdx.y * KT;
+  const double* ils = a.hyp + HYP_ILS;
+  const double s2 = a.hyp[HYP_VAR];
+  double r2[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r2[i][j] = 0.0;
+  for (int d0 = 0; d0 < a.D_in; d0 += KD) {
+    const int dn = min(KD, a.D_in - d0);
+    if (d0 > 0) __syncthreads();
+    for (int idx = tid; idx < KT * dn; idx += 256) {
+      const int rr = idx / dn, d = idx - rr * dn;
+      const int mrow = min(m0 + rr, a.Mp - 1);
+      zt[d][rr] = a.Zs[(int64_t)mrow * a.D_in + d0 + d];
+      const int64_t xr = min<int64_t>(r0 + rr, a.Rin - 1);
+      xt[d][rr] = a.X[xr * a.D_in + d0 + d] * ils[d0 + d];
+    }
+    __syncthreads();
+    for (int d = 0; d < dn; ++d) {
+      double zv[4], xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zv[i] = zt[d][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = xt[d][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double df = zv[i] - xv[j];
+          r2[i][j] = fma(df, df, r2[i][j]);
+        }
+    }
+  }
+  double sv = 0.0;
+  double gs[4];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + tx + 16 * j;
+      double s = 0.0;
+      if (r < a.ld)
+        for (int d = 0; d < a.D_out; ++d) s += a.VB[(int64_t)d * a.ld + r];
+      gs[j] = s;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 16 * i;
+    if (m >= a.Mp) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + tx + 16 * j;
+      if (r >= a.ld) continue;
+      const bool ok = (m < a.M) && (r < a.Rin);
+      if constexpr (!BWD) {
+        a.K[(int64_t)m * a.ld + r] = ok ? kern_val<KIND>(r2[i][j], s2) : 0.0;
+      } else {
+        const double av = a.A[(int64_t)m * a.ld + r];
+        const double e = a.Bm[(int64_t)m * a.ld + r] - gs[j] * av;
+        const double kbar = e - gs[j] * av;
+        double k, dk;
+        kern_val_grad<KIND>(r2[i][j], s2, k, dk);
+        sv += ok ? kbar * k : 0.0;
+        a.GW[(int64_t)m * a.ld + r] = ok ? kbar * dk : 0.0;
+        if (a.E) a.E[(int64_t)m * a.ld + r] = e;
+      }
+    }
+  }
+  if constexpr (BWD) {
+    sv = sum_wave(sv);
+    if ((tid & 63) == 0) red[tid >> 6] = sv;
+    __syncthreads();
+    if (tid == 0) a.svar[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// out = sum of `n` buffers `stride` doubles apart (fixed order), two doubles per thread
+__global__ void k_gl_sum(const double* __restrict__ part, int n, int64_t stride, int64_t count2, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count2) return;
+  d2 s = reinterpret_cast<const d2*>(part)[i];
+  for (int u = 1; u < n; ++u) s += reinterpret_cast<const d2*>(part + (int64_t)u * stride)[i];
+  reinterpret_cast<d2*>(out)[i] = s;
+}
+// q_mu^T, zero padded to (rows16 x Mp); [X^T ; 1] of the layer input for the Z-gradient product
+__global__ void k_gl_qmut(const double* __restrict__ qmu, int qld, int Mp, int D_out, int rows16, double* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows16 * Mp) return;
+  const int d = idx / Mp, m = idx - d * Mp;
+  out[idx] = d < D_out ? qmu[(int64_t)m * qld + d] : 0.0;
+}
+__global__ void k_gl_xt1(const double* __restrict__ X, int64_t Rin, int D_in, int64_t ld, double* __restrict__ XT1) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)(D_in + 1) * ld) return;
+  const int j = (int)(idx / ld);
+  const int64_t r = idx - (int64_t)j * ld;
+  XT1[idx] = (r < Rin) ? (j < D_in ? X[r * D_in + j] : 1.0) : 0.0;
+}
+// ZZ = [Z/l | (Z/l)^2 | 1]^T as (nzz16 x Mp) rows (the W operand of the ZZ^T GW product), rows >= M of Z/l are zero
+__global__ void k_gl_zz(const double* __restrict__ Zs, int M, int Mp, int D_in, int nzz16, double* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nzz16 * Mp) return;
+  const int j = idx / Mp, m = idx - j * Mp;
+  double v = 0.0;
+  if (m < M) {
+    if (j < D_in) v = Zs[(int64_t)m * D_in + j];
+    else if (j < 2 * D_in) { const double z = Zs[(int64_t)m * D_in + j - D_in]; v = z * z; }
+    else if (j == 2 * D_in) v = 1.0;
+  }
+  out[idx] = v;
+}
+
+// forward epilogue: one thread per (row, output); the first layer writes `rep` output rows per input row
+#define GL_EPI_ROWS 64
+template <bool LIK>
+__global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const double* __restrict__ colsq, int tiles_m, const double* __restrict__ MUT) {
+  __shared__ double red[8];
+  const int Dout = a.D_out, Din = a.D_in;
+  const int64_t r0 = (int64_t)blockIdx.x * GL_EPI_ROWS;
+  const double kdiag = a.hyp[HYP_KDIAG];
+  const double lik_s2 = LIK ? a.lik_const[0] : 1.0;
+  const double lik_c0 = -0.91893853320467274178 - 0.5 * log(lik_s2);
+  double lik_ve = 0.0, lik_dl = 0.0;
+  const int nitem = GL_EPI_ROWS * Dout;
+  for (int e = threadIdx.x; e < nitem; e += 256) {
+    const int rr = e / Dout, d = e - rr * Dout;
+    const int64_t r = r0 + rr;
+    if (r >= a.Rin) {
+      if (LIK && r < a.lik_ld) {          // rows of the 16-row padding of the transposed adjoints
+        a.lik_MB[(int64_t)d * a.lik_ld + r] = 0.0;
+        a.lik_VB[(int64_t)d * a.lik_ld + r] = 0.0;
+      }
+      continue;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles_m; ++t) {
+      s1 += colsq[(int64_t)t * a.ldA + r];
+      s2 += colsq[((int64_t)(1 + d) * tiles_m + t) * a.ldA + r];
+    }
+    const double var = kdiag - s1 + s2;                                  // layers.py:212-217
+    double mu = MUT[(int64_t)d * a.ldA + r];                             // layers.py:190
+    if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
+      mu += a.X[r * Din + d];
+    } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+      double m2 = 0.0;
+      for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
+      mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
+    }
+    const double sd = sqrt(var + a.jitter);
+    for (int s = 0; s < a.rep; ++s) {
+      const int64_t orow = (int64_t)s * a.Rin + r;
+      const int64_t o = orow * Dout + d;
+      if (a.mean) a.mean[o] = mu;
+      if (a.var) a.var[o] = var;
+      if (a.F && a.z) {
+        const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
+        a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
+      }
+      if constexpr (LIK) {
+        const double y = a.lik_Y[(orow % a.n_inner) * Dout + d];
+        const double q = (y - mu) * (y - mu) + var;
+        lik_ve += lik_c0 - 0.5 * q / lik_s2;
+        lik_dl += -0.5 / lik_s2 + 0.5 * q / (lik_s2 * lik_s2);
+        a.lik_MB[(int64_t)d * a.lik_ld + orow] = -a.lik_w * (y - mu) / lik_s2;
+        a.lik_VB[(int64_t)d * a.lik_ld + orow] = 0.5 * a.lik_w / lik_s2;
+      }
+    }
+  }
+  if constexpr (LIK) {
+    lik_ve = sum_wave(lik_ve);
+    lik_dl = sum_wave(lik_dl);
+    if ((threadIdx.x & 63) == 0) {
+      red[2 * (threadIdx.x >> 6)] = lik_ve;
+      red[2 * (threadIdx.x >> 6) + 1] = lik_dl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.lik_part[2 * (int64_t)blockIdx.x] = (red[0] + red[2]) + (red[4] + red[6]);
+      a.lik_part[2 * (int64_t)blockIdx.x + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+  }
+}
+int layer_gemm_lik_blocks(int64_t Rin, int D_out) { return ceil_div(round_up(Rin, 16), GL_EPI_ROWS); }
+
+// backward, per data row: dX (or the transposed adjoints of the layer below) and this block's hyper-parameter partial sums from
+// OUT = ZZ^T GW:  WZ[j][r] = sum_m w z_mj,  Z2[j][r] = sum_m w z_mj^2,  W1[r] = sum_m w  (w = GW[m][r], z = Z / l)
+//   d X partial      sum_m w (x - z)   = x W1 - WZ
+//   lengthscale part sum_m w (x - z)^2 = x^2 W1 - 2 x WZ + Z2          (x = X / l)
+// hyp_part row of block i: [0, sum_r g_r, -2 (1/l_j) sum_r (...)_j]; rows nb .. nb + nsv - 1 carry [svar / s2, 0, ...] of the
+// element-wise kernel's blocks (written by block 0's neighbours below).
+#define GL_BR 256
+__global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, const double* __restrict__ OUT, const double* __restrict__ svar,
+                                                       int nsv, int nb) {
+  __shared__ double red[GL_BR / 64];
+  const int Din = a.D_in, Dout = a.D_out;
+  const int tid = threadIdx.x;
+  const double* ils = a.hyp + HYP_ILS;
+  const double s2 = a.hyp[HYP_VAR];
+  if ((int)blockIdx.x >= nb) {       // the svar rows
+    const int64_t i0 = ((int64_t)blockIdx.x - nb) * GL_BR;
+    for (int i = tid; i < GL_BR; i += GL_BR) {
+      const int64_t p = i0 + i;
+      if (p < nsv) {
+        double* hp = a.hyp_part + (int64_t)(nb + p) * (Din + 2);
+        hp[0] = svar[p] / s2;
+        for (int j = 1; j < Din + 2; ++j) hp[j] = 0.0;
+      }
+    }
+    return;
+  }
+  const int64_t r = (int64_t)blockIdx.x * GL_BR + tid;
+  const bool rv = r < a.Rin, rl = r < a.ldA;
+  double* hp = a.hyp_part + (int64_t)blockIdx.x * (Din + 2);
+  auto block_sum = [&](double v) -> double {
+    v = sum_wave(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  double g = 0.0;
+  if (rv)
+    for (int d = 0; d < Dout; ++d) g += a.VB[(int64_t)d * a.ldA + r];
+  const double gk = block_sum(g);
+  if (tid == 0) {
+    hp[0] = 0.0;
+    hp[1] = gk;
+  }
+  const double w1 = rl ? OUT[(int64_t)(2 * Din) * a.ldA + r] : 0.0;
+  for (int j = 0; j < Din; ++j) {
+    double sl = 0.0;
+    if (rl) {
+      const double xv = rv ? a.X[r * Din + j] * ils[j] : 0.0;
+      const double wz = OUT[(int64_t)j * a.ldA + r], z2 = OUT[(int64_t)(Din + j) * a.ldA + r];
+      sl = rv ? fma(xv * xv, w1, fma(-2.0 * xv, wz, z2)) : 0.0;
+      if (a.dX || a.MBp) {
+        if (rv) {
+          double dx = 2.0 * ils[j] * fma(xv, w1, -wz);
+          if (a.mean_kind == DSDGP_MEAN_IDENTITY) {
+            dx += a.MB[(int64_t)j * a.ldA + r];
+          } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+            for (int d = 0; d < Dout; ++d) dx = fma(a.mean_A[(int64_t)j * Dout + d], a.MB[(int64_t)d * a.ldA + r], dx);
+          }
+          if (a.MBp) {
+            const int d = j - a.prop;
+            if (d >= 0) {
+              const double zv = a.zp[(r / a.n_inner) * a.zp_s + (r % a.n_inner) * a.zp_n + d * a.zp_d];
+              const double vv = a.varp[r * a.Dp + d];
+              a.MBp[(int64_t)d * a.ldA + r] = dx;
+              a.VBp[(int64_t)d * a.ldA + r] = dx * zv * 0.5 * rsqrt(vv + a.jitter);
+            }
+          } else {
+            a.dX[r * Din + j] = dx;
+          }
+        } else if (a.MBp && j >= a.prop) {
+          a.MBp[(int64_t)(j - a.prop) * a.ldA + r] = 0.0;
+          a.VBp[(int64_t)(j - a.prop) * a.ldA + r] = 0.0;
+        }
+      }
+    }
+    const double tot = block_sum(sl);
+    if (tid == 0) hp[2 + j] = -2.0 * ils[j] * tot;
+  }
+}
+// hyp_part rows the GEMM-formulated backward writes for ld padded rows: one per block of k_gl_bwd_rows + one per block of k_kuf
+int layer_gemm_hyp_parts(int64_t ld, int Mp) { return ceil_div(ld, GL_BR) + ceil_div(ld, KT) * ceil_div(Mp, KT); }
+
+template <bool BWD>
+static int kuf_launch(dsdgp_ctx* ctx, int kern_kind, const KufArgs& k) {
+  const dim3 grid(ceil_div(k.ld, KT), ceil_div(k.Mp, KT));
+  if (kern_kind == DSDGP_KERN_RBF)
+    hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD>), grid, dim3(256), 0, ctx->stream, k);
+  else
+    hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD>), grid, dim3(256), 0, ctx->stream, k);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, const GemmLayerWs& ws) {
+  ProfScope ps(ctx, "layer_fwd");
+  const int64_t ld = a.ldA;
+  const int Dout = a.D_out, tiles_m = ceil_div(Mp, PT);
+  const int64_t MM = (int64_t)Mp * Mp, ML = (int64_t)Mp * ld;
+  hipStream_t st = ctx->stream;
+  // K = k(Z, X)
+  KufArgs k{};
+  k.Zs = a.Zs; k.X = a.X; k.hyp = a.hyp; k.Rin = a.Rin; k.ld = ld; k.M = a.M; k.Mp = Mp; k.D_in = a.D_in; k.D_out = Dout; k.K = ws.T1;
+  DS_TRY(kuf_launch<false>(ctx, kern_kind, k));
+  if (a.XT1) {
+    const int64_t cnt = (int64_t)(a.D_in + 1) * ld;
+    hipLaunchKernelGGL(k_gl_xt1, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, a.X, a.Rin, a.D_in, ld, a.XT1);
+  }
+  const int rows16 = (int)round_up(Dout, 16);
+  hipLaunchKernelGGL(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * Mp, 256)), dim3(256), 0, st, a.qmu, a.qmu_ld ? a.qmu_ld : Dout, Mp, Dout, rows16,
+                     ws.qmuT);
+  DS_HIP(hipGetLastError());
+  // a1 = Lu^-1 K (layers.py:186), |a1|^2 per tile row.  a = Lu^-T a1 (layers.py:188) goes straight to Asave when the pass keeps it.
+  double* Aout = a.Asave ? a.Asave : ws.T1;      // (K is dead once a1 exists)
+  PGemm P{};
+  P.W = a.Linv; P.B = ws.T1; P.C = ws.T2; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
+  P.tri = 2; P.store = 1; P.alpha = 1.0; P.colsq = ws.colsq; P.ldq = ld;
+  DS_TRY(pgemm_launch(ctx, P));
+  P = PGemm{};
+  P.W = a.LinvT; P.B = ws.T2; P.C = Aout; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
+  P.tri = 8; P.store = 1; P.alpha = 1.0;
+  DS_TRY(pgemm_launch(ctx, P));
+  // c_d = q_sqrt_d^T a for every output in one launch: |c_d|^2 per tile row; c_d itself only when the reverse pass wants it
+  P = PGemm{};
+  P.W = a.TpT; P.sW = MM; P.B = Aout; P.sB = 0; P.C = a.Csave; P.sC = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
+  P.batch = Dout; P.tri = 8; P.store = a.Csave ? 1 : 0; P.alpha = 1.0; P.colsq = ws.colsq + (int64_t)tiles_m * ld; P.ldq = ld;
+  DS_TRY(pgemm_launch(ctx, P));
+  // q_mu^T a (layers.py:190)
+  P = PGemm{};
+  P.W = ws.qmuT; P.B = Aout; P.C = ws.MUT; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = rows16; P.n = (int)ld; P.k = Mp; P.batch = 1;
+  P.tri = 0; P.store = 1; P.alpha = 1.0;
+  DS_TRY(pgemm_launch(ctx, P));
+  const int nb = ceil_div(ld, GL_EPI_ROWS);
+  if (a.lik_Y)
+    hipLaunchKernelGGL(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT);
+  else
+    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, const GemmLayerWs& ws) {
+  ProfScope ps(ctx, "layer_bwd");
+  const int64_t ld = b.ldA;
+  const int Dout = b.D_out, Din = b.D_in;
+  const int64_t MM = (int64_t)Mp * Mp, ML = (int64_t)Mp * ld;
+  hipStream_t st = ctx->stream;
+  const int tiles = ceil_div(Mp, PT) * ceil_div(ld, PT);
+  // abar in `groups` partial sums over the outputs (enough tiles to fill the chip: two workgroups per CU) + the mean part
+  int groups = (512 + tiles - 1) / tiles;
+  if (groups > GL_MAX_GROUPS) groups = GL_MAX_GROUPS;
+  if (groups > Dout) groups = Dout;
+  if (groups < 1) groups = 1;
+  PGemm P{};
+  if (b.Csave) {      // abar += q_sqrt_d (2 vbar_d c_d): triangular
+    P.W = b.Tp; P.B = b.Csave; P.sB = ML; P.tri = 2;
+  } else {            // abar += S_d (2 vbar_d a): dense
+    P.W = b.Sd; P.B = b.Asave; P.sB = 0; P.tri = 0;
+  }
+  P.sW = MM; P.C = ws.Pb; P.sCg = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = Dout; P.groups = groups;
+  P.store = 1; P.alpha = 2.0; P.bscale = b.VB; P.sS = ld;
+  DS_TRY(pgemm_launch(ctx, P));
+  P = PGemm{};        // + q_mu mbar  (k = DP4)
+  P.W = b.qmu4; P.B = b.MB; P.C = ws.Pb + (int64_t)groups * ML; P.ldw = b.DP4; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = b.DP4; P.batch = 1;
+  P.store = 1; P.alpha = 1.0;
+  DS_TRY(pgemm_launch(ctx, P));
+  // abar = the partial sums added in a fixed order (in place of the first one), then b = Ku^-1 abar
+  hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups + 1, ML, ML / 2, ws.T2);
+  DS_HIP(hipGetLastError());
+  P = PGemm{};
+  P.W = b.Kinv; P.B = ws.T2; P.C = ws.T1; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
+  P.batch = 1; P.store = 1; P.alpha = 1.0;
+  DS_TRY(pgemm_launch(ctx, P));
+  // e, kbar, GW (+ E) with the kernel recomputed
+  KufArgs k{};
+  k.Zs = b.Zs; k.X = b.X; k.hyp = b.hyp; k.Rin = b.Rin; k.ld = ld; k.M = b.M; k.Mp = Mp; k.D_in = Din; k.D_out = Dout;
+  k.A = b.Asave; k.Bm = ws.T1; k.VB = b.VB; k.E = b.E; k.GW = b.GW; k.svar = ws.svar;
+  DS_TRY(kuf_launch<true>(ctx, kern_kind, k));
+  const int nsv = ceil_div(ld, KT) * ceil_div(Mp, KT);
+  // sums over the inducing rows: OUT = ZZ^T GW
+  const int nzz = 2 * Din + 1, nzz16 = (int)round_up(nzz, 16);
+  hipLaunchKernelGGL(k_gl_zz, dim3(ceil_div((int64_t)nzz16 * Mp, 256)), dim3(256), 0, st, b.Zs, b.M, Mp, Din, nzz16, ws.ZZ);
+  DS_HIP(hipGetLastError());
+  P = PGemm{};
+  P.W = ws.ZZ; P.B = b.GW; P.C = ws.OUTt; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = nzz16; P.n = (int)ld; P.k = Mp; P.batch = 1; P.store = 1; P.alpha = 1.0;
+  DS_TRY(pgemm_launch(ctx, P));
+  const int nb = ceil_div(ld, GL_BR);
+  hipLaunchKernelGGL(k_gl_bwd_rows, dim3(nb + ceil_div(nsv, GL_BR)), dim3(GL_BR), 0, st, b, ws.OUTt, ws.svar, nsv, nb);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}

@@ -98,6 +98,7 @@ struct LayerState {
   int rep_used;
   int64_t ld_used;
   bool c_used = false;   // the last forward stored c_d (Csave) for the backward chain
+  bool gemm = false;     // this layer's passes are whole-layer GEMMs (layer_gemm.hip) instead of the fused chains
 };
 
 struct dsdgp_model {
@@ -119,6 +120,7 @@ struct dsdgp_model {
   GemmProblem* gp_pt;   // P_d T_d (the only KL/q_sqrt GEMM that depends on the backward pass)
   int n_pt = 0, t_pt = 0;
   hipEvent_t ev_fork, ev_prep_side, ev_z;
+  GemmLayerWs gws{};           // scratch of the GEMM-formulated layers (one set per model: the layers run one after the other)
   bool prepared_grad = false;  // the last prepare also produced U_d, n, U_d U_d^T
   bool track_theta = false;    // dsdgp_model_track_theta: the caller reports its writes to theta
   bool kuu_valid = false;      // Lu / Lu^-1 / Ku^-1 belong to the Z and kernel hyper-parameters currently in theta
@@ -163,8 +165,9 @@ struct dsdgp_model {
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; pipe_tail: per-layer reduction + P_d T_d products behind each layer's
   // weight-gradient products 0 / 1; head / tail / adj_fuse / lik_fuse = 0: the unfused launches (parity tests of the fusions);
   // ext_ev = 0: plain event record behind the head launch; red_ahead = 0: one split-K reduction after the stream join;
-  // white_fwd = 0: forward-only evaluations in plain coordinates.
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1; } force;
+  // white_fwd = 0: forward-only evaluations in plain coordinates.  gemm_mp: smallest padded inducing count whose layers take the
+  // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -192,6 +195,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "adj_fuse") m->force.adj_fuse = v;
       else if (k == "ext_ev") m->force.ext_ev = v;
       else if (k == "lik_fuse") m->force.lik_fuse = v;
+      else if (k == "gemm_mp") m->force.gemm_mp = v;
     }
     pos = end + 1;
   }
@@ -326,7 +330,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
       const int alg_env = m->force.alg_g;   // -1: heuristic, 0: never, 1: always
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
       v.alg_g = (!D.white && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
-      v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp)) ? 1 : 0;
+      v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp) || (!D.white && m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp)) ? 1 : 0;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }
@@ -359,7 +363,9 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * Mw * Mw);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
-    S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), 8 * 160) + 16) * (d.D_in + 2));
+    S.gemm = !D.white && m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp;
+    S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), layer_gemm_hyp_parts(S.ld_max, v.Mp)),
+                                                           8 * 160) + 16) * (d.D_in + 2));
     // d-split of the backward chain on small launches (at most 1024 workgroups): partial abar tiles + arrival counters
     S.bpart = b.take<double>((size_t)1024 * (Mp * 16 + 16));
     S.bcnt = b.take<int>(512);
@@ -367,6 +373,27 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
+  }
+  {   // scratch of the GEMM-formulated layers, sized for the largest of them
+    int64_t ML = 0, cq = 0, mut = 0, qt = 0, zz = 0, ot = 0, sv = 0;
+    for (int l = 0; l < D.L; ++l) {
+      const LayerState& S = m->L[l];
+      if (!S.gemm) continue;
+      const LayerDev& v = S.dev;
+      const int64_t ld = S.ld_max, nzz16 = round_up(2 * v.D_in + 1, 16);
+      ML = std::max<int64_t>(ML, (int64_t)v.Mp * ld);
+      cq = std::max<int64_t>(cq, (int64_t)(1 + v.D_out) * ceil_div(v.Mp, 128) * ld);
+      mut = std::max<int64_t>(mut, (int64_t)v.DP16 * ld);
+      qt = std::max<int64_t>(qt, (int64_t)v.DP16 * v.Mp);
+      zz = std::max<int64_t>(zz, nzz16 * v.Mp);
+      ot = std::max<int64_t>(ot, nzz16 * ld);
+      sv = std::max<int64_t>(sv, (int64_t)ceil_div(ld, 64) * ceil_div(v.Mp, 64));
+    }
+    if (ML > 0) {
+      m->gws.T1 = b.take<double>(ML); m->gws.T2 = b.take<double>(ML); m->gws.Pb = b.take<double>((GL_MAX_GROUPS + 1) * ML);
+      m->gws.colsq = b.take<double>(cq); m->gws.MUT = b.take<double>(mut); m->gws.qmuT = b.take<double>(qt);
+      m->gws.ZZ = b.take<double>(zz); m->gws.OUTt = b.take<double>(ot); m->gws.svar = b.take<double>(sv + 16);
+    }
   }
   *total = (size_t)round_up((int64_t)b.off, 256);
 }
@@ -1921,7 +1948,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     const int rep = (l == 0) ? S : 1;
     const bool last = (l == L - 1);
     const bool want_F = !last || need_last_F;
-    const bool wf = wf_ok && v.Mp <= 256;
+    const bool wf = wf_ok && v.Mp <= 256 && !St.gemm;
     LayerFwdArgs a{};
     a.X = Xin; a.Rin = Rin; a.rep = rep;
     a.D_in = v.D_in; a.D_out = v.D_out; a.M = v.M;
@@ -1952,6 +1979,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
     St.c_used = save_l && St.C && sm_cs_built(v.Mp) &&
                 (v.Mp > 256 || ((Rin + 15) / 16 > m->force.cs_min_blocks && v.D_out >= m->force.cs_min_dout));
+    if (St.gemm) St.c_used = save_l && St.C != nullptr;      // the triangular abar product halves the largest GEMM of the reverse pass
     a.Csave = St.c_used ? St.C : nullptr;
     a.XT1 = save_l ? St.XT1 : nullptr;
     {
@@ -1960,10 +1988,11 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
       if (last && lik_Y) {      // Gaussian variational expectations + adjoints in this chain's epilogue
         a.lik_Y = lik_Y; a.lik_const = m->lik_const; a.lik_w = lik_w; a.lik_part = m->lik_part;
         a.lik_MB = St.MB; a.lik_VB = St.VB; a.lik_ld = round_up(Rin, 16);
-        *lik_nblocks = (int)nblk * a.d_split;
+        *lik_nblocks = St.gemm ? layer_gemm_lik_blocks(Rin, v.D_out) : (int)nblk * a.d_split;
       }
     }
-    DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white || wf));
+    if (St.gemm) DS_TRY(layer_fwd_gemm_launch(ctx, a, v.Mp, v.kern_kind, m->gws));
+    else DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white || wf));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
     if (St.prop && !last) {
@@ -2057,7 +2086,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     jobsB.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, startB, 0, v.DinP16 / 16, 0, 0});   // GW [X|1]^T -> Z
     startB += ns * ti * tjz;
     redB.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
-    redB.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, (int)sm_hyp_parts(ld, v.Mp, v.D_in), 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
+    redB.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, St.gemm ? layer_gemm_hyp_parts(ld, v.Mp) : (int)sm_hyp_parts(ld, v.Mp, v.D_in), 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
     // one list [A | B] with cumulative task numbers: one launch per layer
     std::vector<WgradJob> jobs(jobsA);
     for (WgradJob J : jobsB) {
@@ -2175,7 +2204,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // row; MultiClass) by k_adj_prep
     const bool fused = (last && m->fused_last) || (!last && l >= 1);
     // ... or, for a first layer below others, by this layer's own backward chain in its prologue (LayerBwdArgs::up_dF)
-    const bool in_chain = !fused && !last && m->force.adj_fuse != 0 && !St.c_used && sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
+    const bool in_chain = !fused && !last && m->force.adj_fuse != 0 && !St.c_used && !St.gemm && sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
     if (!fused && !in_chain)
       hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                          last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
@@ -2216,7 +2245,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
-    DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
+    if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->gws));
+    else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, ctx->stream));
       if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
@@ -2568,6 +2598,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
+  if (St.gemm && a.ldA <= St.ld_max) return layer_fwd_gemm_launch(m->ctx, a, v.Mp, v.kern_kind, m->gws);
   return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
 }
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 4: forced GEMM path on the parity shapes + rocprofv3 kernel stats of configs 4 / 5 (serial schedule)
+cd "$GRAFT_REPO_ROOT" || exit 1
+R=$PWD; mkdir -p gpurun_out; O=$R/gpurun_out/r4b; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+DSDGP_FORCE=gemm_mp=16 timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -q > $O/t_forced.log 2>&1; tail -40 $O/t_forced.log | cut -c1-250
+for c in 4 5; do
+  rm -rf /tmp/prof$c
+  (cd /tmp && DSDGP_NO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$c -o p -- python $R/tools/ab_kernels.py $c > $O/run$c.log 2>&1)
+  DB=$(find /tmp/prof$c -name "*results.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $O/kernel_stats_cfg$c.md "round 4 (gemm path, first version): config-$c shape (tools/ab_kernels.py $c) under rocprofv3 --kernel-trace --stats, serial schedule" > /dev/null
+  grep "^{" $O/run$c.log
+  head -22 $O/kernel_stats_cfg$c.md | cut -c1-200
+done
