@@ -26,7 +26,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // One product of a layer pass.  INDEPENDENT mode (groups == 0): for every batch item b
 //     C[b] = alpha W[b] (m x k, row-major) (B'[b] (k x n, row-major))      B' = B with its columns scaled by bscale[b] (or as it is)
 // and colsq[(b tiles_m + tile row) ldq + col] = sum over the tile's rows of C^2.  REDUCE mode (groups > 0): the batch items are cut
-// into `groups` contiguous runs, run z is summed into C + z sCg.
+// into `groups` contiguous runs, run z is summed into C + z sCg; run 0 also adds the TAIL product W2 (m x k2) B2 (k2 x n) (unscaled,
+// dense: the q_mu mbar term of abar) when k2 > 0.
 // tri = 2: W lower-triangular (k ranges over [0, tile row's last row]) ; 8: upper-triangular (k from the tile's first row) ; 0: dense.
 struct PGemm {
   const double* W;
@@ -34,15 +35,23 @@ struct PGemm {
   double* C;
   const double* bscale;
   double* colsq;
-  int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg;
-  int32_t m, n, k, batch, groups, tri, store, pad;
+  const double* W2;
+  const double* B2;
+  int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg, ldw2;
+  int32_t m, n, k, batch, groups, tri, store, k2;
   int32_t tiles_m, tiles_n;
-  double alpha;
+  double alpha, bs_mul;     // bs_mul multiplies the column scales
 };
 
+// TN: tile width (128, or 64 for launches that would not fill the chip with 128-wide tiles: twice the tiles, the four waves take
+// 64 x 32 each).  Two workgroups per CU either way (LDS), i.e. two waves per SIMD — what the fp64 MFMA pipe needs to run at its rate.
+template <int TN>
 __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
+  constexpr int PLB = TN + 16;         // LDS row stride of the B tile: like PLD, the k-rows g and g + 1 sit 32 banks apart
+  constexpr int NB = TN / 16;          // doubles of a B row per staging thread (8 / 4)
+  constexpr int NJ = TN / 32;          // 16-column blocks per wave
   __shared__ __attribute__((aligned(16))) double As[2][PK * PLD];
-  __shared__ __attribute__((aligned(16))) double Bs[2][PK * PLD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][PK * PLB];
   const int Z = P.groups > 0 ? P.groups : P.batch;
   int t = blockIdx.x;
   const int tn = t % P.tiles_n;
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   const int z = t % Z, tmi = t / Z;
   // workgroups are dispatched in index order: the tile rows with the longest k range go first (longest-processing-time order)
   const int tm = (P.tri == 2) ? P.tiles_m - 1 - tmi : tmi;
-  const int m0 = tm * PT, n0 = tn * PT;
+  const int m0 = tm * PT, n0 = tn * TN;
   int b0, b1;
   if (P.groups > 0) {
     const int bc = (P.batch + P.groups - 1) / P.groups;
@@ -64,35 +73,44 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int wr = wave >> 1, wc = wave & 1;
-  d4 acc[4][4];
+  d4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0, 0, 0, 0};
   int kmin = 0, kmax = P.k;
   if (P.tri == 2) kmax = min(kmax, m0 + PT);
   if (P.tri == 8) kmin = m0;
   const int ks_lo = kmin / PK;
   const int ksteps = max(0, (kmax + PK - 1) / PK - ks_lo);
-  const int nsteps = (b1 - b0) * ksteps;
+  const int nmain = (b1 - b0) * ksteps;
+  const int nsteps = nmain + ((P.groups > 0 && z == 0 && P.k2 > 0) ? (P.k2 + PK - 1) / PK : 0);
   // staging roles: W rows (k contiguous): thread takes row m0 + tid / 2, k = 8 (tid & 1) .. + 7 ; B rows (n contiguous): k = tid / 16,
-  // n = n0 + 8 (tid & 15) .. + 7.  64 contiguous bytes per thread either way, as four 16-byte loads.
+  // n = n0 + NB (tid & 15) .. + NB - 1.  16-byte loads.
   const int am = m0 + (tid >> 1), ak = 8 * (tid & 1);
-  const int bk = tid >> 4, bn = n0 + 8 * (tid & 15);
-  const bool a_row = am < P.m, b_col = bn + 8 <= P.n;
-  double ra[8], rb[8], sv[8];
+  const int bk = tid >> 4, bn = n0 + NB * (tid & 15);
+  const bool a_row = am < P.m, b_col = bn + NB <= P.n;
+  double ra[8], rb[NB], sv[NB];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) sv[u] = 1.0;
+  for (int u = 0; u < NB; ++u) sv[u] = 1.0;
   int kq = 0;          // first k of the W chunk in flight (for the triangle mask applied when it is stored to LDS)
+  int tri_q = 0;       // triangle mask of the chunk in flight (none on the tail product)
+  double bs_q = 1.0;   // multiplier of the column scales of the chunk in flight (1 on the tail product)
   // gload only ISSUES the loads of a step; everything that consumes the loaded values (triangle mask, column scale) happens in lstore,
   // i.e. after the MFMAs of the step that runs meanwhile — a use inside gload would put the memory round trip in front of them
   auto gload = [&](int step) {
-    const int bi = step / ksteps;
-    const int b = b0 + bi, k0 = (ks_lo + step - bi * ksteps) * PK;
+    const bool tail = step >= nmain;
+    const int bi = tail ? 0 : step / ksteps;
+    const int b = b0 + bi;
+    const int k0 = tail ? (step - nmain) * PK : (ks_lo + step - bi * ksteps) * PK;
+    const int kdim = tail ? P.k2 : P.k;
+    const int64_t ldw = tail ? P.ldw2 : P.ldw;
     kq = k0 + ak;
+    tri_q = tail ? 0 : P.tri;
+    bs_q = tail ? 1.0 : P.bs_mul;
     {
-      gcptr src = (gcptr)(P.W + (int64_t)b * P.sW + (int64_t)am * P.ldw + k0 + ak);
-      if (a_row && k0 + ak + 8 <= P.k) {
+      gcptr src = (gcptr)((tail ? P.W2 : P.W + (int64_t)b * P.sW) + (int64_t)am * ldw + k0 + ak);
+      if (a_row && k0 + ak + 8 <= kdim) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
@@ -101,49 +119,56 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ra[u] = (a_row && k0 + ak + u < P.k) ? src[u] : 0.0;
+        for (int u = 0; u < 8; ++u) ra[u] = (a_row && k0 + ak + u < kdim) ? src[u] : 0.0;
       }
     }
     {
-      const bool ok = b_col && k0 + bk < P.k;
-      gcptr src = (gcptr)(P.B + (int64_t)b * P.sB + (int64_t)(k0 + bk) * P.ldb + bn);
+      const bool ok = b_col && k0 + bk < kdim;
+      gcptr src = (gcptr)((tail ? P.B2 : P.B + (int64_t)b * P.sB) + (int64_t)(k0 + bk) * P.ldb + bn);
       if (ok) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NB / 2; ++u) {
           const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
           rb[2 * u] = v[0];
           rb[2 * u + 1] = v[1];
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rb[u] = 0.0;
+        for (int u = 0; u < NB; ++u) rb[u] = 0.0;
       }
-      if (P.bscale && step == bi * ksteps && b_col) {      // first k-step of batch item b: its column scales
-        gcptr sp = (gcptr)(P.bscale + (int64_t)b * P.sS + bn);
+      if (P.bscale) {
+        if (tail) {
+          if (step == nmain) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sv[u] = sp[u];
+            for (int u = 0; u < NB; ++u) sv[u] = 1.0;
+          }
+        } else if (step == bi * ksteps && b_col) {      // first k-step of batch item b: its column scales
+          gcptr sp = (gcptr)(P.bscale + (int64_t)b * P.sS + bn);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) sv[u] = sp[u];
+        }
       }
     }
   };
   auto lstore = [&](int buf) {
     const int mm = tid >> 1;
     // entries of the other triangle inside the diagonal tile are not trusted to be zero in memory
-    if (P.tri == 2) {
+    if (tri_q == 2) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) ra[u] = (kq + u <= am) ? ra[u] : 0.0;
-    } else if (P.tri == 8) {
+    } else if (tri_q == 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) ra[u] = (kq + u >= am) ? ra[u] : 0.0;
     }
     if (P.bscale) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rb[u] *= sv[u];
+      for (int u = 0; u < NB; ++u) rb[u] *= sv[u] * bs_q;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) As[buf][(ak + u) * PLD + mm] = ra[u];
-    double* brow = &Bs[buf][bk * PLD + 8 * (tid & 15)];
+    double* brow = &Bs[buf][bk * PLB + NB * (tid & 15)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(brow + 2 * u) = (d2){rb[2 * u], rb[2 * u + 1]};
+    for (int u = 0; u < NB / 2; ++u) *reinterpret_cast<d2*>(brow + 2 * u) = (d2){rb[2 * u], rb[2 * u + 1]};
   };
   if (nsteps > 0) {
     gload(0);
@@ -155,15 +180,15 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
     if (step + 1 < nsteps) gload(step + 1);
 #pragma unroll
     for (int k4 = 0; k4 < PK; k4 += 4) {
-      double a[4], bq[4];
+      double a[4], bq[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = As[buf][(k4 + g) * PLD + wr * 64 + 16 * i + c];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = Bs[buf][(k4 + g) * PLD + wc * 64 + 16 * j + c];
+      for (int j = 0; j < NJ; ++j) bq[j] = Bs[buf][(k4 + g) * PLB + wc * (TN / 2) + 16 * j + c];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(a[i], bq[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f64(a[i], bq[j], acc[i][j]);
     }
     if (step + 1 < nsteps) lstore(buf ^ 1);     // the other buffer: its last readers passed the previous barrier
     __syncthreads();
@@ -173,11 +198,11 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb)
+      for (int jb = 0; jb < NJ; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wr * 64 + ib * 16 + g + 4 * r;
-          const int col = n0 + wc * 64 + jb * 16 + c;
+          const int col = n0 + wc * (TN / 2) + jb * 16 + c;
           if (row < P.m && col < P.n) C[(int64_t)row * P.ldc + col] = P.alpha * acc[ib][jb][r];
         }
   }
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
     // two waves that share the columns through LDS (fixed order).  Rows >= m hold zero (masked W rows).
     double* cs = &As[0][0];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
+    for (int jb = 0; jb < NJ; ++jb) {
       double s = 0.0;
 #pragma unroll
       for (int ib = 0; ib < 4; ++ib)
@@ -196,23 +221,87 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
           s = fma(v, v, s);
         }
       s = sum_groups(s);
-      if (g == 0) cs[wr * PT + wc * 64 + jb * 16 + c] = s;
+      if (g == 0) cs[wr * TN + wc * (TN / 2) + jb * 16 + c] = s;
     }
     __syncthreads();
-    if (tid < PT) {
+    if (tid < TN) {
       const int col = n0 + tid;
-      if (col < P.n) P.colsq[((int64_t)b0 * P.tiles_m + tm) * P.ldq + col] = cs[tid] + cs[PT + tid];
+      if (col < P.n) P.colsq[((int64_t)b0 * P.tiles_m + tm) * P.ldq + col] = cs[tid] + cs[TN + tid];
     }
   }
 }
 
-static int pgemm_launch(dsdgp_ctx* ctx, PGemm P, const char* prof = "layer_gemm") {
+// Thin products C (mt x n) = W (mt x k) B (k x n) with mt = 16 or 32 rows (q_mu^T a; ZZ^T GW at narrow inputs): memory-bound on B, which a
+// 128-row tile would read for 4 - 8x the MFMA work it needs.  One workgroup per 32 columns, its four waves a quarter of k each with
+// both operands straight from global memory (B: 128-byte runs per 16 lanes; W is small and cache-resident), partial tiles added
+// through LDS in wave order.
+#define THC 32
+__global__ __launch_bounds__(256) void k_thin(const double* __restrict__ W, int64_t ldw, const double* __restrict__ B, int64_t ldb,
+                                              double* __restrict__ C, int64_t ldc, int mt, int n, int k, int accumulate) {
+  __shared__ double red[4][4][4][64];          // [wave][tile][reg][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = blockIdx.x * THC;
+  const int nit = mt / 16;                     // 1 or 2 row tiles
+  const int kq = (((k + 3) / 4 + 3) / 4) * 4;  // k per wave: a quarter of k rounded up to whole MFMA steps (k < 4: all of it in wave 0)
+  const int k_lo = wave * kq, k_hi = min(k, k_lo + kq);
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+  const bool c0 = n0 + c < n, c1 = n0 + 16 + c < n;
+  const int col0 = c0 ? n0 + c : 0, col1 = c1 ? n0 + 16 + c : 0;
+#pragma unroll 4
+  for (int kk = k_lo; kk < k_hi; kk += 4) {
+    const int kr = kk + g;
+    const bool kin = kr < k_hi;
+    const int krc = kin ? kr : k_lo;
+    const double b0v = B[(int64_t)krc * ldb + col0], b1v = B[(int64_t)krc * ldb + col1];
+    const double a0 = W[(int64_t)c * ldw + krc];
+    const double a1 = (nit > 1) ? W[(int64_t)(16 + c) * ldw + krc] : 0.0;
+    const double a0m = kin ? a0 : 0.0, a1m = kin ? a1 : 0.0;
+    acc[0][0] = mfma_f64(a0m, c0 ? b0v : 0.0, acc[0][0]);
+    acc[0][1] = mfma_f64(a0m, c1 ? b1v : 0.0, acc[0][1]);
+    if (nit > 1) {
+      acc[1][0] = mfma_f64(a1m, c0 ? b0v : 0.0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1m, c1 ? b1v : 0.0, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][2 * i + j][r][lane] = acc[i][j][r];
+  __syncthreads();
+  // 4 tiles x 4 registers x 64 lanes = 1024 sums over the four waves, 4 per thread
+  for (int e = tid; e < 1024; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, tl = e >> 8;
+    const int i = tl >> 1, j = tl & 1;
+    if (i >= nit) continue;
+    const double v = (red[0][tl][r][l] + red[1][tl][r][l]) + (red[2][tl][r][l] + red[3][tl][r][l]);
+    const int row = 16 * i + (l >> 4) + 4 * r, col = n0 + 16 * j + (l & 15);
+    if (col < n) C[(int64_t)row * ldc + col] = accumulate ? C[(int64_t)row * ldc + col] + v : v;
+  }
+}
+static int thin_launch(dsdgp_ctx* ctx, const double* W, int64_t ldw, const double* B, int64_t ldb, double* C, int64_t ldc, int mt, int n, int k,
+                       int accumulate = 0) {
+  hipLaunchKernelGGL(k_thin, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
+static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
   P.tiles_m = ceil_div(P.m, PT);
-  P.tiles_n = ceil_div(P.n, PT);
   const int Z = P.groups > 0 ? P.groups : P.batch;
+  // 128-wide tiles when they fill the chip (two workgroups per CU), else 64-wide ones
+  const bool narrow = (int64_t)P.tiles_m * ceil_div(P.n, PT) * Z < 512;
+  P.tiles_n = ceil_div(P.n, narrow ? 64 : PT);
   const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * Z;
   if (blocks <= 0) return DSDGP_OK;
-  hipLaunchKernelGGL(k_pgemm, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  if (narrow) hipLaunchKernelGGL(k_pgemm<64>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  else hipLaunchKernelGGL(k_pgemm<128>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -333,6 +422,7 @@ __global__ void k_gl_sum(const double* __restrict__ part, int n, int64_t stride,
   reinterpret_cast<d2*>(out)[i] = s;
 }
 // q_mu^T, zero padded to (rows16 x Mp); [X^T ; 1] of the layer input for the Z-gradient product
+// (also the transposed, padded map of a Linear mean function: qmu = mean_A (D_in x D_out), Mp = D_in)
 __global__ void k_gl_qmut(const double* __restrict__ qmu, int qld, int Mp, int D_out, int rows16, double* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows16 * Mp) return;
@@ -360,71 +450,97 @@ __global__ void k_gl_zz(const double* __restrict__ Zs, int M, int Mp, int D_in, 
   out[idx] = v;
 }
 
-// forward epilogue: one thread per (row, output); the first layer writes `rep` output rows per input row
+// forward epilogue.  A workgroup takes 64 data rows; the per-tile-row sums of squares and q_mu^T a arrive M-major (coalesced along
+// the rows), go through LDS and leave row-major (a row's outputs are contiguous in mean / var / F), 32 outputs at a time.
+// The first layer writes `rep` output rows per input row.
 #define GL_EPI_ROWS 64
+#define GL_EPI_DC 32
+// lin_done: the Linear mean function's X mean_A is already part of MUT (thin product on [X^T ; 1]); only the bias is added here
 template <bool LIK>
-__global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const double* __restrict__ colsq, int tiles_m, const double* __restrict__ MUT) {
+__global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const double* __restrict__ colsq, int tiles_m, const double* __restrict__ MUT,
+                                                     int lin_done) {
   __shared__ double red[8];
-  const int Dout = a.D_out, Din = a.D_in;
+  __shared__ double s1s[GL_EPI_ROWS];
+  __shared__ double s2s[GL_EPI_DC][GL_EPI_ROWS + 1];
+  __shared__ double mus[GL_EPI_DC][GL_EPI_ROWS + 1];
+  const int Dout = a.D_out, Din = a.D_in, tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * GL_EPI_ROWS;
   const double kdiag = a.hyp[HYP_KDIAG];
   const double lik_s2 = LIK ? a.lik_const[0] : 1.0;
   const double lik_c0 = -0.91893853320467274178 - 0.5 * log(lik_s2);
   double lik_ve = 0.0, lik_dl = 0.0;
-  const int nitem = GL_EPI_ROWS * Dout;
-  for (int e = threadIdx.x; e < nitem; e += 256) {
-    const int rr = e / Dout, d = e - rr * Dout;
-    const int64_t r = r0 + rr;
-    if (r >= a.Rin) {
-      if (LIK && r < a.lik_ld) {          // rows of the 16-row padding of the transposed adjoints
-        a.lik_MB[(int64_t)d * a.lik_ld + r] = 0.0;
-        a.lik_VB[(int64_t)d * a.lik_ld + r] = 0.0;
+  if (tid < GL_EPI_ROWS) {
+    const int64_t r = r0 + tid;
+    double v = 0.0;
+    if (r < a.ldA)
+      for (int t = 0; t < tiles_m; ++t) v += colsq[(int64_t)t * a.ldA + r];
+    s1s[tid] = v;
+  }
+  for (int d0 = 0; d0 < Dout; d0 += GL_EPI_DC) {
+    const int dn = min(GL_EPI_DC, Dout - d0);
+    __syncthreads();
+    for (int idx = tid; idx < dn * GL_EPI_ROWS; idx += 256) {
+      const int dd = idx / GL_EPI_ROWS, rr = idx - dd * GL_EPI_ROWS;
+      const int64_t r = r0 + rr;
+      double v = 0.0, mu = 0.0;
+      if (r < a.ldA) {
+        for (int t = 0; t < tiles_m; ++t) v += colsq[((int64_t)(1 + d0 + dd) * tiles_m + t) * a.ldA + r];
+        mu = MUT[(int64_t)(d0 + dd) * a.ldA + r];                           // layers.py:190
       }
-      continue;
+      s2s[dd][rr] = v;
+      mus[dd][rr] = mu;
     }
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles_m; ++t) {
-      s1 += colsq[(int64_t)t * a.ldA + r];
-      s2 += colsq[((int64_t)(1 + d) * tiles_m + t) * a.ldA + r];
-    }
-    const double var = kdiag - s1 + s2;                                  // layers.py:212-217
-    double mu = MUT[(int64_t)d * a.ldA + r];                             // layers.py:190
-    if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
-      mu += a.X[r * Din + d];
-    } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
-      double m2 = 0.0;
-      for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
-      mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
-    }
-    const double sd = sqrt(var + a.jitter);
-    for (int s = 0; s < a.rep; ++s) {
-      const int64_t orow = (int64_t)s * a.Rin + r;
-      const int64_t o = orow * Dout + d;
-      if (a.mean) a.mean[o] = mu;
-      if (a.var) a.var[o] = var;
-      if (a.F && a.z) {
-        const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
-        a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
+    __syncthreads();
+    for (int e = tid; e < dn * GL_EPI_ROWS; e += 256) {
+      const int rr = e / dn, dd = e - rr * dn, d = d0 + dd;
+      const int64_t r = r0 + rr;
+      if (r >= a.Rin) {
+        if (LIK && r < a.lik_ld) {          // rows of the 16-row padding of the transposed adjoints
+          a.lik_MB[(int64_t)d * a.lik_ld + r] = 0.0;
+          a.lik_VB[(int64_t)d * a.lik_ld + r] = 0.0;
+        }
+        continue;
       }
-      if constexpr (LIK) {
-        const double y = a.lik_Y[(orow % a.n_inner) * Dout + d];
-        const double q = (y - mu) * (y - mu) + var;
-        lik_ve += lik_c0 - 0.5 * q / lik_s2;
-        lik_dl += -0.5 / lik_s2 + 0.5 * q / (lik_s2 * lik_s2);
-        a.lik_MB[(int64_t)d * a.lik_ld + orow] = -a.lik_w * (y - mu) / lik_s2;
-        a.lik_VB[(int64_t)d * a.lik_ld + orow] = 0.5 * a.lik_w / lik_s2;
+      const double var = kdiag - s1s[rr] + s2s[dd][rr];                     // layers.py:212-217
+      double mu = mus[dd][rr];
+      if (a.mean_kind == DSDGP_MEAN_IDENTITY) {                            // layers.py:219
+        mu += a.X[r * Din + d];
+      } else if (a.mean_kind == DSDGP_MEAN_LINEAR) {
+        double m2 = 0.0;
+        if (!lin_done)
+          for (int j = 0; j < Din; ++j) m2 = fma(a.X[r * Din + j], a.mean_A[(int64_t)j * Dout + d], m2);
+        mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
+      }
+      const double sd = sqrt(var + a.jitter);
+      for (int s = 0; s < a.rep; ++s) {
+        const int64_t orow = (int64_t)s * a.Rin + r;
+        const int64_t o = orow * Dout + d;
+        if (a.mean) a.mean[o] = mu;
+        if (a.var) a.var[o] = var;
+        if (a.F && a.z) {
+          const double zv = a.z[(orow / a.n_inner) * a.zs_s + (orow % a.n_inner) * a.zs_n + d * a.zs_d];
+          a.F[o] = mu + zv * sd;                                           // utils.py:41 (no clamp)
+        }
+        if constexpr (LIK) {
+          const double y = a.lik_Y[(orow % a.n_inner) * Dout + d];
+          const double q = (y - mu) * (y - mu) + var;
+          lik_ve += lik_c0 - 0.5 * q / lik_s2;
+          lik_dl += -0.5 / lik_s2 + 0.5 * q / (lik_s2 * lik_s2);
+          a.lik_MB[(int64_t)d * a.lik_ld + orow] = -a.lik_w * (y - mu) / lik_s2;
+          a.lik_VB[(int64_t)d * a.lik_ld + orow] = 0.5 * a.lik_w / lik_s2;
+        }
       }
     }
   }
   if constexpr (LIK) {
     lik_ve = sum_wave(lik_ve);
     lik_dl = sum_wave(lik_dl);
-    if ((threadIdx.x & 63) == 0) {
-      red[2 * (threadIdx.x >> 6)] = lik_ve;
-      red[2 * (threadIdx.x >> 6) + 1] = lik_dl;
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = lik_ve;
+      red[2 * (tid >> 6) + 1] = lik_dl;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       a.lik_part[2 * (int64_t)blockIdx.x] = (red[0] + red[2]) + (red[4] + red[6]);
       a.lik_part[2 * (int64_t)blockIdx.x + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
@@ -438,46 +554,52 @@ int layer_gemm_lik_blocks(int64_t Rin, int D_out) { return ceil_div(round_up(Rin
 //   lengthscale part sum_m w (x - z)^2 = x^2 W1 - 2 x WZ + Z2          (x = X / l)
 // hyp_part row of block i: [0, sum_r g_r, -2 (1/l_j) sum_r (...)_j]; rows nb .. nb + nsv - 1 carry [svar / s2, 0, ...] of the
 // element-wise kernel's blocks (written by block 0's neighbours below).
+// grid (row blocks + svar blocks, chunks of GL_JC input dimensions): a chunk's workgroup owns columns 2 + j of its row block's hyp_part
+// row for its own j (chunk 0 also columns 0, 1), so that the 784 dimensions of a wide first layer spread over 49 workgroups per row block
 #define GL_BR 256
+#define GL_JC 16
 __global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, const double* __restrict__ OUT, const double* __restrict__ svar,
                                                        int nsv, int nb) {
-  __shared__ double red[GL_BR / 64];
+  __shared__ double red[2][GL_BR / 64];
   const int Din = a.D_in, Dout = a.D_out;
   const int tid = threadIdx.x;
   const double* ils = a.hyp + HYP_ILS;
   const double s2 = a.hyp[HYP_VAR];
   if ((int)blockIdx.x >= nb) {       // the svar rows
-    const int64_t i0 = ((int64_t)blockIdx.x - nb) * GL_BR;
-    for (int i = tid; i < GL_BR; i += GL_BR) {
-      const int64_t p = i0 + i;
-      if (p < nsv) {
-        double* hp = a.hyp_part + (int64_t)(nb + p) * (Din + 2);
-        hp[0] = svar[p] / s2;
-        for (int j = 1; j < Din + 2; ++j) hp[j] = 0.0;
-      }
+    if (blockIdx.y != 0) return;
+    const int64_t p = ((int64_t)blockIdx.x - nb) * GL_BR + tid;
+    if (p < nsv) {
+      double* hp = a.hyp_part + (int64_t)(nb + p) * (Din + 2);
+      hp[0] = svar[p] / s2;
+      for (int j = 1; j < Din + 2; ++j) hp[j] = 0.0;
     }
     return;
   }
   const int64_t r = (int64_t)blockIdx.x * GL_BR + tid;
   const bool rv = r < a.Rin, rl = r < a.ldA;
   double* hp = a.hyp_part + (int64_t)blockIdx.x * (Din + 2);
-  auto block_sum = [&](double v) -> double {
+  int par = 0;
+  auto block_sum = [&](double v) -> double {      // (alternating scratch: one barrier per sum)
     v = sum_wave(v);
+    if ((tid & 63) == 0) red[par][tid >> 6] = v;
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    const double t = (red[par][0] + red[par][1]) + (red[par][2] + red[par][3]);
+    par ^= 1;
+    return t;
   };
-  double g = 0.0;
-  if (rv)
-    for (int d = 0; d < Dout; ++d) g += a.VB[(int64_t)d * a.ldA + r];
-  const double gk = block_sum(g);
-  if (tid == 0) {
-    hp[0] = 0.0;
-    hp[1] = gk;
+  if (blockIdx.y == 0) {
+    double g = 0.0;
+    if (rv)
+      for (int d = 0; d < Dout; ++d) g += a.VB[(int64_t)d * a.ldA + r];
+    const double gk = block_sum(g);
+    if (tid == 0) {
+      hp[0] = 0.0;
+      hp[1] = gk;
+    }
   }
   const double w1 = rl ? OUT[(int64_t)(2 * Din) * a.ldA + r] : 0.0;
-  for (int j = 0; j < Din; ++j) {
+  const int j_lo = blockIdx.y * GL_JC, j_hi = min(Din, j_lo + GL_JC);
+  for (int j = j_lo; j < j_hi; ++j) {
     double sl = 0.0;
     if (rl) {
       const double xv = rv ? a.X[r * Din + j] * ils[j] : 0.0;
@@ -536,11 +658,14 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   KufArgs k{};
   k.Zs = a.Zs; k.X = a.X; k.hyp = a.hyp; k.Rin = a.Rin; k.ld = ld; k.M = a.M; k.Mp = Mp; k.D_in = a.D_in; k.D_out = Dout; k.K = ws.T1;
   DS_TRY(kuf_launch<false>(ctx, kern_kind, k));
-  if (a.XT1) {
-    const int64_t cnt = (int64_t)(a.D_in + 1) * ld;
-    hipLaunchKernelGGL(k_gl_xt1, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, a.X, a.Rin, a.D_in, ld, a.XT1);
-  }
+  // [X^T ; 1]: the Z-gradient product of the reverse pass reads it, and so does the Linear mean function's product below
   const int rows16 = (int)round_up(Dout, 16);
+  const bool lin_thin = a.mean_kind == DSDGP_MEAN_LINEAR && rows16 <= 32;
+  double* XT = a.XT1 ? a.XT1 : (lin_thin ? ws.OUTt : nullptr);
+  if (XT) {
+    const int64_t cnt = (int64_t)(a.D_in + 1) * ld;
+    hipLaunchKernelGGL(k_gl_xt1, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, a.X, a.Rin, a.D_in, ld, XT);
+  }
   hipLaunchKernelGGL(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * Mp, 256)), dim3(256), 0, st, a.qmu, a.qmu_ld ? a.qmu_ld : Dout, Mp, Dout, rows16,
                      ws.qmuT);
   DS_HIP(hipGetLastError());
@@ -560,15 +685,26 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   P.batch = Dout; P.tri = 8; P.store = a.Csave ? 1 : 0; P.alpha = 1.0; P.colsq = ws.colsq + (int64_t)tiles_m * ld; P.ldq = ld;
   DS_TRY(pgemm_launch(ctx, P));
   // q_mu^T a (layers.py:190)
-  P = PGemm{};
-  P.W = ws.qmuT; P.B = Aout; P.C = ws.MUT; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = rows16; P.n = (int)ld; P.k = Mp; P.batch = 1;
-  P.tri = 0; P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_launch(ctx, P));
+  if (rows16 <= 32) {
+    DS_TRY(thin_launch(ctx, ws.qmuT, Mp, Aout, ld, ws.MUT, ld, rows16, (int)ld, Mp));
+  } else {
+    P = PGemm{};
+    P.W = ws.qmuT; P.B = Aout; P.C = ws.MUT; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = rows16; P.n = (int)ld; P.k = Mp; P.batch = 1;
+    P.tri = 0; P.store = 1; P.alpha = 1.0;
+    DS_TRY(pgemm_launch(ctx, P));
+  }
+  if (lin_thin) {
+    // Linear mean function (layers.py:219; the PCA step-down of a 784-pixel first layer): MUT += mean_A^T X^T as a thin product — the
+    // per-(row, output) dot product over D_in strided reads was 0.97 ms per step at config 4
+    hipLaunchKernelGGL(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * a.D_in, 256)), dim3(256), 0, st, a.mean_A, Dout, a.D_in, Dout, rows16, ws.ZZ);
+    DS_HIP(hipGetLastError());
+    DS_TRY(thin_launch(ctx, ws.ZZ, a.D_in, XT, ld, ws.MUT, ld, rows16, (int)ld, a.D_in, 1));
+  }
   const int nb = ceil_div(ld, GL_EPI_ROWS);
   if (a.lik_Y)
-    hipLaunchKernelGGL(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT);
+    hipLaunchKernelGGL(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT);
+    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -579,9 +715,10 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   const int Dout = b.D_out, Din = b.D_in;
   const int64_t MM = (int64_t)Mp * Mp, ML = (int64_t)Mp * ld;
   hipStream_t st = ctx->stream;
-  const int tiles = ceil_div(Mp, PT) * ceil_div(ld, PT);
-  // abar in `groups` partial sums over the outputs (enough tiles to fill the chip: two workgroups per CU) + the mean part
-  int groups = (512 + tiles - 1) / tiles;
+  // abar = sum_d (...) + q_mu mbar: the outputs in `groups` runs when one run per tile would not fill the chip with 128-wide tiles
+  // (partial sums in Pb, added in a fixed order), the q_mu mbar term as the tail product of run 0
+  const int tiles128 = ceil_div(Mp, PT) * ceil_div(ld, PT);
+  int groups = (512 + tiles128 - 1) / tiles128;           // (128-wide tiles run at 50 TFLOP/s when they fill the chip, 64-wide ones at 31 - 38)
   if (groups > GL_MAX_GROUPS) groups = GL_MAX_GROUPS;
   if (groups > Dout) groups = Dout;
   if (groups < 1) groups = 1;
@@ -591,17 +728,15 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   } else {            // abar += S_d (2 vbar_d a): dense
     P.W = b.Sd; P.B = b.Asave; P.sB = 0; P.tri = 0;
   }
-  P.sW = MM; P.C = ws.Pb; P.sCg = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = Dout; P.groups = groups;
-  P.store = 1; P.alpha = 2.0; P.bscale = b.VB; P.sS = ld;
+  P.sW = MM; P.C = groups > 1 ? ws.Pb : ws.T2; P.sCg = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = Dout;
+  P.groups = groups; P.store = 1; P.alpha = 1.0; P.bscale = b.VB; P.sS = ld; P.bs_mul = 2.0;      // columns scaled by 2 vbar_d
+  P.W2 = b.qmu4; P.B2 = b.MB; P.k2 = b.DP4; P.ldw2 = b.DP4;
   DS_TRY(pgemm_launch(ctx, P));
-  P = PGemm{};        // + q_mu mbar  (k = DP4)
-  P.W = b.qmu4; P.B = b.MB; P.C = ws.Pb + (int64_t)groups * ML; P.ldw = b.DP4; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = b.DP4; P.batch = 1;
-  P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_launch(ctx, P));
-  // abar = the partial sums added in a fixed order (in place of the first one), then b = Ku^-1 abar
-  hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups + 1, ML, ML / 2, ws.T2);
-  DS_HIP(hipGetLastError());
-  P = PGemm{};
+  if (groups > 1) {
+    hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2);
+    DS_HIP(hipGetLastError());
+  }
+  P = PGemm{};        // b = Ku^-1 abar
   P.W = b.Kinv; P.B = ws.T2; P.C = ws.T1; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
   P.batch = 1; P.store = 1; P.alpha = 1.0;
   DS_TRY(pgemm_launch(ctx, P));
@@ -615,11 +750,15 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   const int nzz = 2 * Din + 1, nzz16 = (int)round_up(nzz, 16);
   hipLaunchKernelGGL(k_gl_zz, dim3(ceil_div((int64_t)nzz16 * Mp, 256)), dim3(256), 0, st, b.Zs, b.M, Mp, Din, nzz16, ws.ZZ);
   DS_HIP(hipGetLastError());
-  P = PGemm{};
-  P.W = ws.ZZ; P.B = b.GW; P.C = ws.OUTt; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = nzz16; P.n = (int)ld; P.k = Mp; P.batch = 1; P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_launch(ctx, P));
+  if (nzz16 <= 32) {
+    DS_TRY(thin_launch(ctx, ws.ZZ, Mp, b.GW, ld, ws.OUTt, ld, nzz16, (int)ld, Mp));
+  } else {
+    P = PGemm{};
+    P.W = ws.ZZ; P.B = b.GW; P.C = ws.OUTt; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = nzz16; P.n = (int)ld; P.k = Mp; P.batch = 1; P.store = 1; P.alpha = 1.0;
+    DS_TRY(pgemm_launch(ctx, P));
+  }
   const int nb = ceil_div(ld, GL_BR);
-  hipLaunchKernelGGL(k_gl_bwd_rows, dim3(nb + ceil_div(nsv, GL_BR)), dim3(GL_BR), 0, st, b, ws.OUTt, ws.svar, nsv, nb);
+  hipLaunchKernelGGL(k_gl_bwd_rows, dim3(nb + ceil_div(nsv, GL_BR), ceil_div(Din, GL_JC)), dim3(GL_BR), 0, st, b, ws.OUTt, ws.svar, nsv, nb);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

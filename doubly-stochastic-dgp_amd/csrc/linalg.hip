@@ -393,9 +393,10 @@ static bool gemm_small_ok(const GemmProblem& P) {
 
 int gemm_plan(GemmProblem* host, int nprob, int allow_big) {
   int big = allow_big == 2, small = nprob > 0;          // 2: the 128 x 128 kernel whatever the sizes (in-place 128-column panels)
+  static const int big_min = getenv("DSDGP_GEMM_BIG_MIN") ? atoi(getenv("DSDGP_GEMM_BIG_MIN")) : GEMM_BIG_MIN;   // (A/B aid)
   if (allow_big == 1)
     for (int i = 0; i < nprob; ++i)
-      if (host[i].m >= GEMM_BIG_MIN && host[i].n >= GEMM_BIG_MIN && host[i].k >= 64) big = 1;
+      if (host[i].m >= big_min && host[i].n >= big_min && host[i].k >= 64) big = 1;
   for (int i = 0; i < nprob; ++i) small = small && gemm_small_ok(host[i]);
   if (big) small = 0;
   const int T = big ? BT : GT;
