@@ -23,11 +23,13 @@
 #define PLD 144    // LDS row stride in doubles: the g and g + 1 k-rows of a fragment read sit 32 banks apart (conflict-free ds_read_b64)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-// One product of a layer pass.  INDEPENDENT mode (groups == 0): for every batch item b
-//     C[b] = alpha W[b] (m x k, row-major) (B'[b] (k x n, row-major))      B' = B with its columns scaled by bscale[b] (or as it is)
-// and colsq[(b tiles_m + tile row) ldq + col] = sum over the tile's rows of C^2.  REDUCE mode (groups > 0): the batch items are cut
-// into `groups` contiguous runs, run z is summed into C + z sCg; run 0 also adds the TAIL product W2 (m x k2) B2 (k2 x n) (unscaled,
-// dense: the q_mu mbar term of abar) when k2 > 0.
+// One product of a layer pass:  C[o] = alpha * sum over a range of (batch item, k) steps of  W[b] (m x k, row-major) B'[b] (k x n)
+//   B' = B (k x n, row-major) with its columns scaled by bs_mul * bscale[b][col] (or as it is).
+// reduce_batch = 0: every batch item is its own output o = b;  1: the batch items are summed into ONE output (o = 0), followed by the
+//   TAIL product W2 (m x k2) B2 (k2 x n) (unscaled, dense: the q_mu mbar term of abar) when k2 > 0.
+// groups >= 1: the step range of an output is cut into `groups` contiguous pieces, piece g goes to C + o sC + g sCg (partial sums:
+//   split-K / split-batch; the caller adds them in a fixed order).  colsq (groups == 1 only): colsq[(o tiles_m + tile row) ldq + col] =
+//   sum over the tile's rows of C^2.
 // tri = 2: W lower-triangular (k ranges over [0, tile row's last row]) ; 8: upper-triangular (k from the tile's first row) ; 0: dense.
 struct PGemm {
   const double* W;
@@ -38,7 +40,7 @@ struct PGemm {
   const double* W2;
   const double* B2;
   int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg, ldw2;
-  int32_t m, n, k, batch, groups, tri, store, k2;
+  int32_t m, n, k, batch, reduce_batch, groups, tri, store, k2, pad;
   int32_t tiles_m, tiles_n;
   double alpha, bs_mul;     // bs_mul multiplies the column scales
 };
@@ -52,24 +54,17 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   constexpr int NJ = TN / 32;          // 16-column blocks per wave
   __shared__ __attribute__((aligned(16))) double As[2][PK * PLD];
   __shared__ __attribute__((aligned(16))) double Bs[2][PK * PLB];
-  const int Z = P.groups > 0 ? P.groups : P.batch;
+  const int G = P.groups > 1 ? P.groups : 1;
+  const int nb_out = P.reduce_batch ? 1 : P.batch;
+  const int Z = nb_out * G;
   int t = blockIdx.x;
   const int tn = t % P.tiles_n;
   t /= P.tiles_n;
   const int z = t % Z, tmi = t / Z;
   // workgroups are dispatched in index order: the tile rows with the longest k range go first (longest-processing-time order)
   const int tm = (P.tri == 2) ? P.tiles_m - 1 - tmi : tmi;
+  const int o = z / G, gidx = z - o * G;
   const int m0 = tm * PT, n0 = tn * TN;
-  int b0, b1;
-  if (P.groups > 0) {
-    const int bc = (P.batch + P.groups - 1) / P.groups;
-    b0 = z * bc;
-    b1 = min(P.batch, b0 + bc);
-    if (b1 < b0) b1 = b0;
-  } else {
-    b0 = z;
-    b1 = z + 1;
-  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int wr = wave >> 1, wc = wave & 1;
@@ -83,8 +78,9 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   if (P.tri == 8) kmin = m0;
   const int ks_lo = kmin / PK;
   const int ksteps = max(0, (kmax + PK - 1) / PK - ks_lo);
-  const int nmain = (b1 - b0) * ksteps;
-  const int nsteps = nmain + ((P.groups > 0 && z == 0 && P.k2 > 0) ? (P.k2 + PK - 1) / PK : 0);
+  const int nmain = (P.reduce_batch ? P.batch : 1) * ksteps;
+  const int T = nmain + ((P.reduce_batch && P.k2 > 0) ? (P.k2 + PK - 1) / PK : 0);
+  const int s_lo = (int)((int64_t)gidx * T / G), s_hi = (int)((int64_t)(gidx + 1) * T / G);
   // staging roles: W rows (k contiguous): thread takes row m0 + tid / 2, k = 8 (tid & 1) .. + 7 ; B rows (n contiguous): k = tid / 16,
   // n = n0 + NB (tid & 15) .. + NB - 1.  16-byte loads.
   const int am = m0 + (tid >> 1), ak = 8 * (tid & 1);
@@ -96,12 +92,12 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   int kq = 0;          // first k of the W chunk in flight (for the triangle mask applied when it is stored to LDS)
   int tri_q = 0;       // triangle mask of the chunk in flight (none on the tail product)
   double bs_q = 1.0;   // multiplier of the column scales of the chunk in flight (1 on the tail product)
-  // gload only ISSUES the loads of a step; everything that consumes the loaded values (triangle mask, column scale) happens in lstore,
+  // gload only ISSUES the loads of a step; everything that consumes the loaded values (triangle mask, scales) happens in lstore,
   // i.e. after the MFMAs of the step that runs meanwhile — a use inside gload would put the memory round trip in front of them
   auto gload = [&](int step) {
     const bool tail = step >= nmain;
     const int bi = tail ? 0 : step / ksteps;
-    const int b = b0 + bi;
+    const int b = P.reduce_batch ? bi : o;
     const int k0 = tail ? (step - nmain) * PK : (ks_lo + step - bi * ksteps) * PK;
     const int kdim = tail ? P.k2 : P.k;
     const int64_t ldw = tail ? P.ldw2 : P.ldw;
@@ -138,11 +134,11 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
       }
       if (P.bscale) {
         if (tail) {
-          if (step == nmain) {
+          if (step == nmain || step == s_lo) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) sv[u] = 1.0;
           }
-        } else if (step == bi * ksteps && b_col) {      // first k-step of batch item b: its column scales
+        } else if ((step == bi * ksteps || step == s_lo) && b_col) {      // first k-step of batch item b in this piece: its column scales
           gcptr sp = (gcptr)(P.bscale + (int64_t)b * P.sS + bn);
 #pragma unroll
           for (int u = 0; u < NB; ++u) sv[u] = sp[u];
@@ -160,24 +156,24 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) ra[u] = (kq + u >= am) ? ra[u] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) As[buf][(ak + u) * PLD + mm] = ra[u];
     if (P.bscale) {
 #pragma unroll
       for (int u = 0; u < NB; ++u) rb[u] *= sv[u] * bs_q;
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) As[buf][(ak + u) * PLD + mm] = ra[u];
     double* brow = &Bs[buf][bk * PLB + NB * (tid & 15)];
 #pragma unroll
     for (int u = 0; u < NB / 2; ++u) *reinterpret_cast<d2*>(brow + 2 * u) = (d2){rb[2 * u], rb[2 * u + 1]};
   };
-  if (nsteps > 0) {
-    gload(0);
+  if (s_hi > s_lo) {
+    gload(s_lo);
     lstore(0);
   }
   __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < nsteps) gload(step + 1);
+  for (int step = s_lo; step < s_hi; ++step) {
+    const int buf = (step - s_lo) & 1;
+    if (step + 1 < s_hi) gload(step + 1);
 #pragma unroll
     for (int k4 = 0; k4 < PK; k4 += 4) {
       double a[4], bq[NJ];
@@ -190,11 +186,11 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f64(a[i], bq[j], acc[i][j]);
     }
-    if (step + 1 < nsteps) lstore(buf ^ 1);     // the other buffer: its last readers passed the previous barrier
+    if (step + 1 < s_hi) lstore(buf ^ 1);     // the other buffer: its last readers passed the previous barrier
     __syncthreads();
   }
   if (P.store) {
-    gptr C = (gptr)(P.C + (P.groups > 0 ? (int64_t)z * P.sCg : (int64_t)b0 * P.sC));
+    gptr C = (gptr)(P.C + (int64_t)o * P.sC + (int64_t)gidx * P.sCg);
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
     __syncthreads();
     if (tid < TN) {
       const int col = n0 + tid;
-      if (col < P.n) P.colsq[((int64_t)b0 * P.tiles_m + tm) * P.ldq + col] = cs[tid] + cs[TN + tid];
+      if (col < P.n) P.colsq[((int64_t)o * P.tiles_m + tm) * P.ldq + col] = cs[tid] + cs[TN + tid];
     }
   }
 }
@@ -294,7 +290,8 @@ static int thin_launch(dsdgp_ctx* ctx, const double* W, int64_t ldw, const doubl
 
 static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
   P.tiles_m = ceil_div(P.m, PT);
-  const int Z = P.groups > 0 ? P.groups : P.batch;
+  const int G = P.groups > 1 ? P.groups : 1;
+  const int Z = (P.reduce_batch ? 1 : P.batch) * G;
   // 128-wide tiles when they fill the chip (two workgroups per CU), else 64-wide ones
   const bool narrow = (int64_t)P.tiles_m * ceil_div(P.n, PT) * Z < 512;
   P.tiles_n = ceil_div(P.n, narrow ? 64 : PT);
@@ -715,12 +712,11 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   const int Dout = b.D_out, Din = b.D_in;
   const int64_t MM = (int64_t)Mp * Mp, ML = (int64_t)Mp * ld;
   hipStream_t st = ctx->stream;
-  // abar = sum_d (...) + q_mu mbar: the outputs in `groups` runs when one run per tile would not fill the chip with 128-wide tiles
-  // (partial sums in Pb, added in a fixed order), the q_mu mbar term as the tail product of run 0
+  // abar = sum_d (...) + q_mu mbar (the tail product): the (output, k) steps of a tile cut into `groups` contiguous pieces when one
+  // workgroup per tile would not fill the chip with 128-wide tiles (partial sums in Pb, added in a fixed order)
   const int tiles128 = ceil_div(Mp, PT) * ceil_div(ld, PT);
   int groups = (512 + tiles128 - 1) / tiles128;           // (128-wide tiles run at 50 TFLOP/s when they fill the chip, 64-wide ones at 31 - 38)
   if (groups > GL_MAX_GROUPS) groups = GL_MAX_GROUPS;
-  if (groups > Dout) groups = Dout;
   if (groups < 1) groups = 1;
   PGemm P{};
   if (b.Csave) {      // abar += q_sqrt_d (2 vbar_d c_d): triangular
@@ -729,7 +725,7 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
     P.W = b.Sd; P.B = b.Asave; P.sB = 0; P.tri = 0;
   }
   P.sW = MM; P.C = groups > 1 ? ws.Pb : ws.T2; P.sCg = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = Dout;
-  P.groups = groups; P.store = 1; P.alpha = 1.0; P.bscale = b.VB; P.sS = ld; P.bs_mul = 2.0;      // columns scaled by 2 vbar_d
+  P.reduce_batch = 1; P.groups = groups; P.store = 1; P.alpha = 1.0; P.bscale = b.VB; P.sS = ld; P.bs_mul = 2.0;   // columns scaled by 2 vbar_d
   P.W2 = b.qmu4; P.B2 = b.MB; P.k2 = b.DP4; P.ldw2 = b.DP4;
   DS_TRY(pgemm_launch(ctx, P));
   if (groups > 1) {

@@ -4,6 +4,7 @@
 //                     the blocked triangular inverse that turns the two tf.matrix_triangular_solve calls of
 //                     layers.py:186,188 into MFMA products inside the layer chain kernel.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "linalg.hpp"
 #include "chol_lds.hpp"
@@ -16,10 +17,15 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
   __shared__ double As[GK * GLD];
   __shared__ double Bs[GK * GLD];
   const int bid = blockIdx.x;
-  int p = 0;
-  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  int p = 0, t;
+  if (probs[0].order) {          // longest-processing-time order of the launch (gemm_plan_lpt)
+    p = probs[0].order[2 * bid];
+    t = probs[0].order[2 * bid + 1];
+  } else {
+    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    t = bid - probs[p].tile_start;
+  }
   const GemmProblem P = probs[p];
-  int t = bid - P.tile_start;
   const int tiles = P.tiles_m * P.tiles_n;
   int b0, b1;
   if (P.batch_reduce) {
@@ -133,10 +139,15 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmProblem* __restrict_
   __shared__ __attribute__((aligned(16))) double As[2][BK * BLD];
   __shared__ __attribute__((aligned(16))) double Bs[2][BK * BLD];
   const int bid = blockIdx.x;
-  int p = 0;
-  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  int p = 0, t;
+  if (probs[0].order) {          // longest-processing-time order of the launch (gemm_plan_lpt)
+    p = probs[0].order[2 * bid];
+    t = probs[0].order[2 * bid + 1];
+  } else {
+    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    t = bid - probs[p].tile_start;
+  }
   const GemmProblem P = probs[p];
-  int t = bid - P.tile_start;
   const int tiles = P.tiles_m * P.tiles_n;
   int b0, b1;
   if (P.batch_reduce) {
@@ -307,10 +318,15 @@ __device__ __forceinline__ void gemm_small_loop(gcptr A, gcptr B, int64_t lda, i
 
 __global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restrict__ probs, int nprob) {
   const int bid = blockIdx.x;
-  int p = 0;
-  while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+  int p = 0, t;
+  if (probs[0].order) {          // longest-processing-time order of the launch (gemm_plan_lpt)
+    p = probs[0].order[2 * bid];
+    t = probs[0].order[2 * bid + 1];
+  } else {
+    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    t = bid - probs[p].tile_start;
+  }
   const GemmProblem P = probs[p];
-  int t = bid - P.tile_start;
   const int tiles = P.tiles_m * P.tiles_n;
   int b0, b1;
   if (P.batch_reduce) {
@@ -409,6 +425,39 @@ int gemm_plan(GemmProblem* host, int nprob, int allow_big) {
     total += P.tiles_m * P.tiles_n * (P.batch_reduce ? 1 : P.batch);
   }
   return big ? (total | GEMM_BIG_FLAG) : (small ? (total | GEMM_SMALL_FLAG) : total);
+}
+
+int gemm_plan_lpt(GemmProblem* host, int nprob, std::vector<int32_t>& order, int allow_big) {
+  const int planned = gemm_plan(host, nprob, allow_big);
+  const bool big = (planned & GEMM_BIG_FLAG) != 0;
+  const int T = big ? BT : GT;
+  struct Tile { int work, p, t; };
+  std::vector<Tile> tiles;
+  for (int p = 0; p < nprob; ++p) {
+    const GemmProblem& P = host[p];
+    const int per = P.tiles_m * P.tiles_n, nb = P.batch_reduce ? 1 : P.batch;
+    for (int t = 0; t < per * nb; ++t) {
+      const int tt = t % per;
+      const int m0 = (tt / P.tiles_n) * T, n0 = (tt % P.tiles_n) * T;
+      if (P.lower_only && n0 > m0) continue;
+      // the k range the kernels give this tile (the LDS-free kernel trims per 32 x 32 quarter: its widest quarter has this range)
+      int kmin = 0, kmax = P.k;
+      if (P.tri & 1) kmin = std::max(kmin, n0);
+      if (P.tri & 2) kmax = std::min(kmax, m0 + T);
+      if (P.tri & 4) kmax = std::min(kmax, n0 + T);
+      if (P.tri & 8) kmin = std::max(kmin, m0);
+      const int steps = std::max(0, (kmax + 15) / 16 - kmin / 16) * (P.batch_reduce ? P.batch : 1);
+      tiles.push_back(Tile{steps, p, t});
+    }
+  }
+  std::stable_sort(tiles.begin(), tiles.end(), [](const Tile& a, const Tile& b) { return a.work > b.work; });
+  order.clear();
+  order.reserve(2 * tiles.size());
+  for (const Tile& t : tiles) {
+    order.push_back(t.p);
+    order.push_back(t.t);
+  }
+  return (int)tiles.size() | (planned & (GEMM_BIG_FLAG | GEMM_SMALL_FLAG));
 }
 
 static void gemm_dispatch(const GemmProblem* dev, int nprob, int planned, hipStream_t st) {

@@ -19,6 +19,12 @@ struct GemmProblem {
                              //   1: B[k][n] lower-triangular (k >= n)      2: A[m][k] lower-triangular (k <= m)
                              //   4: transB with B[n][k] lower-triangular (k <= n)   8: A[m][k] upper-triangular (k >= m)
                              //  16: with lower_only — also store the transposed tile (symmetric result, full matrix wanted)
+  // Longest-processing-time tile order of the launch this problem belongs to (gemm_plan_lpt; the same pointer in every problem of the
+  // launch, NULL: workgroup b takes tile b): workgroup b takes tile order[2 b + 1] of problem order[2 b].  The structure hints give the
+  // tiles of one launch k ranges from one to M / 16 steps; in index order the longest ones of the last problem start last and the launch
+  // ends with a few workgroups running alone (the four 17 x 1024^3 launches of a config-5 step: ~800 us each against ~400 us of work).
+  const int32_t* order;
+  int32_t n_order, pad_order;
 };
 
 // One matrix of a batched factorisation launch (n multiple of 16; rows/cols >= nreal carry an identity pad).
@@ -34,6 +40,10 @@ struct PotrfItem {
 // Fills tile_start/tiles_* of `host` problems, returns the total number of tiles (64 x 64, or 128 x 128 with the large-tile
 // kernel flagged in bit 30 when the launch holds a problem of at least 512 x 512 and allow_big): pass it to gemm_launch as is.
 int gemm_plan(GemmProblem* host, int nprob, int allow_big = 1);     // 0: 64 x 64 kernels only, 1: by size, 2: the 128 x 128 kernel
+// gemm_plan + the launch's tiles that do any work (lower_only drops the ones above the diagonal), heaviest first: `order` gets
+// (problem, tile) pairs; the caller puts them in device memory and points every problem's `order` / `n_order` at them.  The returned
+// count (with the kernel flags) is the number of pairs = workgroups to launch.
+int gemm_plan_lpt(GemmProblem* host, int nprob, std::vector<int32_t>& order, int allow_big = 1);
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream = nullptr);
 // n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant

@@ -120,6 +120,8 @@ struct dsdgp_model {
   GemmProblem* gp_pt;   // P_d T_d (the only KL/q_sqrt GEMM that depends on the backward pass)
   int n_pt = 0, t_pt = 0;
   hipEvent_t ev_fork, ev_prep_side, ev_z;
+  int32_t* gemm_order = nullptr;   // device pool of the longest-processing-time tile lists of the grouped M x M launches (gemm_plan_lpt)
+  int64_t gemm_order_cap = 0, gemm_order_used = 0;
   GemmLayerWs gws{};           // scratch of the GEMM-formulated layers (one set per model: the layers run one after the other)
   bool prepared_grad = false;  // the last prepare also produced U_d, n, U_d U_d^T
   bool track_theta = false;    // dsdgp_model_track_theta: the caller reports its writes to theta
@@ -373,6 +375,16 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.wj = b.take<WgradJob>(d.D_out + 4);
     S.ng_gp = b.take<GemmProblem>(5);
     S.ng_items = b.take<PotrfItem>(2 * d.D_out);
+  }
+  {   // tile lists of the grouped M x M launches: every problem list is planned at most three times (whole model, per layer, natural
+      // gradients), a problem has at most D_out x (Mw / 64)^2 tiles
+    int64_t cap = 0;
+    for (int l = 0; l < D.L; ++l) {
+      const int64_t t64 = ceil_div(pad_Mw(m->L[l].dev.Mp), 64);
+      cap += (int64_t)(20 * D.layers[l].D_out + 24) * t64 * t64;
+    }
+    m->gemm_order_cap = 2 * 2 * cap;
+    m->gemm_order = b.take<int32_t>((size_t)m->gemm_order_cap);
   }
   {   // scratch of the GEMM-formulated layers, sized for the largest of them
     int64_t ML = 0, cq = 0, mut = 0, qt = 0, zz = 0, ot = 0, sv = 0;
@@ -1548,6 +1560,24 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   std::vector<LayerDev> ld(L);
   std::vector<PotrfItem> items(L);
   std::vector<GemmProblem> gf, g1, g2, w1, w2, w3, wz, gpt;
+  // plan a launch and give it its longest-processing-time tile list (device copy in the model's pool; in index order when the pool is full)
+  m->gemm_order_used = 0;
+  auto plan_lpt = [&](GemmProblem* probs, int n) -> int {
+    std::vector<int32_t> order;
+    const int total = gemm_plan_lpt(probs, n, order);
+    if (order.empty() || m->gemm_order_used + (int64_t)order.size() > m->gemm_order_cap) return gemm_plan(probs, n);
+    int32_t* dst = m->gemm_order + m->gemm_order_used;
+    // (on the model's stream: behind the asynchronous clearing of the workspace)
+    if (hipMemcpyAsync(dst, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return gemm_plan(probs, n);
+    for (int i = 0; i < n; ++i) {
+      probs[i].order = dst;
+      probs[i].n_order = (int32_t)(order.size() / 2);
+    }
+    m->gemm_order_used += (int64_t)order.size();
+    return total;
+  };
   int64_t asm_elems = 0;
   for (int l = 0; l < L; ++l) {
     const LayerDev& v = m->L[l].dev;
@@ -1599,12 +1629,12 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       LayerState& Sq = m->L[l];
       std::vector<GemmProblem> lq(gf.begin() + gf0, gf.end());
       Sq.lq_nf = (int)lq.size();
-      Sq.lq_tf = gemm_plan(lq.data(), Sq.lq_nf);
+      Sq.lq_tf = plan_lpt(lq.data(), Sq.lq_nf);
       std::vector<GemmProblem> q1(g1.begin() + g10, g1.end()), q2(g2.begin() + g20, g2.end());
-      Sq.lq_n1 = (int)q1.size(); Sq.lq_t1 = gemm_plan(q1.data(), Sq.lq_n1);
-      Sq.lq_n2 = (int)q2.size(); Sq.lq_t2 = gemm_plan(q2.data(), Sq.lq_n2);
+      Sq.lq_n1 = (int)q1.size(); Sq.lq_t1 = plan_lpt(q1.data(), Sq.lq_n1);
+      Sq.lq_n2 = (int)q2.size(); Sq.lq_t2 = plan_lpt(q2.data(), Sq.lq_n2);
       std::vector<GemmProblem> qp(gpt.begin() + gp0, gpt.end());
-      Sq.lq_np = (int)qp.size(); Sq.lq_tp = gemm_plan(qp.data(), Sq.lq_np);
+      Sq.lq_np = (int)qp.size(); Sq.lq_tp = plan_lpt(qp.data(), Sq.lq_np);
       lq.insert(lq.end(), q1.begin(), q1.end());
       lq.insert(lq.end(), q2.begin(), q2.end());
       lq.insert(lq.end(), qp.begin(), qp.end());
@@ -1631,16 +1661,16 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       fill_gemm(ng[1], v.ngTinv, v.ngTinv, v.ngSinv, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);   // S^-1
       ng[0].lower_only = 1; ng[0].tri = 8 | 1;          // upper x lower; k_ng_phi keeps tril(H) only
       ng[1].lower_only = 1; ng[1].tri = 8 | 1 | 16;     // upper x lower, symmetric (as Ku^-1)
-      St.ng_t1 = gemm_plan(ng, 2);
+      St.ng_t1 = plan_lpt(ng, 2);
       fill_gemm(ng[2], v.ngH, v.ngTinv, v.ngY, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);         // Phi T^-1
       ng[2].tri = 2 | 1;                                // lower x lower = lower (the tiles above the diagonal come out as zeros: ng[3] reads them)
-      St.ng_t2 = gemm_plan(ng + 2, 1);
+      St.ng_t2 = plan_lpt(ng + 2, 1);
       fill_gemm(ng[3], v.ngTinv, v.ngY, v.ngX, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);         // T^-T Phi T^-1
       ng[3].tri = 8 | 1;                                // upper x lower
-      St.ng_t3 = gemm_plan(ng + 3, 1);
+      St.ng_t3 = plan_lpt(ng + 3, 1);
       fill_gemm(ng[4], v.ngLAinvT, v.ngLAinv, v.ngSplus, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);  // S+
       ng[4].lower_only = 1; ng[4].tri = 8 | 1 | 16;     // upper x lower, symmetric
-      St.ng_t4 = gemm_plan(ng + 4, 1);
+      St.ng_t4 = plan_lpt(ng + 4, 1);
       DS_HIP(hipMemcpyAsync(St.ng_gp, ng, sizeof(ng), hipMemcpyHostToDevice, st));
       std::vector<PotrfItem> it(2 * v.D_out);
       for (int d = 0; d < v.D_out; ++d) {
@@ -1675,19 +1705,19 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   }
   m->head_ok = m->force.head != 0 && !m->uniform_big;
   for (int l = 0; l < L; ++l) m->head_ok = m->head_ok && m->L[l].dev.Mp <= HEAD_MAX_N && m->L[l].dev.D_in <= HEAD_MAX_DIN;
-  m->n_fwd = (int)gf.size(); m->t_fwd = gemm_plan(gf.data(), m->n_fwd);
-  m->n_bwd1 = (int)g1.size(); m->t_bwd1 = gemm_plan(g1.data(), m->n_bwd1);
-  m->n_pt = (int)gpt.size(); m->t_pt = gemm_plan(gpt.data(), m->n_pt);
+  m->n_fwd = (int)gf.size(); m->t_fwd = plan_lpt(gf.data(), m->n_fwd);
+  m->n_bwd1 = (int)g1.size(); m->t_bwd1 = plan_lpt(g1.data(), m->n_bwd1);
+  m->n_pt = (int)gpt.size(); m->t_pt = plan_lpt(gpt.data(), m->n_pt);
   DS_HIP(hipMemcpyAsync(m->gp_pt, gpt.data(), gpt.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
-  m->n_bwd2 = (int)g2.size(); m->t_bwd2 = gemm_plan(g2.data(), m->n_bwd2);
+  m->n_bwd2 = (int)g2.size(); m->t_bwd2 = plan_lpt(g2.data(), m->n_bwd2);
   m->n_wz = (int)wz.size();
   if (m->n_wz) {
-    m->t_wz = gemm_plan(wz.data(), m->n_wz);
+    m->t_wz = plan_lpt(wz.data(), m->n_wz);
     DS_HIP(hipMemcpyAsync(m->gp_wz, wz.data(), wz.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
   }
   m->asm_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, asm_elems / 1024));
   m->n_w = L;
-  m->t_w1 = gemm_plan(w1.data(), 2 * L); m->t_w2 = gemm_plan(w2.data(), L); m->t_w3 = gemm_plan(w3.data(), L);
+  m->t_w1 = plan_lpt(w1.data(), 2 * L); m->t_w2 = plan_lpt(w2.data(), L); m->t_w3 = plan_lpt(w3.data(), L);
   DS_HIP(hipMemcpyAsync(m->gp_w1, w1.data(), w1.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
   DS_HIP(hipMemcpyAsync(m->gp_w2, w2.data(), w2.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
   DS_HIP(hipMemcpyAsync(m->gp_w3, w3.data(), w3.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, st));
