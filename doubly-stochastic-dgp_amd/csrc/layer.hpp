@@ -147,6 +147,7 @@ struct GemmLayerWs {
   double* ZZ;        // (Mp_max x nzz_max)   [Z/l | (Z/l)^2 | 1]
   double* OUTt;      // (nzz_max x ld_max)   ZZ^T GW
   double* svar;      // per block of the element-wise backward kernel: sum kbar k
+  int64_t pb_doubles; // capacity of Pb
 };
 #define GL_MAX_GROUPS 4
 // doubles of each GemmLayerWs array for a model whose gemm-path layers have at most these extents

@@ -17,6 +17,7 @@
 //   ZZ^T GW with ZZ = [Z/l | (Z/l)^2 | 1]                k_pgemm (W = ZZ^T)  -> sums over the inducing rows for dX and the lengthscales
 //   dX / transposed adjoints of the layer below, hyp_part k_gl_bwd_rows
 #include "layer.hpp"
+#include <algorithm>
 
 #define PT 128     // output tile (both dimensions)
 #define PK 16      // k per staging step
@@ -326,25 +327,28 @@ struct KufArgs {
   double* GW;
   double* svar;         // [blocks]
 };
-template <int KIND, bool BWD>
+// TS: tile edge, 64 or 32 (small launches — the 512 x 512 tile of a 784-pixel first layer is 64 tiles of 64 x 64 on 256 CUs, each a
+// chain of 784 staged dimensions — take 32 x 32 tiles: four times the workgroups, a quarter of the chain each)
+template <int KIND, bool BWD, int TS>
 __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
-  __shared__ double zt[KD][KT + 1];
-  __shared__ double xt[KD][KT + 1];
+  constexpr int NI = TS / 16;
+  __shared__ double zt[KD][TS + 1];
+  __shared__ double xt[KD][TS + 1];
   __shared__ double red[4];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * KT;
-  const int m0 = blockIdx.y * KT;
+  const int64_t r0 = (int64_t)blockIdx.x * TS;
+  const int m0 = blockIdx.y * TS;
   const double* ils = a.hyp + HYP_ILS;
   const double s2 = a.hyp[HYP_VAR];
-  double r2[4][4];
+  double r2[NI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r2[i][j] = 0.0;
+    for (int j = 0; j < NI; ++j) r2[i][j] = 0.0;
   for (int d0 = 0; d0 < a.D_in; d0 += KD) {
     const int dn = min(KD, a.D_in - d0);
     if (d0 > 0) __syncthreads();
-    for (int idx = tid; idx < KT * dn; idx += 256) {
+    for (int idx = tid; idx < TS * dn; idx += 256) {
       const int rr = idx / dn, d = idx - rr * dn;
       const int mrow = min(m0 + rr, a.Mp - 1);
       zt[d][rr] = a.Zs[(int64_t)mrow * a.D_in + d0 + d];
@@ -353,25 +357,25 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
     }
     __syncthreads();
     for (int d = 0; d < dn; ++d) {
-      double zv[4], xv[4];
+      double zv[NI], xv[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) zv[i] = zt[d][ty + 16 * i];
+      for (int i = 0; i < NI; ++i) zv[i] = zt[d][ty + 16 * i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[j] = xt[d][tx + 16 * j];
+      for (int j = 0; j < NI; ++j) xv[j] = xt[d][tx + 16 * j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NI; ++j) {
           const double df = zv[i] - xv[j];
           r2[i][j] = fma(df, df, r2[i][j]);
         }
     }
   }
   double sv = 0.0;
-  double gs[4];
+  double gs[NI];
   if constexpr (BWD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const int64_t r = r0 + tx + 16 * j;
       double s = 0.0;
       if (r < a.ld)
@@ -380,11 +384,11 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int m = m0 + ty + 16 * i;
     if (m >= a.Mp) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const int64_t r = r0 + tx + 16 * j;
       if (r >= a.ld) continue;
       const bool ok = (m < a.M) && (r < a.Rin);
@@ -632,15 +636,25 @@ __global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, con
   }
 }
 // hyp_part rows the GEMM-formulated backward writes for ld padded rows: one per block of k_gl_bwd_rows + one per block of k_kuf
-int layer_gemm_hyp_parts(int64_t ld, int Mp) { return ceil_div(ld, GL_BR) + ceil_div(ld, KT) * ceil_div(Mp, KT); }
+static inline int kuf_tile(int64_t ld, int Mp);
+int layer_gemm_hyp_parts(int64_t ld, int Mp) {
+  const int ts = kuf_tile(ld, Mp);
+  return ceil_div(ld, GL_BR) + ceil_div(ld, ts) * ceil_div(Mp, ts);
+}
 
+// tile edge of the Kuf kernels for a launch of these extents (the same rule sizes the svar partials of the backward form)
+static inline int kuf_tile(int64_t ld, int Mp) { return ((int64_t)ceil_div(ld, KT) * ceil_div(Mp, KT) >= 256) ? KT : 32; }
 template <bool BWD>
 static int kuf_launch(dsdgp_ctx* ctx, int kern_kind, const KufArgs& k) {
-  const dim3 grid(ceil_div(k.ld, KT), ceil_div(k.Mp, KT));
-  if (kern_kind == DSDGP_KERN_RBF)
-    hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD>), grid, dim3(256), 0, ctx->stream, k);
-  else
-    hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD>), grid, dim3(256), 0, ctx->stream, k);
+  const int ts = kuf_tile(k.ld, k.Mp);
+  const dim3 grid(ceil_div(k.ld, ts), ceil_div(k.Mp, ts));
+  if (kern_kind == DSDGP_KERN_RBF) {
+    if (ts == KT) hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
+    else hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
+  } else {
+    if (ts == KT) hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
+    else hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -716,7 +730,8 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   // workgroup per tile would not fill the chip with 128-wide tiles (partial sums in Pb, added in a fixed order)
   const int tiles128 = ceil_div(Mp, PT) * ceil_div(ld, PT);
   int groups = (512 + tiles128 - 1) / tiles128;           // (128-wide tiles run at 50 TFLOP/s when they fill the chip, 64-wide ones at 31 - 38)
-  if (groups > GL_MAX_GROUPS) groups = GL_MAX_GROUPS;
+  const int gmax = (int)std::min<int64_t>(8, std::max<int64_t>(GL_MAX_GROUPS, ws.pb_doubles / ML));      // (more pieces fit when the launch is small)
+  if (groups > gmax) groups = gmax;
   if (groups < 1) groups = 1;
   PGemm P{};
   if (b.Csave) {      // abar += q_sqrt_d (2 vbar_d c_d): triangular
@@ -741,7 +756,8 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   k.Zs = b.Zs; k.X = b.X; k.hyp = b.hyp; k.Rin = b.Rin; k.ld = ld; k.M = b.M; k.Mp = Mp; k.D_in = Din; k.D_out = Dout;
   k.A = b.Asave; k.Bm = ws.T1; k.VB = b.VB; k.E = b.E; k.GW = b.GW; k.svar = ws.svar;
   DS_TRY(kuf_launch<true>(ctx, kern_kind, k));
-  const int nsv = ceil_div(ld, KT) * ceil_div(Mp, KT);
+  const int kts = kuf_tile(ld, Mp);
+  const int nsv = ceil_div(ld, kts) * ceil_div(Mp, kts);
   // sums over the inducing rows: OUT = ZZ^T GW
   const int nzz = 2 * Din + 1, nzz16 = (int)round_up(nzz, 16);
   hipLaunchKernelGGL(k_gl_zz, dim3(ceil_div((int64_t)nzz16 * Mp, 256)), dim3(256), 0, st, b.Zs, b.M, Mp, Din, nzz16, ws.ZZ);

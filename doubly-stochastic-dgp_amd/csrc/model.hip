@@ -399,10 +399,11 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
       qt = std::max<int64_t>(qt, (int64_t)v.DP16 * v.Mp);
       zz = std::max<int64_t>(zz, nzz16 * v.Mp);
       ot = std::max<int64_t>(ot, nzz16 * ld);
-      sv = std::max<int64_t>(sv, (int64_t)ceil_div(ld, 64) * ceil_div(v.Mp, 64));
+      sv = std::max<int64_t>(sv, (int64_t)ceil_div(ld, 32) * ceil_div(v.Mp, 32));
     }
     if (ML > 0) {
       m->gws.T1 = b.take<double>(ML); m->gws.T2 = b.take<double>(ML); m->gws.Pb = b.take<double>((GL_MAX_GROUPS + 1) * ML);
+      m->gws.pb_doubles = (GL_MAX_GROUPS + 1) * ML;
       m->gws.colsq = b.take<double>(cq); m->gws.MUT = b.take<double>(mut); m->gws.qmuT = b.take<double>(qt);
       m->gws.ZZ = b.take<double>(zz); m->gws.OUTt = b.take<double>(ot); m->gws.svar = b.take<double>(sv + 16);
     }
