@@ -191,7 +191,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     w3.push_back(P);
     {
       LayerState& St = m->L[l];
-      GemmProblem ng[5];
+      GemmProblem ng[4];
       fill_gemm(ng[0], v.ngTI, v.ngTbar, v.ngH, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);        // T^T Tbar
       fill_gemm(ng[1], v.ngTinv, v.ngTinv, v.ngSinv, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);   // S^-1
       ng[0].lower_only = 1; ng[0].tri = 8 | 1;          // upper x lower; k_ng_phi keeps tril(H) only
@@ -203,15 +203,10 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
       fill_gemm(ng[3], v.ngTinv, v.ngY, v.ngX, Mp, Mp, Mp, Mp, Mp, Mp, 1, 0, v.D_out, MM, MM, MM, 0);         // T^-T Phi T^-1
       ng[3].tri = 8 | 1;                                // upper x lower
       St.ng_t3 = plan_lpt(ng + 3, 1);
-      fill_gemm(ng[4], v.ngLAinvT, v.ngLAinv, v.ngSplus, Mp, Mp, Mp, Mp, Mp, Mp, 0, 0, v.D_out, MM, MM, MM, 0);  // S+
-      ng[4].lower_only = 1; ng[4].tri = 8 | 1 | 16;     // upper x lower, symmetric
-      St.ng_t4 = plan_lpt(ng + 4, 1);
       DS_HIP(hipMemcpyAsync(St.ng_gp, ng, sizeof(ng), hipMemcpyHostToDevice, st));
-      std::vector<PotrfItem> it(2 * v.D_out);
-      for (int d = 0; d < v.D_out; ++d) {
+      std::vector<PotrfItem> it(v.D_out);
+      for (int d = 0; d < v.D_out; ++d)
         it[d] = PotrfItem{v.ngA + d * MM, v.ngLAinv + d * MM, v.ngLAinvT + d * MM, v.ngScal + 2 * d, Mp, Mp, v.M, 0, 0, 0};
-        it[v.D_out + d] = PotrfItem{v.ngSplus + d * MM, nullptr, nullptr, v.ngScal + 2 * v.D_out + 2 * d, Mp, Mp, v.M, 0, 0, 0};
-      }
       DS_HIP(hipMemcpyAsync(St.ng_items, it.data(), it.size() * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
       DS_HIP(hipStreamSynchronize(st));
       St.big = Mp >= big_mp(m->uniform_big);
@@ -219,7 +214,6 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
         if (!m->uniform_big) DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
         else if (l == 0) DS_TRY(bigchol_build(ctx, m->big_all, v.Kp, v.Linv, v.LinvT, v.scal, L, MM, 8, Mp, v.M, nullptr, false));
         DS_TRY(bigchol_build(ctx, St.big_ngA, v.ngA, v.ngLAinv, v.ngLAinvT, v.ngScal, v.D_out, MM, 2, Mp, v.M, nullptr, false));
-        DS_TRY(bigchol_build(ctx, St.big_ngS, v.ngSplus, nullptr, nullptr, v.ngScal + 2 * v.D_out, v.D_out, MM, 2, Mp, v.M, nullptr, false));
         DS_TRY(bigchol_build(ctx, St.big_ngT, v.ngTI, v.ngTinv, nullptr, nullptr, v.D_out, MM, 0, Mp, v.M, nullptr, true));
       }
     }
@@ -315,7 +309,7 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
     for (int l = 0; l < m->desc.L; ++l) {
       if (l == 0) bigchol_free(m->big_all);
-      bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngS); bigchol_free(m->L[l].big_ngT);
+      bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngT);
     }
     delete m;
   }

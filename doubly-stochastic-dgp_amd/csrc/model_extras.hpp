@@ -6,6 +6,10 @@
 // (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100).
 // Per output d:  Sbar = sym(T^-T Phi(T^T Tbar) T^-1);  theta1 = S^-1 m - gamma (mbar - 2 Sbar m);
 //                A = S^-1 + 2 gamma Sbar (= -2 theta2);  S+ = A^-1;  m+ = S+ theta1;  T+ = chol(S+).
+// ONE factorisation for the last two lines (round 4; rounds 1-3 factored A, formed S+ = A^-1 with a GEMM and factored S+ again): with
+// J the index reversal, J A J = Lr Lr^T gives A = U U^T with U = J Lr J UPPER-triangular, so S+ = U^-T U^-1 and its lower Cholesky
+// factor IS U^-T = J Lr^-T J (positive diagonal: the factor is unique):  T+[i][j] = Lr^-1[M-1-j][M-1-i],  m+ = T+ (T+^T theta1).
+// The blocked factorisation of a 1024 x 1024 matrix is a ~0.7 ms launch sequence (linalg.hip): config 5 runs three per step instead of four.
 // ------------------------------------------------------------------------------------------------------
 __global__ void k_ng_prep(const LayerDev* __restrict__ layers, int l, const double* __restrict__ grad) {
   const LayerDev v = layers[l];
@@ -28,7 +32,7 @@ __global__ void k_ng_phi(const LayerDev* __restrict__ layers, int l) {
     v.ngH[idx] = (j < i) ? h : (j == i ? 0.5 * h : 0.0);
   }
 }
-// A = S^-1 + 2 gamma Sbar with identity pad ; Sbar stored (symmetrised) into ngY
+// A = S^-1 + 2 gamma Sbar, written INDEX-REVERSED inside its M x M block (J A J), identity pad ; Sbar stored (symmetrised) into ngY
 __global__ void k_ng_assemble(const LayerDev* __restrict__ layers, int l, double gamma) {
   const LayerDev v = layers[l];
   const int Mp = v.Mp, M = v.M;
@@ -42,7 +46,8 @@ __global__ void k_ng_assemble(const LayerDev* __restrict__ layers, int l, double
       a = v.ngSinv[idx] + 2.0 * gamma * sb;
     }
     v.ngY[idx] = sb;
-    v.ngA[idx] = a;
+    if (i < M && j < M) v.ngA[base + (int64_t)(M - 1 - i) * Mp + (M - 1 - j)] = a;
+    else v.ngA[idx] = a;
   }
 }
 // matrix-vector products of the natural-gradient step: ONE WAVE PER ROW (the lanes walk the row: coalesced; a thread per row read
@@ -65,17 +70,27 @@ __global__ __launch_bounds__(256) void k_ng_theta1(const LayerDev* __restrict__ 
   s2 = sum_wave(s2);
   if (lane == 0) v.ngTheta1[d * Mp + i] = s1 - gamma * (grad[v.off_q_mu + (int64_t)i * v.D_out + d] - 2.0 * s2);
 }
-__global__ __launch_bounds__(256) void k_ng_mu(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
+// m+ = T+ (T+^T theta1) with T+[i][j] = Lr^-1[M-1-j][M-1-i]: both products walk ROWS of the inverse factor / its transpose
+//   w[j]  = sum_i T+[i][j] theta1[i] = sum_c Lr^-1[M-1-j][c] theta1[M-1-c]         (second = 0: row M-1-j of ngLAinv)
+//   m+[i] = sum_j T+[i][j] w[j]      = sum_c Lr^-T[M-1-i][c] w[M-1-c]              (second = 1: row M-1-i of ngLAinvT)
+__global__ __launch_bounds__(256) void k_ng_mu(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta, int second) {
   const LayerDev v = layers[l];
   const int Mp = v.Mp, M = v.M;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= v.D_out * M) return;
   const int d = row / M, i = row % M;
-  const double* Sp = v.ngSplus + (int64_t)d * Mp * Mp + (int64_t)i * Mp;
+  const double* R = (second ? v.ngLAinvT : v.ngLAinv) + (int64_t)d * Mp * Mp + (int64_t)(M - 1 - i) * Mp;
+  const double* x = (second ? v.ngV : v.ngTheta1) + d * Mp;
+  // only the triangle that holds the factor is read: columns <= the row of Lr^-1, >= the row of its transpose
+  const int r = M - 1 - i;
+  const int c_lo = second ? r : 0, c_hi = second ? M : r + 1;
   double s = 0.0;
-  for (int j = lane; j < M; j += 64) s = fma(Sp[j], v.ngTheta1[d * Mp + j], s);
+  for (int c = c_lo + lane; c < c_hi; c += 64) s = fma(R[c], x[M - 1 - c], s);
   s = sum_wave(s);
-  if (lane == 0) theta[v.off_q_mu + (int64_t)i * v.D_out + d] = s;
+  if (lane == 0) {
+    if (second) theta[v.off_q_mu + (int64_t)i * v.D_out + d] = s;
+    else v.ngV[d * Mp + i] = s;
+  }
 }
 __global__ void k_ng_write(const LayerDev* __restrict__ layers, int l, double* __restrict__ theta) {
   const LayerDev v = layers[l];
@@ -83,7 +98,7 @@ __global__ void k_ng_write(const LayerDev* __restrict__ layers, int l, double* _
   const int64_t tot = (int64_t)v.D_out * M * M;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * blockDim.x) {
     const int d = (int)(idx / ((int64_t)M * M)), rem = (int)(idx % ((int64_t)M * M)), i = rem / M, j = rem % M;
-    theta[v.off_q_sqrt + idx] = (j <= i) ? v.ngSplus[((int64_t)d * Mp + i) * Mp + j] : 0.0;
+    theta[v.off_q_sqrt + idx] = (j <= i) ? v.ngLAinvT[((int64_t)d * Mp + (M - 1 - i)) * Mp + (M - 1 - j)] : 0.0;
   }
 }
 
@@ -110,21 +125,18 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   DS_HIP(hipGetLastError());
   if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngA));
   else DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
-  DS_TRY(gemm_launch(ctx, St.ng_gp + 4, 1, St.ng_t4));
-  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
-  DS_HIP(hipGetLastError());
-  if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngS));
-  else DS_TRY(potrf_launch(ctx, St.ng_items + v.D_out, v.D_out, v.Mp));
+  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 0);
+  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 1);
   hipLaunchKernelGGL(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
   m->prepared = false;
   m->q_dirty = (m->q_dirty == -1 || m->q_dirty == l) ? l : -2;     // Z and the kernel hyper-parameters are untouched: kuu_valid stays
   if (info) {
-    std::vector<double> sc(4 * v.D_out);
+    std::vector<double> sc(2 * v.D_out);
     DS_HIP(hipMemcpyAsync(sc.data(), v.ngScal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DS_HIP(hipStreamSynchronize(ctx->stream));
     *info = 0;
-    for (int d = 0; d < 2 * v.D_out; ++d)
+    for (int d = 0; d < v.D_out; ++d)
       if (sc[2 * d + 1] != 0.0 && *info == 0) *info = (int)sc[2 * d + 1];
     if (*info) {
       dsdgp_set_error("natural-gradient step left q(u) covariance non-SPD (gamma too large?): pivot %d", *info);

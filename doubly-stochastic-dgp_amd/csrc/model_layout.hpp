@@ -72,7 +72,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.ngTI = b.take<double>(d.D_out * MM); v.ngTinv = b.take<double>(d.D_out * MM); v.ngTbar = b.take<double>(d.D_out * MM);
     v.ngH = b.take<double>(d.D_out * MM); v.ngY = b.take<double>(d.D_out * MM); v.ngX = b.take<double>(d.D_out * MM);
     v.ngSinv = b.take<double>(d.D_out * MM); v.ngA = b.take<double>(d.D_out * MM); v.ngLAinv = b.take<double>(d.D_out * MM);
-    v.ngLAinvT = b.take<double>(d.D_out * MM); v.ngSplus = b.take<double>(d.D_out * MM);
+    v.ngLAinvT = b.take<double>(d.D_out * MM); v.ngV = b.take<double>(d.D_out * Mp);
     v.ngTheta1 = b.take<double>(d.D_out * Mp); v.ngScal = b.take<double>(4 * d.D_out + 8);
     v.wLbar = b.take<double>(MM); v.wH = b.take<double>(MM); v.wY = b.take<double>(MM); v.wX = b.take<double>(MM);
     v.hyp2part = b.take<double>(1024 * (d.D_in + 2));
@@ -121,8 +121,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.bcnt = b.take<int>(512);
     S.lq = b.take<GemmProblem>(12);
     S.wj = b.take<WgradJob>(d.D_out + 4);
-    S.ng_gp = b.take<GemmProblem>(5);
-    S.ng_items = b.take<PotrfItem>(2 * d.D_out);
+    S.ng_gp = b.take<GemmProblem>(4);
+    S.ng_items = b.take<PotrfItem>(d.D_out);
   }
   {   // tile lists of the grouped M x M launches: every problem list is planned at most three times (whole model, per layer, natural
       // gradients), a problem has at most D_out x (Mw / 64)^2 tiles

@@ -26,7 +26,7 @@ struct LayerDev {
   int32_t alg_g, need_tpt;   // need_tpt: some chain kernel reads q_sqrt^T (Mp >= 512 row-oriented loads; the Csave backward chain)
   double *wLbar, *wH, *wY, *wX;  // white=True: Cholesky-adjoint temporaries (Mp x Mp each)
   // natural-gradient temporaries, (D_out x Mp x Mp) each unless noted
-  double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngSplus, *ngTheta1 /* D_out x Mp */, *ngScal /* 4 x D_out */;
+  double *ngTI, *ngTinv, *ngTbar, *ngH, *ngY, *ngX, *ngSinv, *ngA, *ngLAinv, *ngLAinvT, *ngV /* D_out x Mp */, *ngTheta1 /* D_out x Mp */, *ngScal /* 2 x D_out */;
 };
 #define NPART 32
 #define PREP_BLOCKS 64      // minimum; large models take more (dsdgp_model::prep_blocks: ~2048 elements of q_sqrt per thread block pass)
@@ -66,10 +66,10 @@ struct LayerState {
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
   bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
-  BigChol big_k, big_ngA, big_ngS, big_ngT;
-  GemmProblem* ng_gp;  // device: 5 natural-gradient GEMM problems (H, Sinv | Y | X | Splus)
-  PotrfItem* ng_items; // device: 2 * D_out factorisation items (A_d, then Splus_d)
-  int ng_t1, ng_t2, ng_t3, ng_t4;
+  BigChol big_k, big_ngA, big_ngT;
+  GemmProblem* ng_gp;  // device: 4 natural-gradient GEMM problems (H, Sinv | Y | X)
+  PotrfItem* ng_items; // device: D_out factorisation items (the index-reversed A_d)
+  int ng_t1, ng_t2, ng_t3;
   // the products of THIS layer that depend on (q_mu, q_sqrt) only, as launches of their own (prepare after a natural-gradient
   // step on this layer alone: the other layers' S_d / U_d / ... are still those of the previous evaluation)
   GemmProblem* lq = nullptr;
