@@ -415,7 +415,7 @@ def main():
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (2*FETCH + WRITE, the gfx950
     # correction of MI355X_MICROARCH.md) and labelled with its source; null when no current profile is shipped
     traffic, traffic_source = {}, None
-    for cand in ("r03_pmc_traffic.json",):
+    for cand in ("r04_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)
