@@ -304,6 +304,12 @@ static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
   return DSDGP_OK;
 }
 
+// An independent product whose tiles would leave most of the chip idle — the 125-row first layer of a config-5 shard is 16 tiles of up to
+// 64 dependent k-steps: ~105 us per launch whatever its size — is cut along k into G pieces (partial results in `pb`), added in a fixed
+// order by k_gl_sum; the column sums of squares then come from the sum (k_gl_colsq).  Plain launch when the tiles fill a good part of
+// the chip or k is short.
+static int pgemm_split(dsdgp_ctx* ctx, PGemm P, double* pb, int64_t pb_doubles);
+
 // ------------------------------------------------------------------------------------------------------
 // Kuf tile kernel.  64 x 64 outputs per workgroup, thread (ty, tx) owns rows ty + 16 i, columns tx + 16 j; Z / l and x / l of the tile
 // staged through LDS in chunks of KD input dimensions ([dimension][64 + 1], Z reads broadcast over tx, x reads conflict-free);
@@ -414,15 +420,38 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
   }
 }
 
-// out = sum of `n` buffers `stride` doubles apart (fixed order), two doubles per thread
-__global__ void k_gl_sum(const double* __restrict__ part, int n, int64_t stride, int64_t count2, double* __restrict__ out) {
+// out[o] = sum of `n` buffers `stride` doubles apart (fixed order), two doubles per thread; grid.y = outputs (ostride apart in `part`,
+// ostride_out apart in `out`)
+__global__ void k_gl_sum(const double* __restrict__ part, int n, int64_t stride, int64_t count2, double* __restrict__ out, int64_t ostride,
+                         int64_t ostride_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count2) return;
-  d2 s = reinterpret_cast<const d2*>(part)[i];
-  for (int u = 1; u < n; ++u) s += reinterpret_cast<const d2*>(part + (int64_t)u * stride)[i];
-  reinterpret_cast<d2*>(out)[i] = s;
+  const double* p = part + (int64_t)blockIdx.y * ostride;
+  d2 s = reinterpret_cast<const d2*>(p)[i];
+  for (int u = 1; u < n; ++u) s += reinterpret_cast<const d2*>(p + (int64_t)u * stride)[i];
+  reinterpret_cast<d2*>(out + (int64_t)blockIdx.y * ostride_out)[i] = s;
 }
-// q_mu^T, zero padded to (rows16 x Mp); [X^T ; 1] of the layer input for the Z-gradient product
+// column sums of squares of C (m x n) per 128-row tile (what k_pgemm's epilogue leaves when a product is not split): grid (64-column
+// blocks, tiles, outputs), thread = (row group 0..3, column), fixed-order tree over the four row groups
+__global__ __launch_bounds__(256) void k_gl_colsq(const double* __restrict__ C, int64_t sC, int64_t ldc, int m, int n, double* __restrict__ colsq,
+                                                  int64_t ldq) {
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, cc = tid & 63, rr = tid >> 6;
+  const int col = blockIdx.x * 64 + cc, tm = blockIdx.y, o = blockIdx.z;
+  double sq = 0.0;
+  if (col < n) {
+    const double* p = C + (int64_t)o * sC + col;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const int row = tm * PT + rr + 4 * i;
+      const double v = row < m ? p[(int64_t)row * ldc] : 0.0;
+      sq = fma(v, v, sq);
+    }
+  }
+  red[rr][cc] = sq;
+  __syncthreads();
+  if (rr == 0 && col < n) colsq[((int64_t)o * gridDim.y + tm) * ldq + col] = (red[0][cc] + red[1][cc]) + (red[2][cc] + red[3][cc]);
+}
 // (also the transposed, padded map of a Linear mean function: qmu = mean_A (D_in x D_out), Mp = D_in)
 __global__ void k_gl_qmut(const double* __restrict__ qmu, int qld, int Mp, int D_out, int rows16, double* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -492,6 +521,9 @@ __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const
       mus[dd][rr] = mu;
     }
     __syncthreads();
+    // the first layer writes `rep` = S output rows per input row: the samples are cut over gridDim.y workgroups (one workgroup per 64
+    // input rows walking all S — a z load and three stores each — was 50 us of a two-workgroup launch at config 5)
+    const int s_lo = (int)((int64_t)blockIdx.y * a.rep / gridDim.y), s_hi = (int)((int64_t)(blockIdx.y + 1) * a.rep / gridDim.y);
     for (int e = tid; e < dn * GL_EPI_ROWS; e += 256) {
       const int rr = e / dn, dd = e - rr * dn, d = d0 + dd;
       const int64_t r = r0 + rr;
@@ -513,7 +545,7 @@ __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const
         mu += m2 + (a.mean_b ? a.mean_b[d] : 0.0);
       }
       const double sd = sqrt(var + a.jitter);
-      for (int s = 0; s < a.rep; ++s) {
+      for (int s = s_lo; s < s_hi; ++s) {
         const int64_t orow = (int64_t)s * a.Rin + r;
         const int64_t o = orow * Dout + d;
         if (a.mean) a.mean[o] = mu;
@@ -546,6 +578,27 @@ __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const
       a.lik_part[2 * (int64_t)blockIdx.x + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
   }
+}
+static int pgemm_split(dsdgp_ctx* ctx, PGemm P, double* pb, int64_t pb_doubles) {
+  const int tiles_m = ceil_div(P.m, PT);
+  const int Z0 = P.batch;
+  const int64_t tiles = (int64_t)tiles_m * ceil_div(P.n, 64) * Z0;
+  const int ksteps = ceil_div(P.k, PK);
+  const int64_t one = (int64_t)P.m * P.ldc;
+  int G = (int)std::min<int64_t>(8, std::min<int64_t>(ksteps / 8, (256 + tiles - 1) / tiles));
+  if (G > 1 && (int64_t)G * Z0 * one > pb_doubles) G = (int)(pb_doubles / (Z0 * one));
+  if (tiles >= 128 || P.groups > 1 || P.reduce_batch || G < 2 || (one & 1)) return pgemm_launch(ctx, P);
+  PGemm Q = P;
+  Q.C = pb; Q.sC = (int64_t)G * one; Q.sCg = one; Q.groups = G; Q.store = 1; Q.colsq = nullptr;
+  DS_TRY(pgemm_launch(ctx, Q));
+  // the sum goes to the product's own output, or (not stored: only the norms are wanted) over the first piece of each output
+  double* sum = P.store ? P.C : pb;
+  const int64_t sum_stride = P.store ? P.sC : (int64_t)G * one;
+  hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(one / 2, 256), Z0), dim3(256), 0, ctx->stream, pb, G, one, one / 2, sum, (int64_t)G * one, sum_stride);
+  if (P.colsq)
+    hipLaunchKernelGGL(k_gl_colsq, dim3(ceil_div(P.n, 64), tiles_m, Z0), dim3(256), 0, ctx->stream, sum, sum_stride, P.ldc, P.m, P.n, P.colsq, P.ldq);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
 }
 int layer_gemm_lik_blocks(int64_t Rin, int D_out) { return ceil_div(round_up(Rin, 16), GL_EPI_ROWS); }
 
@@ -685,16 +738,16 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   PGemm P{};
   P.W = a.Linv; P.B = ws.T1; P.C = ws.T2; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
   P.tri = 2; P.store = 1; P.alpha = 1.0; P.colsq = ws.colsq; P.ldq = ld;
-  DS_TRY(pgemm_launch(ctx, P));
+  DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
   P = PGemm{};
   P.W = a.LinvT; P.B = ws.T2; P.C = Aout; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
   P.tri = 8; P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_launch(ctx, P));
+  DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
   // c_d = q_sqrt_d^T a for every output in one launch: |c_d|^2 per tile row; c_d itself only when the reverse pass wants it
   P = PGemm{};
   P.W = a.TpT; P.sW = MM; P.B = Aout; P.sB = 0; P.C = a.Csave; P.sC = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
   P.batch = Dout; P.tri = 8; P.store = a.Csave ? 1 : 0; P.alpha = 1.0; P.colsq = ws.colsq + (int64_t)tiles_m * ld; P.ldq = ld;
-  DS_TRY(pgemm_launch(ctx, P));
+  DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
   // q_mu^T a (layers.py:190)
   if (rows16 <= 32) {
     DS_TRY(thin_launch(ctx, ws.qmuT, Mp, Aout, ld, ws.MUT, ld, rows16, (int)ld, Mp));
@@ -712,10 +765,12 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
     DS_TRY(thin_launch(ctx, ws.ZZ, a.D_in, XT, ld, ws.MUT, ld, rows16, (int)ld, a.D_in, 1));
   }
   const int nb = ceil_div(ld, GL_EPI_ROWS);
-  if (a.lik_Y)
+  if (a.lik_Y) {
     hipLaunchKernelGGL(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
-  else
-    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
+  } else {
+    const int ny = std::max(1, std::min(a.rep, 512 / nb));      // sample chunks of a first layer: ~512 workgroups
+    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb, ny), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
+  }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -744,13 +799,13 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   P.W2 = b.qmu4; P.B2 = b.MB; P.k2 = b.DP4; P.ldw2 = b.DP4;
   DS_TRY(pgemm_launch(ctx, P));
   if (groups > 1) {
-    hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2);
+    hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2, (int64_t)0, (int64_t)0);
     DS_HIP(hipGetLastError());
   }
   P = PGemm{};        // b = Ku^-1 abar
   P.W = b.Kinv; P.B = ws.T2; P.C = ws.T1; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
   P.batch = 1; P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_launch(ctx, P));
+  DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
   // e, kbar, GW (+ E) with the kernel recomputed
   KufArgs k{};
   k.Zs = b.Zs; k.X = b.X; k.hyp = b.hyp; k.Rin = b.Rin; k.ld = ld; k.M = b.M; k.Mp = Mp; k.D_in = Din; k.D_out = Dout;
