@@ -1,4 +1,6 @@
 #!/bin/bash
+# round-4 regression check of the large-M path: full-size fixtures, the GEMM-formulated layers forced onto every parity shape
+# (DSDGP_FORCE=gemm_mp=16), config shapes 4 / 5, rocprofv3 kernel stats + per-launch tables of both
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$PWD; mkdir -p gpurun_out; O=$R/gpurun_out/r4e; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
