@@ -96,3 +96,25 @@ def test_gemm_path_natural_gradient_step(monkeypatch):
     NatGradOptimizer(0.1).minimize(model, var_list=[[last.q_mu, last.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
     assert_allclose(last.q_mu.value, mu, rtol=1e-6, atol=1e-8)
     assert_allclose(last.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("mean_linear", [False, True])
+def test_gemm_path_wide_output_layer(monkeypatch, mean_linear):
+    """More than 32 outputs per layer (q_mu^T a and the Linear mean function then take k_pgemm / the per-row form instead of the thin
+    kernel): ELBO and every gradient block of the GEMM-formulated model against the chain model on the same inputs."""
+    rng = np.random.RandomState(13)
+    N, D, M, S, DO = 40, 5, 20, 2, 40
+    X, Y = rng.randn(N, D), rng.randn(N, DO)
+    Z = rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.0, 1.2)] if not mean_linear else [kern_spec("rbf", D, 1.0, 1.2), kern_spec("rbf", 3, 1.0, 1.0)]
+    Yt = Y if not mean_linear else Y[:, :2]
+    zs = [rng.randn(S, N, DO)] if not mean_linear else [rng.randn(S, N, 3), rng.randn(S, N, 2)]
+    out = {}
+    for tag, force in (("chain", "gemm_mp=0"), ("gemm", FORCE)):
+        monkeypatch.setenv("DSDGP_FORCE", force)
+        _, _, model = make_case(X, Yt, Z, specs, S=S, num_data=100)
+        e = model._build_likelihood(X, Yt, zs=zs, with_grad=True)
+        out[tag] = (e, {k: np.asarray(v).copy() for k, v in model.engine().gradient_dict().items()})
+    assert_allclose(out["gemm"][0], out["chain"][0], rtol=1e-10)
+    for k, v in out["chain"][1].items():
+        assert np.max(np.abs(out["gemm"][1][k] - v)) <= 1e-8 * (np.max(np.abs(v)) + 1e-12), k
