@@ -2,19 +2,21 @@
 // formulated as whole-layer MFMA GEMMs (see layer.hpp, "GEMM-formulated layer passes").  gfx950 only.
 //
 // forward (non-white, math of DESIGN.md section 2):
-//   K   = k(Z, X)                       k_kuf<KIND, false>            (Mp x ld, rows >= M and columns >= Rin are zero)
-//   a1  = Lu^-1 K                       k_pgemm, W lower-triangular   + column sums of squares per tile row  -> |a1|^2
+//   K   = k(Z, X)                       k_kuf<KIND, false, TS>        (Mp x ld, rows >= M and columns >= Rin are zero)
+//   a1  = Lu^-1 K                       k_pgemm, W lower-triangular   + column sums of squares per 128-row tile  -> |a1|^2
 //   a   = Lu^-T a1                      k_pgemm, W upper-triangular   -> Asave
 //   c_d = q_sqrt_d^T a   (all d)        k_pgemm, batched, W upper     + column sums of squares -> |c_d|^2 ; stored only for the reverse pass
-//   mu  = q_mu^T a                      k_pgemm on the transposed, padded q_mu
+//   mu  = q_mu^T a (+ mean_A^T X^T)     k_thin on the transposed, padded q_mu (k_pgemm above 32 outputs)
 //   mean / var / F                      k_gl_epilogue  (var = kdiag - |a1|^2 + |c_d|^2, utils.py:41)
+//   (products of a launch too small to fill a good part of the chip are cut along k: pgemm_split, k_gl_sum, k_gl_colsq)
 // backward:
-//   abar = sum_d q_sqrt_d (2 vbar_d c_d) + q_mu mbar     k_pgemm, W lower-triangular, B scaled per column, the outputs split into
-//                                                        groups so that a launch has enough tiles; partial sums in Pb
+//   abar = sum_d q_sqrt_d (2 vbar_d c_d) + q_mu mbar     ONE k_pgemm: W lower-triangular, B scaled per column, batch items summed, the
+//                                                        q_mu mbar term as tail product; the (output, k) steps of a tile in up to 8
+//                                                        pieces when the tiles alone would not fill the chip (partial sums in Pb)
 //          (no c_d kept: abar = sum_d S_d (2 vbar_d a), dense)
-//   b    = Ku^-1 abar                                    k_gl_sum (the partial buffers, fixed order), k_pgemm
-//   e = b - g a, kbar = e - g a, GW = kbar dk/dr2, E      k_kuf<KIND, true> (recomputes r2), sum kbar k per block
-//   ZZ^T GW with ZZ = [Z/l | (Z/l)^2 | 1]                k_pgemm (W = ZZ^T)  -> sums over the inducing rows for dX and the lengthscales
+//   b    = Ku^-1 abar                                    k_gl_sum (the pieces, fixed order), k_pgemm
+//   e = b - g a, kbar = e - g a, GW = kbar dk/dr2, E      k_kuf<KIND, true, TS> (recomputes r2), sum kbar k per block
+//   ZZ^T GW with ZZ = [Z/l | (Z/l)^2 | 1]                k_thin (k_pgemm for wide inputs) -> sums over the inducing rows for dX and the lengthscales
 //   dX / transposed adjoints of the layer below, hyp_part k_gl_bwd_rows
 #include "layer.hpp"
 #include <algorithm>
@@ -41,7 +43,7 @@ struct PGemm {
   const double* W2;
   const double* B2;
   int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg, ldw2;
-  int32_t m, n, k, batch, reduce_batch, groups, tri, store, k2, pad;
+  int32_t m, n, k, batch, reduce_batch, groups, tri, store, k2, pad;      // (pad: alignment)
   int32_t tiles_m, tiles_n;
   double alpha, bs_mul;     // bs_mul multiplies the column scales
 };
@@ -606,8 +608,8 @@ int layer_gemm_lik_blocks(int64_t Rin, int D_out) { return ceil_div(round_up(Rin
 // OUT = ZZ^T GW:  WZ[j][r] = sum_m w z_mj,  Z2[j][r] = sum_m w z_mj^2,  W1[r] = sum_m w  (w = GW[m][r], z = Z / l)
 //   d X partial      sum_m w (x - z)   = x W1 - WZ
 //   lengthscale part sum_m w (x - z)^2 = x^2 W1 - 2 x WZ + Z2          (x = X / l)
-// hyp_part row of block i: [0, sum_r g_r, -2 (1/l_j) sum_r (...)_j]; rows nb .. nb + nsv - 1 carry [svar / s2, 0, ...] of the
-// element-wise kernel's blocks (written by block 0's neighbours below).
+// hyp_part row of row block i: [0, sum_r g_r, -2 (1/l_j) sum_r (...)_j]; rows nb .. nb + nsv - 1 carry [svar / s2, 0, ...] of the
+// element-wise kernel's blocks (written by the workgroups with blockIdx.x >= nb).
 // grid (row blocks + svar blocks, chunks of GL_JC input dimensions): a chunk's workgroup owns columns 2 + j of its row block's hyp_part
 // row for its own j (chunk 0 also columns 0, 1), so that the 784 dimensions of a wide first layer spread over 49 workgroups per row block
 #define GL_BR 256
