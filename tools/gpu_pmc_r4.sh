@@ -15,4 +15,4 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE
 { echo "# round 4 — SQ counters per launch shape, config 5 (tools/ab_kernels.py 5), serial schedule (rocprofv3 --pmc, separate passes; averages per launch)"; echo;
   echo "## pass 1: cycles and waits"; echo; cat $O/sq1.md; echo; echo "## pass 2: instruction mix"; echo; cat $O/sq2.md; } > $O/r04_pmc_sq_cfg5.md
-cat $O/r04_pmc_sq_cfg5.md | cut -c1-220 | grep "pgemm\|kernel\|pass"
+rm -rf $O/sq1 $O/sq2 $O/*.log $O/*.err; cat $O/r04_pmc_sq_cfg5.md | cut -c1-200 | grep "pgemm" | head -4
