@@ -365,6 +365,12 @@ extern "C" int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first) {
   m->grad_first = first;
   return DSDGP_OK;
 }
+extern "C" int dsdgp_model_set_grad_q_only(dsdgp_model* m, int32_t on) {
+  DS_CHECK_ARG(m != nullptr);
+  m->grad_q_only = on != 0;
+  return DSDGP_OK;
+}
+
 extern "C" int dsdgp_model_track_theta(dsdgp_model* m, int enable) {
   DS_CHECK_ARG(m != nullptr);
   m->track_theta = enable != 0;

@@ -225,8 +225,11 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     St.c_used = save_l && St.C && sm_cs_built(v.Mp) &&
                 (v.Mp > 256 || ((Rin + 15) / 16 > m->force.cs_min_blocks && v.D_out >= m->force.cs_min_dout));
     if (St.gemm) St.c_used = save_l && St.C != nullptr;      // the triangular abar product halves the largest GEMM of the reverse pass
+    // (q, q_sqrt)-only gradients: the lowest layer of the reverse pass runs no backward chain (backward_layers), so it keeps neither
+    const bool q_lowest = save_l && m->grad_q_only && !m->desc.white && l == m->grad_first;
+    if (q_lowest) St.c_used = false;
     a.Csave = St.c_used ? St.C : nullptr;
-    a.XT1 = save_l ? St.XT1 : nullptr;
+    a.XT1 = (save_l && !q_lowest) ? St.XT1 : nullptr;
     {
       const int64_t nblk = (Rin + 15) / 16;
       a.d_split = chain_d_split(nblk, v.D_out);
@@ -339,6 +342,8 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       jobs.push_back(J);
     }
     St.njobs = (int)jobs.size();
+    St.njobsA = (int)jobsA.size();
+    St.totA = startA;
     St.tot_big = startA + startB;
     St.tot_thin = 0;
     St.red_off = (int)red.size();
@@ -434,8 +439,13 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     }
     return DSDGP_OK;
   };
+  // (q_mu, q_sqrt)-only gradients (dsdgp_model_set_grad_q_only): the lowest layer of the pass needs d/dq_mu = sum_r a mbar^T and
+  // d/dq_sqrt_d = 2 tril(P_d q_sqrt_d), P_d = sum_r vbar_d a a^T — the forward pass's A and the upstream adjoints, nothing the backward
+  // chain produces (E, GW, dX feed Z, the kernel hyper-parameters and the layers below): no chain, and only the A jobs of its products
+  const bool q_only = m->grad_q_only && !m->desc.white;
   auto launch_wgrad = [&](LayerState& Sx, hipStream_t st) -> int {
     const int64_t ldx = Sx.ld_used;
+    if (q_only && &Sx == &m->L[gfirst]) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st);
     return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st);
   };
   for (int l = L - 1; l >= gfirst; --l) {
@@ -449,7 +459,9 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // row; MultiClass) by k_adj_prep
     const bool fused = (last && m->fused_last) || (!last && l >= 1);
     // ... or, for a first layer below others, by this layer's own backward chain in its prologue (LayerBwdArgs::up_dF)
-    const bool in_chain = !fused && !last && m->force.adj_fuse != 0 && !St.c_used && !St.gemm && sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
+    const bool skip_chain = q_only && l == gfirst;
+    const bool in_chain = !fused && !last && !skip_chain && m->force.adj_fuse != 0 && !St.c_used && !St.gemm &&
+                          sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
     if (!fused && !in_chain)
       hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                          last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
@@ -490,7 +502,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
-    if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->gws));
+    if (skip_chain) { /* nothing downstream of this layer's chain is wanted */ }
+    else if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->gws));
     else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, ctx->stream));
@@ -530,7 +543,10 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + S1.red_off,
                          m->n_red - S1.red_off, S1.red_blk0);
     } else {
-      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks), dim3(256), 0, ctx->stream, m->rjobs, m->n_red, 0);
+      // (the partial sums of the layers below a pruned pass are stale: their jobs — ordered by layer — are left out)
+      const LayerState& Sg = m->L[gfirst];
+      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks - Sg.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + Sg.red_off,
+                         m->n_red - Sg.red_off, Sg.red_blk0);
     }
     DS_HIP(hipGetLastError());
     if (m->desc.white) {
@@ -689,7 +705,7 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
   m->fin.done = false;
   if (with_grad) {
     DS_TRY(backward_layers(m, n, S, kl_weight));
-    m->grad_pruned = !m->desc.white && m->grad_first > 0;
+    m->grad_pruned = !m->desc.white && (m->grad_first > 0 || m->grad_q_only);
   }
   if (!m->fin.done) {
     DS_TRY(join_prep(m));   // KL values
@@ -738,8 +754,9 @@ static int train_step_impl(dsdgp_model* m, const double* X, const double* Y, int
                            const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
                            double beta2, double eps, int64_t t, double* out, const GatherSrc* gs) {
   DS_CHECK_ARG(m && m->grad && m->adam_m && m->adam_v && t >= 1);
-  if (!m->desc.white && m->grad_first > 0) {
-    dsdgp_set_error("dsdgp_model_train_step: the reverse pass is restricted to layers >= %d (dsdgp_model_set_grad_first_layer)", m->grad_first);
+  if (!m->desc.white && (m->grad_first > 0 || m->grad_q_only)) {
+    dsdgp_set_error("dsdgp_model_train_step: the reverse pass is restricted to layers >= %d%s (dsdgp_model_set_grad_first_layer / _q_only)",
+                    m->grad_first, m->grad_q_only ? ", (q_mu, q_sqrt) only" : "");
     return DSDGP_ERR_BAD_ARG;
   }
   if (!m->tail_ok) {

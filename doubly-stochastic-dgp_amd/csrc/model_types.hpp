@@ -57,6 +57,7 @@ struct LayerState {
   double *F, *mean, *var, *zbuf, *dF;
   const double *meanA, *meanb;   // Linear mean function: A (fixed device array or inside theta), bias or NULL
   int njobs;                     // weight-gradient jobs of this layer in the current plan
+  int njobsA = 0, totA = 0;      // ... of which the first njobsA (tasks [0, totA)) read only the forward pass's A and the upstream adjoints
   double* part_mean;             // split-K partials of the mean-function gradient product (only when it is trainable)
   bool mean_grad;
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
@@ -117,6 +118,7 @@ struct dsdgp_model {
   bool kuu_valid = false;      // Lu / Lu^-1 / Ku^-1 belong to the Z and kernel hyper-parameters currently in theta
   int grad_first = 0;          // dsdgp_model_set_grad_first_layer: reverse mode stops below this layer
   bool grad_pruned = false;    // the gradient buffer holds a pruned reverse pass (entries of the lower layers are stale)
+  bool grad_q_only = false;    // dsdgp_model_set_grad_q_only: only the (q_mu, q_sqrt) entries of the layers >= grad_first are wanted
   int q_dirty = -2;            // with kuu_valid: -1 nothing changed, l >= 0 only layer l's (q_mu, q_sqrt) changed, -2 unknown / several
   bool side_pending = false;   // parameter-only work (Ku^-1, S_d, KL, U, UU) still running on the side stream
   int n_fwd, n_bwd1, n_bwd2, t_fwd, t_bwd1, t_bwd2, n_w, t_w1, t_w2, t_w3;

@@ -113,6 +113,7 @@ _PROTOS = {
                                           C.c_int, C.c_void_p, C.c_void_p]),
     "dsdgp_bernoulli_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dsdgp_model_set_grad_first_layer": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dsdgp_model_set_grad_q_only": (C.c_int, [C.c_void_p, C.c_int32]),
     "dsdgp_model_track_theta": (C.c_int, [C.c_void_p, C.c_int]),
     "dsdgp_model_theta_changed": (C.c_int, [C.c_void_p]),
     "dsdgp_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -187,7 +187,7 @@ class DGP_Base(Parameterized):
         return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64))
 
     # dgp.py:92-98
-    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0):
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0, grad_q_only=False):
         eng = self.engine()
         if X is None:
             X, Y = self.next_minibatch()
@@ -202,7 +202,8 @@ class DGP_Base(Parameterized):
             eng._upload_if_needed()            # may re-create the device model (layout / jitter change): before the hook looks at it
             hook(eng)
         out = eng.elbo(X, Y, self.num_samples, zs=zs, seed=self._next_seed() * world + rank, data_scale=scale,
-                       kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer)
+                       kl_weight=klw, with_grad=with_grad, sync=allreduce is None, grad_from_layer=grad_from_layer,
+                       grad_q_only=grad_q_only)
         if allreduce is not None:
             out = allreduce(eng, with_grad)
             if out[3] != 0.0:          # every rank factorises the same Kuu ([UPSTREAM] tf.cholesky raises)
@@ -313,8 +314,9 @@ class DGP_Quad(DGP_Base):
         Fmean, Fvar = self._build_predict(X, full_cov=False, S=self.num_samples, zs=self.gh_x)
         return self.likelihood.variational_expectations_mean(Fmean, Fvar, np.asarray(Y, dtype=np.float64), weights=self.gh_w)
 
-    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0):
-        return DGP_Base._build_likelihood(self, X, Y, zs=self.gh_x, with_grad=with_grad, grad_from_layer=grad_from_layer)
+    def _build_likelihood(self, X=None, Y=None, zs=None, with_grad=False, grad_from_layer=0, grad_q_only=False):
+        return DGP_Base._build_likelihood(self, X, Y, zs=self.gh_x, with_grad=with_grad, grad_from_layer=grad_from_layer,
+                                          grad_q_only=grad_q_only)
 
     def train_step(self, *args, **kwargs):
         kwargs["zs"] = self.gh_x

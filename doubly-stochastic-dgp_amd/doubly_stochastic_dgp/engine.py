@@ -285,6 +285,7 @@ class Engine:
         self.model = h
         self.generation = getattr(self, "generation", 0) + 1     # identifies THIS device model (a freed handle's address can come back)
         self._grad_first = 0
+        self._grad_q_only = False
         # this engine is the only writer of theta besides the library's own optimiser steps and reports its uploads
         # (_upload_if_needed): an evaluation after a natural-gradient step alone keeps the factorisation of Ku
         _lib.check(self.lib.dsdgp_model_track_theta(self.model, 1))
@@ -352,9 +353,12 @@ class Engine:
                                                   arrs["mean"], arrs["var"]))
         return outs["F"], outs["mean"], outs["var"]
 
-    def elbo(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, with_grad=False, sync=True, grad_from_layer=0):
+    def elbo(self, X, Y, S, zs=None, seed=0, data_scale=1.0, kl_weight=1.0, with_grad=False, sync=True, grad_from_layer=0,
+             grad_q_only=False):
         """grad_from_layer = l > 0: the reverse pass stops below layer l, as tf.gradients(loss, var_list) does for a var_list of
-        upper-layer (q_mu, q_sqrt) pairs (NatGradOptimizer); the gradient entries of the lower layers are then NOT updated."""
+        upper-layer (q_mu, q_sqrt) pairs (NatGradOptimizer); the gradient entries of the lower layers are then NOT updated.
+        grad_q_only: var_list holds nothing but (q_mu, q_sqrt) pairs — only those entries of the layers >= l are produced (the other
+        entries of these layers are undefined afterwards; an Adam step is refused until a full gradient has been evaluated)."""
         Xd = X if hasattr(X, "data_ptr") else self.ctx.to_device(X)
         Yd = Y if hasattr(Y, "data_ptr") else self.ctx.to_device(Y)
         n = Xd.shape[0]
@@ -366,6 +370,10 @@ class Engine:
         if gfl != getattr(self, "_grad_first", 0):
             _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, gfl))
             self._grad_first = gfl
+        qo = bool(grad_q_only) and bool(with_grad)
+        if qo != getattr(self, "_grad_q_only", False):
+            _lib.check(self.lib.dsdgp_model_set_grad_q_only(self.model, int(qo)))
+            self._grad_q_only = qo
         _lib.check(self.lib.dsdgp_model_elbo(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed),
                                              float(data_scale), float(kl_weight), int(with_grad), ptr(self.out4)))
         if not sync:
@@ -395,6 +403,9 @@ class Engine:
         if getattr(self, "_grad_first", 0) != 0:
             _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, 0))
             self._grad_first = 0
+        if getattr(self, "_grad_q_only", False):
+            _lib.check(self.lib.dsdgp_model_set_grad_q_only(self.model, 0))
+            self._grad_q_only = False
         _lib.check(self.lib.dsdgp_model_train_step(self.model, ptr(Xd), ptr(Yd), n, S, zp, zst, C.c_uint64(seed), float(data_scale),
                                                    float(kl_weight), lr, beta1, beta2, eps, self.adam_t + 1, ptr(self.out4)))
         self.adam_t += 1
@@ -414,6 +425,9 @@ class Engine:
         if getattr(self, "_grad_first", 0) != 0:
             _lib.check(self.lib.dsdgp_model_set_grad_first_layer(self.model, 0))
             self._grad_first = 0
+        if getattr(self, "_grad_q_only", False):
+            _lib.check(self.lib.dsdgp_model_set_grad_q_only(self.model, 0))
+            self._grad_q_only = False
         _lib.check(self.lib.dsdgp_model_train_step_minibatch(self.model, ptr(Xall), ptr(Yall), ptr(idx), int(idx_offset), int(n), S,
                                                              C.c_uint64(seed), float(data_scale), float(kl_weight), lr, beta1, beta2,
                                                              eps, self.adam_t + 1, ptr(self.out4)))

@@ -35,8 +35,9 @@ class NatGradOptimizer:
         layers = self._layer_indices(model, var_list)
         eng = model.engine()
         for _ in range(int(maxiter)):
-            # tf.gradients w.r.t. var_list only: the reverse pass stops below the lowest layer in it
-            model._build_likelihood(X, Y, zs=zs, with_grad=True, grad_from_layer=min(layers))
+            # tf.gradients w.r.t. var_list only: the reverse pass stops below the lowest layer in it, and — var_list holding nothing
+            # but (q_mu, q_sqrt) pairs — it never visits that layer's Kuf / Kuu adjoints (they feed Z and the kernel hyper-parameters)
+            model._build_likelihood(X, Y, zs=zs, with_grad=True, grad_from_layer=min(layers), grad_q_only=True)
             for l in layers:
                 eng.natgrad_step(l, self.gamma)
         eng.ctx.sync()

@@ -207,6 +207,14 @@ int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma, int* info)
  * first = 0 restores the full gradient.  Ignored (full gradient) for white=True models. */
 int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first);
 
+/* [UPSTREAM] the same tf.gradients(loss, var_list) when var_list holds NOTHING BUT (q_mu, q_sqrt) pairs — what
+ * NatGradOptimizer.minimize always passes (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100): TensorFlow's reverse
+ * pass then never visits Kuf / Kuu of the lowest layer in var_list (their adjoints feed Z, the kernel hyper-parameters and the layers
+ * below only).  on != 0: dsdgp_model_elbo(with_grad=1) leaves complete (q_mu, q_sqrt) entries for the layers >= first
+ * (dsdgp_model_set_grad_first_layer) and UNDEFINED values in their other entries; dsdgp_model_adam_step / _train_step fail with
+ * DSDGP_ERR_BAD_ARG until a full gradient has been evaluated again.  on = 0 restores the full gradient.  Ignored for white=True models. */
+int dsdgp_model_set_grad_q_only(dsdgp_model* m, int32_t on);
+
 /* Optional contract for callers that alternate optimisers (demo_regression_UCI.ipynb:360-366: one Adam step on the hyper-parameters,
  * one natural-gradient step on the last layer).  theta is caller-owned, so every evaluation normally rebuilds Ku, its Cholesky
  * factor and the inverses (layers.py:167-175 build_cholesky_if_needed).  With tracking enabled the caller promises to report its

@@ -55,7 +55,7 @@ def _build(cfg):
 
     def step():
         if ng is not None:
-            model._build_likelihood(with_grad=True, grad_from_layer=len(model.layers) - 1)   # as NatGradOptimizer.minimize does
+            model._build_likelihood(with_grad=True, grad_from_layer=len(model.layers) - 1, grad_q_only=True)   # as NatGradOptimizer.minimize does
             model.engine().natgrad_step(len(model.layers) - 1, ng.gamma, check=False)
         model.train_step(0.01)
 
