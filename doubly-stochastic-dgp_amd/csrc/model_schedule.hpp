@@ -92,11 +92,19 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   const int klb = mp_max >= 512 ? 512 : NPART;    // M = 512 / 1024: V alone is 8..64 MB per layer — 32 workgroups were latency-bound
   // only layer lq's (q_mu, q_sqrt) moved since an evaluation that produced everything this one needs: its products alone
   const int gfirst = (with_grad && !m->desc.white) ? m->grad_first : 0;
-  const int lq = (keep_kuu && m->q_dirty >= 0 && (m->prepared_grad || !with_grad)) ? m->q_dirty : -1;
-  if (lq >= 0) {
-    LayerState& Sq = m->L[lq];
+  // The forward-side products (Ku^-1, Lu^-1 q_sqrt, Lu^-1 q_mu, S_d, the KL sums) and the gradient-side ones (U_d, n, U_d U_d^T) are
+  // decided separately: after a natural-gradient step on layer lf the forward side of every other layer is still that of the previous
+  // evaluation, whatever that evaluation did on the gradient side (a pruned natural-gradient evaluation leaves the lower layers' U_d
+  // undone: the Adam evaluation that follows redoes the gradient side of ALL layers, but the forward side of layer lf only — it used to
+  // redo all 17 Lu^-1 q_sqrt_d of a config-5 model as well)
+  const int lf = (keep_kuu && m->q_dirty >= 0) ? m->q_dirty : -1;
+  const int lq = (lf >= 0 && (m->prepared_grad || !with_grad)) ? lf : -1;
+  if (keep_kuu && m->q_dirty == -1) {
+    // nothing moved since the last evaluation (it lacked the gradient side only): the forward side stands as it is
+  } else if (lf >= 0) {
+    LayerState& Sq = m->L[lf];
     DS_TRY(gemm_launch(ctx, Sq.lq, Sq.lq_nf, Sq.lq_tf, st));
-    hipLaunchKernelGGL(k_kl_part, dim3(klb, 1), dim3(256), 0, st, m->layers_dev + lq);
+    hipLaunchKernelGGL(k_kl_part, dim3(klb, 1), dim3(256), 0, st, m->layers_dev + lf);
   } else {
     DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
     hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
