@@ -27,8 +27,10 @@ static int validate_desc(const dsdgp_model_desc* d) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
     DS_CHECK_ARG(y.kern_kind == DSDGP_KERN_RBF || y.kern_kind == DSDGP_KERN_MATERN52);
-    if (pad_M(y.M) > 1024) {
-      dsdgp_set_error("layer %d: M=%d inducing points exceeds the built chain kernels (<= 1024)", l, y.M);
+    // the chain kernels hold a row block's activations in LDS and are built up to Mp = 1024; the GEMM-formulated passes
+    // (layer_gemm.hip) have no such limit, but carry no white = True variant
+    if (pad_M(y.M) > 1024 && (d->white || pad_M(y.M) > DSDGP_MAX_MP)) {
+      dsdgp_set_error("layer %d: M=%d inducing points: white = True is built up to M = 1024, white = False up to M = %d", l, y.M, DSDGP_MAX_MP);
       return DSDGP_ERR_UNSUPPORTED;
     }
     DS_CHECK_ARG(y.input_prop_dim >= 0 && y.input_prop_dim <= y.D_in);
@@ -79,6 +81,12 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   m->theta = theta; m->grad = grad; m->adam_m = adam_m; m->adam_v = adam_v;
   size_t total = 0;
   layout(m, (char*)workspace, &total);
+  for (int l = 0; l < desc->L; ++l)
+    if (m->L[l].dev.Mp > 1024 && !m->L[l].gemm) {      // (only reachable with the DSDGP_FORCE=gemm_mp=... test hook)
+      dsdgp_set_error("layer %d: M=%d needs the GEMM-formulated passes, which DSDGP_FORCE switched off", l, desc->layers[l].M);
+      delete m;
+      return DSDGP_ERR_UNSUPPORTED;
+    }
   if ((int64_t)total > workspace_bytes) {
     dsdgp_set_error("workspace too small: need %zu bytes, got %lld", total, (long long)workspace_bytes);
     delete m;
