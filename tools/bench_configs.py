@@ -27,11 +27,16 @@ CONFIGS = [
     dict(name="cfg5: 3-layer, M=1024, S=50, mb=1000/8 per GPU, + natgrad(last layer)", n=7372, D=8, widths=[8, 8, 8],
          M=1024, S=50, mb=125, steps=5, natgrad=0.1),
 ]
+# beyond BASELINE.json (ids continue after the configs): inducing counts above the chain kernels' 1024
+EXTRA = [
+    dict(name="x6: 3-layer, M=2048, S=20, mb=250 (GEMM-formulated passes only)", n=7372, D=8, widths=[8, 8, 8], M=2048, S=20, mb=250, steps=5),
+    dict(name="x7: 2-layer, M=1536, S=10, mb=1000", n=7372, D=8, widths=[8, 8], M=1536, S=10, mb=1000, steps=5),
+]
 
 
 def build(cfg_id):
     """(model, step) of config `cfg_id` (1-based) without timing — used by tools/ab_kernels.py."""
-    return _build(CONFIGS[cfg_id - 1])
+    return _build((CONFIGS + EXTRA)[cfg_id - 1])
 
 
 def _build(cfg):
@@ -79,7 +84,7 @@ def run(cfg):
 
 if __name__ == "__main__":
     only = sys.argv[1:] or None
-    for i, cfg in enumerate(CONFIGS):
-        if only and str(i + 1) not in only:
+    for i, cfg in enumerate(CONFIGS + EXTRA):
+        if (only and str(i + 1) not in only) or (not only and i >= len(CONFIGS)):
             continue
         print(json.dumps(run(cfg)), flush=True)
