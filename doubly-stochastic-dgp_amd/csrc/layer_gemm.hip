@@ -340,8 +340,12 @@ struct KufArgs {
 template <int KIND, bool BWD, int TS>
 __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
   constexpr int NI = TS / 16;
-  __shared__ double zt[KD][TS + 1];
-  __shared__ double xt[KD][TS + 1];
+  // dimensions staged per round: a round costs a global round trip whatever its size (one workgroup per CU on the small launches),
+  // so the 32 x 32 form — the 784-pixel layer's — takes 128 at a time (7 rounds instead of 25)
+  constexpr int KDT = TS == 32 ? 4 * KD : KD;
+  constexpr int NV = KDT / 32;
+  __shared__ double zt[KDT][TS + 1];
+  __shared__ double xt[KDT][TS + 1];
   __shared__ double red[4];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * TS;
@@ -353,30 +357,63 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) r2[i][j] = 0.0;
-  for (int d0 = 0; d0 < a.D_in; d0 += KD) {
-    const int dn = min(KD, a.D_in - d0);
-    if (d0 > 0) __syncthreads();
-    for (int idx = tid; idx < TS * dn; idx += 256) {
-      const int rr = idx / dn, d = idx - rr * dn;
-      const int mrow = min(m0 + rr, a.Mp - 1);
-      zt[d][rr] = a.Zs[(int64_t)mrow * a.D_in + d0 + d];
-      const int64_t xr = min<int64_t>(r0 + rr, a.Rin - 1);
-      xt[d][rr] = a.X[xr * a.D_in + d0 + d] * ils[d0 + d];
+  // staging: thread = (dimension tid & 31 of the chunk, rows tid >> 5 + 8 u); the loads of chunk c + 1 are issued before the distance
+  // updates of chunk c (the 784-pixel layer walks 25 chunks: with the load -> LDS -> barrier -> compute rounds one after the other the
+  // 512 x 512 tile took 102 us, most of it exposed load latency)
+  constexpr int NS = TS / 8;
+  static_assert(KD == 32, "staging map");
+  const int sd = tid & 31, sr = tid >> 5;
+  double zr[NV][NS], xr[NV][NS];
+  auto gload = [&](int d0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int dd = d0 + 32 * v + sd;
+      const bool ok = dd < a.D_in;
+      const double il = ok ? ils[dd] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const int rr = sr + 8 * u;
+        const int mrow = min(m0 + rr, a.Mp - 1);
+        const int64_t xrow = min<int64_t>(r0 + rr, a.Rin - 1);
+        zr[v][u] = ok ? a.Zs[(int64_t)mrow * a.D_in + dd] : 0.0;
+        xr[v][u] = ok ? a.X[xrow * a.D_in + dd] * il : 0.0;
+      }
     }
+  };
+  gload(0);
+  for (int d0 = 0; d0 < a.D_in; d0 += KDT) {
+    const int dn = min(KDT, a.D_in - d0);
+    if (d0 > 0) __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        zt[32 * v + sd][sr + 8 * u] = zr[v][u];
+        xt[32 * v + sd][sr + 8 * u] = xr[v][u];
+      }
     __syncthreads();
-    for (int d = 0; d < dn; ++d) {
-      double zv[NI], xv[NI];
+    if (d0 + KDT < a.D_in) gload(d0 + KDT);
+    // UD dimensions per trip, their LDS reads issued together (one workgroup per CU on the small launches: a read -> use round trip
+    // per dimension was the other half of those 102 us); the chunk's tail is zero on both sides
+    constexpr int UD = NI == 2 ? 8 : 1;        // (64 x 64 tiles: 16 accumulators + 4 x 8 operands measured slower than the plain loop)
+    for (int db = 0; db < dn; db += UD) {
+      double zv[UD][NI], xv[UD][NI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) zv[i] = zt[d][ty + 16 * i];
+      for (int u = 0; u < UD; ++u) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) xv[j] = xt[d][tx + 16 * j];
+        for (int i = 0; i < NI; ++i) zv[u][i] = zt[db + u][ty + 16 * i];
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+        for (int j = 0; j < NI; ++j) xv[u][j] = xt[db + u][tx + 16 * j];
+      }
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const double df = zv[i] - xv[j];
-          r2[i][j] = fma(df, df, r2[i][j]);
-        }
+      for (int u = 0; u < UD; ++u)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const double df = zv[u][i] - xv[u][j];
+            r2[i][j] = fma(df, df, r2[i][j]);
+          }
     }
   }
   double sv = 0.0;
@@ -587,9 +624,12 @@ static int pgemm_split(dsdgp_ctx* ctx, PGemm P, double* pb, int64_t pb_doubles) 
   const int64_t tiles = (int64_t)tiles_m * ceil_div(P.n, 64) * Z0;
   const int ksteps = ceil_div(P.k, PK);
   const int64_t one = (int64_t)P.m * P.ldc;
-  int G = (int)std::min<int64_t>(8, std::min<int64_t>(ksteps / 8, (256 + tiles - 1) / tiles));
+  // up to 127 tiles: towards one workgroup per CU; 128 - 255 tiles of a long product (M = 1024: the 8 outputs of config 5's 125-row first
+  // layer, 128 workgroups of 36 - 64 steps, 113 us): towards two per CU
+  const bool mid = tiles >= 128 && tiles < 256 && ksteps >= 64;
+  int G = (int)std::min<int64_t>(8, std::min<int64_t>(ksteps / 8, ((mid ? 512 : 256) + tiles - 1) / tiles));
   if (G > 1 && (int64_t)G * Z0 * one > pb_doubles) G = (int)(pb_doubles / (Z0 * one));
-  if (tiles >= 128 || P.groups > 1 || P.reduce_batch || G < 2 || (one & 1)) return pgemm_launch(ctx, P);
+  if ((tiles >= 128 && !mid) || P.groups > 1 || P.reduce_batch || G < 2 || (one & 1)) return pgemm_launch(ctx, P);
   PGemm Q = P;
   Q.C = pb; Q.sC = (int64_t)G * one; Q.sCg = one; Q.groups = G; Q.store = 1; Q.colsq = nullptr;
   DS_TRY(pgemm_launch(ctx, Q));
@@ -621,13 +661,15 @@ __global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, con
   const int tid = threadIdx.x;
   const double* ils = a.hyp + HYP_ILS;
   const double s2 = a.hyp[HYP_VAR];
-  if ((int)blockIdx.x >= nb) {       // the svar rows
-    if (blockIdx.y != 0) return;
-    const int64_t p = ((int64_t)blockIdx.x - nb) * GL_BR + tid;
-    if (p < nsv) {
-      double* hp = a.hyp_part + (int64_t)(nb + p) * (Din + 2);
-      hp[0] = svar[p] / s2;
-      for (int j = 1; j < Din + 2; ++j) hp[j] = 0.0;
+  if ((int)blockIdx.x >= nb) {       // the svar rows: [svar / s2, 0, ...], stored along the rows (a thread per row walked Din + 2 scattered
+                                     // stores: 100 us of one workgroup on the 784-pixel layer), the chunks of grid.y sharing them
+    const int64_t p0 = ((int64_t)blockIdx.x - nb) * GL_BR;
+    const int wd = Din + 2;
+    const int64_t cnt = (int64_t)min<int64_t>(GL_BR, nsv - p0) * wd;
+    for (int64_t idx = (int64_t)blockIdx.y * GL_BR + tid; idx < cnt; idx += (int64_t)gridDim.y * GL_BR) {
+      const int64_t p = p0 + idx / wd;
+      const int col = (int)(idx % wd);
+      a.hyp_part[(int64_t)nb * wd + p0 * wd + idx] = col == 0 ? svar[p] / s2 : 0.0;
     }
     return;
   }
@@ -654,12 +696,26 @@ __global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, con
     }
   }
   const double w1 = rl ? OUT[(int64_t)(2 * Din) * a.ldA + r] : 0.0;
-  const int j_lo = blockIdx.y * GL_JC, j_hi = min(Din, j_lo + GL_JC);
-  for (int j = j_lo; j < j_hi; ++j) {
+  const int j_lo = blockIdx.y * GL_JC;
+  // every load of the chunk first (the rows of X are Din doubles apart: a load -> sum -> barrier sequence per dimension walked GL_JC
+  // dependent round trips, 102 us on the 784-pixel layer), then the GL_JC block sums
+  double xs[GL_JC], wzs[GL_JC], z2s[GL_JC];
+#pragma unroll
+  for (int t = 0; t < GL_JC; ++t) {
+    const int j = j_lo + t;
+    const bool ok = rl && j < Din;
+    xs[t] = (ok && rv) ? a.X[r * Din + j] : 0.0;
+    wzs[t] = ok ? OUT[(int64_t)j * a.ldA + r] : 0.0;
+    z2s[t] = ok ? OUT[(int64_t)(Din + j) * a.ldA + r] : 0.0;
+  }
+  double sls[GL_JC];
+#pragma unroll
+  for (int t = 0; t < GL_JC; ++t) {
+    const int j = j_lo + t;
     double sl = 0.0;
-    if (rl) {
-      const double xv = rv ? a.X[r * Din + j] * ils[j] : 0.0;
-      const double wz = OUT[(int64_t)j * a.ldA + r], z2 = OUT[(int64_t)(Din + j) * a.ldA + r];
+    if (rl && j < Din) {
+      const double xv = xs[t] * ils[j];
+      const double wz = wzs[t], z2 = z2s[t];
       sl = rv ? fma(xv * xv, w1, fma(-2.0 * xv, wz, z2)) : 0.0;
       if (a.dX || a.MBp) {
         if (rv) {
@@ -686,7 +742,13 @@ __global__ __launch_bounds__(GL_BR) void k_gl_bwd_rows(const LayerBwdArgs a, con
         }
       }
     }
-    const double tot = block_sum(sl);
+    sls[t] = sl;
+  }
+#pragma unroll
+  for (int t = 0; t < GL_JC; ++t) {
+    const int j = j_lo + t;
+    if (j >= Din) break;            // (uniform over the workgroup)
+    const double tot = block_sum(sls[t]);
     if (tid == 0) hp[2 + j] = -2.0 * ils[j] * tot;
   }
 }
@@ -787,7 +849,9 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   // workgroup per tile would not fill the chip with 128-wide tiles (partial sums in Pb, added in a fixed order)
   const int tiles128 = ceil_div(Mp, PT) * ceil_div(ld, PT);
   int groups = (512 + tiles128 - 1) / tiles128;           // (128-wide tiles run at 50 TFLOP/s when they fill the chip, 64-wide ones at 31 - 38)
-  const int gmax = (int)std::min<int64_t>(8, std::max<int64_t>(GL_MAX_GROUPS, ws.pb_doubles / ML));      // (more pieces fit when the launch is small)
+  // (more pieces fit when the launch is small: the 512-row first layer of config 4 — 16 tiles — ran 278 us as 32 x 8 workgroups of
+  // 64-wide tiles, one per CU; as 16 x 32 of 128-wide ones it fills the chip)
+  const int gmax = (int)std::min<int64_t>(32, std::max<int64_t>(GL_MAX_GROUPS, ws.pb_doubles / ML));
   if (groups > gmax) groups = gmax;
   if (groups < 1) groups = 1;
   PGemm P{};
