@@ -235,13 +235,14 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
 // both operands straight from global memory (B: 128-byte runs per 16 lanes; W is small and cache-resident), partial tiles added
 // through LDS in wave order.
 #define THC 32
+template <int NIT>
 __global__ __launch_bounds__(256) void k_thin(const double* __restrict__ W, int64_t ldw, const double* __restrict__ B, int64_t ldb,
                                               double* __restrict__ C, int64_t ldc, int mt, int n, int k, int accumulate) {
   __shared__ double red[4][4][4][64];          // [wave][tile][reg][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int n0 = blockIdx.x * THC;
-  const int nit = mt / 16;                     // 1 or 2 row tiles
+  constexpr int nit = NIT;                     // 1 or 2 row tiles (mt / 16)
   const int kq = (((k + 3) / 4 + 3) / 4) * 4;  // k per wave: a quarter of k rounded up to whole MFMA steps (k < 4: all of it in wave 0)
   const int k_lo = wave * kq, k_hi = min(k, k_lo + kq);
   d4 acc[2][2];
@@ -249,22 +250,37 @@ __global__ __launch_bounds__(256) void k_thin(const double* __restrict__ W, int6
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0, 0, 0, 0};
-  const bool c0 = n0 + c < n, c1 = n0 + 16 + c < n;
-  const int col0 = c0 ? n0 + c : 0, col1 = c1 ? n0 + 16 + c : 0;
-#pragma unroll 4
-  for (int kk = k_lo; kk < k_hi; kk += 4) {
-    const int kr = kk + g;
-    const bool kin = kr < k_hi;
-    const int krc = kin ? kr : k_lo;
-    const double b0v = B[(int64_t)krc * ldb + col0], b1v = B[(int64_t)krc * ldb + col1];
-    const double a0 = W[(int64_t)c * ldw + krc];
-    const double a1 = (nit > 1) ? W[(int64_t)(16 + c) * ldw + krc] : 0.0;
-    const double a0m = kin ? a0 : 0.0, a1m = kin ? a1 : 0.0;
-    acc[0][0] = mfma_f64(a0m, c0 ? b0v : 0.0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0m, c1 ? b1v : 0.0, acc[0][1]);
-    if (nit > 1) {
-      acc[1][0] = mfma_f64(a1m, c0 ? b0v : 0.0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1m, c1 ? b1v : 0.0, acc[1][1]);
+  // lane c holds the ADJACENT columns n0 + 2c, n0 + 2c + 1 (one 16-byte load; column tile j = the columns of parity j): with 8-byte
+  // loads and four steps in flight a CU had 32 KB outstanding, half of what the HBM latency asks for (config 5: 33 us for 51 MB)
+  const int cc = n0 + 2 * c;
+  const bool cin = cc < n;           // (n is even: thin_launch)
+  const int colc = cin ? cc : 0;
+  // TU steps per trip: every load of the trip is issued before its first MFMA (with the row-tile count a run-time value the loop
+  // kept a branch, was not unrolled, and each step waited for its own loads: 30 us for a FOUR-workgroup launch)
+  constexpr int TU = 8;
+  for (int kk = k_lo; kk < k_hi; kk += 4 * TU) {
+    d2 bv[TU];
+    double a0[TU], a1[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int kr = kk + 4 * u + g;
+      const int krc = kr < k_hi ? kr : k_lo;
+      bv[u] = *reinterpret_cast<const d2*>(B + (int64_t)krc * ldb + colc);
+      a0[u] = W[(int64_t)c * ldw + krc];
+      if constexpr (NIT > 1) a1[u] = W[(int64_t)(16 + c) * ldw + krc];
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const bool kin = kk + 4 * u + g < k_hi;
+      const double a0m = kin ? a0[u] : 0.0;
+      const double b0v = cin ? bv[u].x : 0.0, b1v = cin ? bv[u].y : 0.0;
+      acc[0][0] = mfma_f64(a0m, b0v, acc[0][0]);
+      acc[0][1] = mfma_f64(a0m, b1v, acc[0][1]);
+      if constexpr (NIT > 1) {
+        const double a1m = kin ? a1[u] : 0.0;
+        acc[1][0] = mfma_f64(a1m, b0v, acc[1][0]);
+        acc[1][1] = mfma_f64(a1m, b1v, acc[1][1]);
+      }
     }
   }
 #pragma unroll
@@ -280,13 +296,15 @@ __global__ __launch_bounds__(256) void k_thin(const double* __restrict__ W, int6
     const int i = tl >> 1, j = tl & 1;
     if (i >= nit) continue;
     const double v = (red[0][tl][r][l] + red[1][tl][r][l]) + (red[2][tl][r][l] + red[3][tl][r][l]);
-    const int row = 16 * i + (l >> 4) + 4 * r, col = n0 + 16 * j + (l & 15);
+    const int row = 16 * i + (l >> 4) + 4 * r, col = n0 + 2 * (l & 15) + j;
     if (col < n) C[(int64_t)row * ldc + col] = accumulate ? C[(int64_t)row * ldc + col] + v : v;
   }
 }
 static int thin_launch(dsdgp_ctx* ctx, const double* W, int64_t ldw, const double* B, int64_t ldb, double* C, int64_t ldc, int mt, int n, int k,
                        int accumulate = 0) {
-  hipLaunchKernelGGL(k_thin, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
+  DS_CHECK_ARG((n & 1) == 0 && (ldb & 1) == 0 && ((uintptr_t)B & 15) == 0);        // (padded row counts: multiples of 16)
+  if (mt > 16) hipLaunchKernelGGL(k_thin<2>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
+  else hipLaunchKernelGGL(k_thin<1>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -363,20 +381,21 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
   constexpr int NS = TS / 8;
   static_assert(KD == 32, "staging map");
   const int sd = tid & 31, sr = tid >> 5;
-  double zr[NV][NS], xr[NV][NS];
+  double zr[NV][NS], xr[NV][NS], ilr[NV];
+  // (gload only ISSUES loads — clamped addresses, no use of the values: a `* il` or a zero-select next to a load makes the compiler wait
+  // for each pair in turn, sixteen round trips per chunk; scale and padding are applied when the chunk goes to LDS)
   auto gload = [&](int d0) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int dd = d0 + 32 * v + sd;
-      const bool ok = dd < a.D_in;
-      const double il = ok ? ils[dd] : 0.0;
+      const int dd = min(d0 + 32 * v + sd, a.D_in - 1);
+      ilr[v] = ils[dd];
 #pragma unroll
       for (int u = 0; u < NS; ++u) {
         const int rr = sr + 8 * u;
         const int mrow = min(m0 + rr, a.Mp - 1);
         const int64_t xrow = min<int64_t>(r0 + rr, a.Rin - 1);
-        zr[v][u] = ok ? a.Zs[(int64_t)mrow * a.D_in + dd] : 0.0;
-        xr[v][u] = ok ? a.X[xrow * a.D_in + dd] * il : 0.0;
+        zr[v][u] = a.Zs[(int64_t)mrow * a.D_in + dd];
+        xr[v][u] = a.X[xrow * a.D_in + dd];
       }
     }
   };
@@ -385,12 +404,14 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
     const int dn = min(KDT, a.D_in - d0);
     if (d0 > 0) __syncthreads();
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+    for (int v = 0; v < NV; ++v) {
+      const bool ok = d0 + 32 * v + sd < a.D_in;
 #pragma unroll
       for (int u = 0; u < NS; ++u) {
-        zt[32 * v + sd][sr + 8 * u] = zr[v][u];
-        xt[32 * v + sd][sr + 8 * u] = xr[v][u];
+        zt[32 * v + sd][sr + 8 * u] = ok ? zr[v][u] : 0.0;
+        xt[32 * v + sd][sr + 8 * u] = ok ? xr[v][u] * ilr[v] : 0.0;
       }
+    }
     __syncthreads();
     if (d0 + KDT < a.D_in) gload(d0 + KDT);
     // UD dimensions per trip, their LDS reads issued together (one workgroup per CU on the small launches: a read -> use round trip
@@ -418,13 +439,24 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
   }
   double sv = 0.0;
   double gs[NI];
+  double avs[BWD ? NI : 1][BWD ? NI : 1], bvs[BWD ? NI : 1][BWD ? NI : 1];
   if constexpr (BWD) {
+    // every load of the tile first (clamped addresses): the stores below may alias them as far as the compiler knows, so a load next
+    // to its use waited behind the previous element's stores — NI^2 round trips per thread
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int64_t off = (int64_t)min(m0 + ty + 16 * i, a.Mp - 1) * a.ld + min<int64_t>(r0 + tx + 16 * j, a.ld - 1);
+        avs[i][j] = a.A[off];
+        bvs[i][j] = a.Bm[off];
+      }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int64_t r = r0 + tx + 16 * j;
+      const int64_t r = min<int64_t>(r0 + tx + 16 * j, a.ld - 1);
       double s = 0.0;
-      if (r < a.ld)
-        for (int d = 0; d < a.D_out; ++d) s += a.VB[(int64_t)d * a.ld + r];
+#pragma unroll 8
+      for (int d = 0; d < a.D_out; ++d) s += a.VB[(int64_t)d * a.ld + r];
       gs[j] = s;
     }
   }
@@ -440,8 +472,8 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
       if constexpr (!BWD) {
         a.K[(int64_t)m * a.ld + r] = ok ? kern_val<KIND>(r2[i][j], s2) : 0.0;
       } else {
-        const double av = a.A[(int64_t)m * a.ld + r];
-        const double e = a.Bm[(int64_t)m * a.ld + r] - gs[j] * av;
+        const double av = avs[i][j];
+        const double e = bvs[i][j] - gs[j] * av;
         const double kbar = e - gs[j] * av;
         double k, dk;
         kern_val_grad<KIND>(r2[i][j], s2, k, dk);

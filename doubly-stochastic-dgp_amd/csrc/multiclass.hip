@@ -2,7 +2,8 @@
 // Appendix B), reached through BroadcastingLikelihood's flatten/tile (utils.py:76-93):
 //   X_h = mu_y + x_h sqrt(clip(2 v_y, 1e-10));  cdf_kh = (1 + erf((X_h - mu_k)/sqrt(2 clip(v_k,1e-10))))/2 * (1-2e-4) + 1e-4 (k != y)
 //   p = sum_h w_h/sqrt(pi) prod_{k != y} cdf_kh ;  var_exp = p log(1-eps) + (1-p) log(eps/(K-1))
-// One thread per (sample,row); the 20 x K erf evaluations are ALU-bound; per-class gradient accumulators sit in LDS.
+// Four lanes per (sample,row), five quadrature nodes each; the 20 x K erf evaluations are ALU-bound; per-class gradient accumulators
+// sit in LDS.
 #include "common.hpp"
 
 #define MC_H 20
@@ -37,6 +38,12 @@ static int ensure_gh(hipStream_t st) {
 }
 
 // mode 0: out[row] = var_exp ; mode 1: out[row] = log predictive density ; optional adjoints dmean/dvar = w * d(-ve)/d(mu, v)
+// A workgroup (one wave) takes MC_RW rows; lane (row rr, group hg) evaluates MC_H / MC_HG of the row's quadrature nodes, the four
+// partial sums of a row meet in LDS and are added in group order.  (One thread per row walked 20 x (K - 1) erf twice — 80 waves for the
+// 5120 rows of config 4's shard, 153 us; the cdf values of a node are now kept for its gradient pass.)
+#define MC_RW 16
+#define MC_HG 4
+static_assert(MC_RW * MC_HG == MC_T && MC_H % MC_HG == 0, "lane map");
 __global__ __launch_bounds__(MC_T) void k_multiclass(const double* __restrict__ mean, const double* __restrict__ var,
                                                      const double* __restrict__ Y, int64_t n, int64_t R, int K, double eps,
                                                      int mode, double wgt, double* __restrict__ out,
@@ -44,25 +51,30 @@ __global__ __launch_bounds__(MC_T) void k_multiclass(const double* __restrict__ 
                                                      int y_override) {
   __shared__ double gmu[MC_KMAX * MC_T];
   __shared__ double gv[MC_KMAX * MC_T];
-  const int tid = threadIdx.x;
-  const int64_t row = (int64_t)blockIdx.x * MC_T + tid;
-  if (row >= R) return;
-  const int y = y_override >= 0 ? y_override : (int)Y[row % n];
-  const double* mu = mean + row * K;
-  const double* vv = var + row * K;
+  __shared__ double cdfs[MC_KMAX * MC_T];
+  __shared__ double ps[MC_T], gsys[MC_T];
+  const int tid = threadIdx.x, rr = tid & (MC_RW - 1), hg = tid / MC_RW;
+  const int64_t row = (int64_t)blockIdx.x * MC_RW + rr;
+  const bool live = row < R;
+  const int64_t rc = live ? row : R - 1;                      // (every lane reaches the barrier)
+  const int y = y_override >= 0 ? y_override : (int)Y[rc % n];
+  const double* mu = mean + rc * K;
+  const double* vv = var + rc * K;
   const double vy = fmax(vv[y], 0.5e-10);                     // clip(2 v_y, 1e-10)
   const double sy = sqrt(2.0 * vy);
   for (int k = 0; k < K; ++k) gmu[k * MC_T + tid] = gv[k * MC_T + tid] = 0.0;
   double p = 0.0, gsy = 0.0;                                  // gsy: dp / d(sqrt(2 v_y))
   const double isp = 0.56418958354775628695;
-  for (int h = 0; h < MC_H; ++h) {
+  for (int h = hg * (MC_H / MC_HG); h < (hg + 1) * (MC_H / MC_HG); ++h) {
     const double X = mu[y] + c_gh_x[h] * sy;
     double P = 1.0;
     for (int k = 0; k < K; ++k) {
       if (k == y) continue;
       const double vk = fmax(vv[k], 1e-10);
       const double u = (X - mu[k]) * rsqrt(2.0 * vk);
-      P *= 0.5 * (1.0 + erf(u)) * (1.0 - 2e-4) + 1e-4;
+      const double cdf = 0.5 * (1.0 + erf(u)) * (1.0 - 2e-4) + 1e-4;
+      cdfs[k * MC_T + tid] = cdf;
+      P *= cdf;
     }
     p = fma(c_gh_w[h], P, p);
     if (dmean) {
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(MC_T) void k_multiclass(const double* __restrict__ 
         const double vk = fmax(vv[k], 1e-10);
         const double rs = rsqrt(2.0 * vk);
         const double u = (X - mu[k]) * rs;
-        const double cdf = 0.5 * (1.0 + erf(u)) * (1.0 - 2e-4) + 1e-4;
+        const double cdf = cdfs[k * MC_T + tid];
         const double t = c_gh_w[h] * (P / cdf) * (1.0 - 2e-4) * isp * exp(-u * u);   // w_h dP/du_k
         gmu[k * MC_T + tid] -= t * rs;                                                // du/dmu_k = -rs
         if (vv[k] > 1e-10) gv[k * MC_T + tid] -= t * u / (2.0 * vk);                  // du/dv_k = -u / (2 v_k)
@@ -80,17 +92,28 @@ __global__ __launch_bounds__(MC_T) void k_multiclass(const double* __restrict__ 
       }
     }
   }
+  ps[tid] = p;
+  gsys[tid] = gsy;
+  __syncthreads();
+  if (!live) return;
+  auto row_sum = [&](const double* v) { return ((v[rr] + v[rr + MC_RW]) + v[rr + 2 * MC_RW]) + v[rr + 3 * MC_RW]; };
   const double l1 = log(1.0 - eps), l0 = log(eps / (K - 1.0));
-  if (mode == 0)
-    out[row] = p * l1 + (1.0 - p) * l0;
-  else
-    out[row] = log(p * (1.0 - eps) + (1.0 - p) * (eps / (K - 1.0)));
+  if (hg == 0) {
+    const double pt = row_sum(ps);
+    if (mode == 0)
+      out[row] = pt * l1 + (1.0 - pt) * l0;
+    else
+      out[row] = log(pt * (1.0 - eps) + (1.0 - pt) * (eps / (K - 1.0)));
+  }
   if (dmean) {
-    if (vv[y] > 0.5e-10) gv[y * MC_T + tid] += gsy / sy;     // d sy / d v_y = 1 / sy
+    const double gsy_t = row_sum(gsys);
     const double s = -wgt * (l1 - l0);                       // d loss / d p  (loss = -wgt * var_exp)
-    for (int k = 0; k < K; ++k) {
-      dmean[row * K + k] = s * gmu[k * MC_T + tid];
-      dvar[row * K + k] = s * gv[k * MC_T + tid];
+    for (int k = hg; k < K; k += MC_HG) {                    // the row's classes over its four lanes
+      const double gm = row_sum(gmu + k * MC_T);
+      double gw = row_sum(gv + k * MC_T);
+      if (k == y && vv[y] > 0.5e-10) gw += gsy_t / sy;       // d sy / d v_y = 1 / sy
+      dmean[row * K + k] = s * gm;
+      dvar[row * K + k] = s * gw;
     }
   }
 }
@@ -102,7 +125,7 @@ int multiclass_launch(dsdgp_ctx* ctx, const double* mean, const double* var, con
     return DSDGP_ERR_UNSUPPORTED;
   }
   DS_TRY(ensure_gh(ctx->stream));
-  hipLaunchKernelGGL(k_multiclass, dim3(ceil_div(R, MC_T)), dim3(MC_T), 0, ctx->stream, mean, var, Y, n, R, K, 1e-3, mode,
+  hipLaunchKernelGGL(k_multiclass, dim3(ceil_div(R, MC_RW)), dim3(MC_T), 0, ctx->stream, mean, var, Y, n, R, K, 1e-3, mode,
                      wgt, out, dmean, dvar, y_override);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
