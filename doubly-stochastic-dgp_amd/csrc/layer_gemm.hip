@@ -314,7 +314,8 @@ static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
   const int G = P.groups > 1 ? P.groups : 1;
   const int Z = (P.reduce_batch ? 1 : P.batch) * G;
   // 128-wide tiles when they fill the chip (two workgroups per CU), else 64-wide ones
-  const bool narrow = (int64_t)P.tiles_m * ceil_div(P.n, PT) * Z < 512;
+  static const int narrow_below = getenv("DSDGP_PGEMM_NARROW_BELOW") ? atoi(getenv("DSDGP_PGEMM_NARROW_BELOW")) : 512;   // (A/B aid)
+  const bool narrow = (int64_t)P.tiles_m * ceil_div(P.n, PT) * Z < narrow_below;
   P.tiles_n = ceil_div(P.n, narrow ? 64 : PT);
   const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * Z;
   if (blocks <= 0) return DSDGP_OK;
