@@ -500,7 +500,15 @@ __global__ void k_gl_sum(const double* __restrict__ part, int n, int64_t stride,
   if (i >= count2) return;
   const double* p = part + (int64_t)blockIdx.y * ostride;
   d2 s = reinterpret_cast<const d2*>(p)[i];
-  for (int u = 1; u < n; ++u) s += reinterpret_cast<const d2*>(p + (int64_t)u * stride)[i];
+  int u = 1;
+  for (; u + 3 < n; u += 4) {          // four loads in flight, added in index order
+    d2 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = reinterpret_cast<const d2*>(p + (int64_t)(u + t) * stride)[i];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s += v[t];
+  }
+  for (; u < n; ++u) s += reinterpret_cast<const d2*>(p + (int64_t)u * stride)[i];
   reinterpret_cast<d2*>(out + (int64_t)blockIdx.y * ostride_out)[i] = s;
 }
 // column sums of squares of C (m x n) per 128-row tile (what k_pgemm's epilogue leaves when a product is not split): grid (64-column
@@ -558,6 +566,20 @@ __global__ void k_gl_zz(const double* __restrict__ Zs, int M, int Mp, int D_in, 
 #define GL_EPI_ROWS 64
 #define GL_EPI_DC 32
 // lin_done: the Linear mean function's X mean_A is already part of MUT (thin product on [X^T ; 1]); only the bias is added here
+// sum of the per-tile-row partials p[t * ld], t < n, in tile order; four loads in flight
+__device__ __forceinline__ double tile_sum(const double* __restrict__ p, int64_t ld, int n) {
+  double v = 0.0;
+  int t = 0;
+  for (; t + 3 < n; t += 4) {
+    double w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = p[(int64_t)(t + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += w[u];
+  }
+  for (; t < n; ++t) v += p[(int64_t)t * ld];
+  return v;
+}
 template <bool LIK>
 __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const double* __restrict__ colsq, int tiles_m, const double* __restrict__ MUT,
                                                      int lin_done) {
@@ -573,10 +595,7 @@ __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const
   double lik_ve = 0.0, lik_dl = 0.0;
   if (tid < GL_EPI_ROWS) {
     const int64_t r = r0 + tid;
-    double v = 0.0;
-    if (r < a.ldA)
-      for (int t = 0; t < tiles_m; ++t) v += colsq[(int64_t)t * a.ldA + r];
-    s1s[tid] = v;
+    s1s[tid] = r < a.ldA ? tile_sum(colsq + r, a.ldA, tiles_m) : 0.0;
   }
   for (int d0 = 0; d0 < Dout; d0 += GL_EPI_DC) {
     const int dn = min(GL_EPI_DC, Dout - d0);
@@ -586,8 +605,8 @@ __global__ __launch_bounds__(256) void k_gl_epilogue(const LayerFwdArgs a, const
       const int64_t r = r0 + rr;
       double v = 0.0, mu = 0.0;
       if (r < a.ldA) {
-        for (int t = 0; t < tiles_m; ++t) v += colsq[((int64_t)(1 + d0 + dd) * tiles_m + t) * a.ldA + r];
         mu = MUT[(int64_t)(d0 + dd) * a.ldA + r];                           // layers.py:190
+        v = tile_sum(colsq + (int64_t)(1 + d0 + dd) * tiles_m * a.ldA + r, a.ldA, tiles_m);
       }
       s2s[dd][rr] = v;
       mus[dd][rr] = mu;
