@@ -107,7 +107,7 @@ static inline int pad_M(int M) {
   if (M <= 512) return (int)round_up(M, 64);
   return (int)round_up(M, 128);
 }
-// largest padded inducing count: up to 1024 the LDS-resident chains, above it the GEMM-formulated passes only (white = False)
+// largest padded inducing count: up to 1024 the LDS-resident chains, above it the GEMM-formulated passes only
 #define DSDGP_MAX_MP 2048
 // Row count of the M-major per-row intermediates (A, E, GW) and of the weight-gradient results: whole 64 x 64 split-K tiles
 static inline int pad_Mw(int Mp) { return (int)round_up(Mp, 64); }

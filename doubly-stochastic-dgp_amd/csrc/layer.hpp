@@ -154,5 +154,5 @@ struct GemmLayerWs {
 struct GemmLayerExtents { int64_t Mp, ld, D_out, D_in; };
 int layer_gemm_hyp_parts(int64_t ld, int Mp);
 int layer_gemm_lik_blocks(int64_t Rin, int D_out);
-int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, const GemmLayerWs& ws);
-int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, const GemmLayerWs& ws);
+int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white, const GemmLayerWs& ws);
+int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, int white, const GemmLayerWs& ws);

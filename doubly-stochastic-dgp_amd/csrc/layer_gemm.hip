@@ -1,7 +1,7 @@
 // SVGP_Layer.conditional_ND + reparameterize (layers.py:178-219, utils.py:40-41) and their reverse mode for LARGE inducing counts,
 // formulated as whole-layer MFMA GEMMs (see layer.hpp, "GEMM-formulated layer passes").  gfx950 only.
 //
-// forward (non-white, math of DESIGN.md section 2):
+// forward (white = False; math of DESIGN.md section 2):
 //   K   = k(Z, X)                       k_kuf<KIND, false, TS>        (Mp x ld, rows >= M and columns >= Rin are zero)
 //   a1  = Lu^-1 K                       k_pgemm, W lower-triangular   + column sums of squares per 128-row tile  -> |a1|^2
 //   a   = Lu^-T a1                      k_pgemm, W upper-triangular   -> Asave
@@ -18,6 +18,8 @@
 //   e = b - g a, kbar = e - g a, GW = kbar dk/dr2, E      k_kuf<KIND, true, TS> (recomputes r2), sum kbar k per block
 //   ZZ^T GW with ZZ = [Z/l | (Z/l)^2 | 1]                k_thin (k_pgemm for wide inputs) -> sums over the inducing rows for dX and the lengthscales
 //   dX / transposed adjoints of the layer below, hyp_part k_gl_bwd_rows
+// white = True (layers.py:186-188 without the second solve): a1 stands where a does (no Lu^-T product forward); backward
+//   a1bar = abar - 2 (sum_d vbar_d) a1 (k_gl_white_abar), kbar = Lu^-T a1bar (ONE triangular k_pgemm instead of the dense Ku^-1 abar), e = kbar
 #include "layer.hpp"
 #include <algorithm>
 
@@ -353,6 +355,7 @@ struct KufArgs {
   double* E;            // or NULL
   double* GW;
   double* svar;         // [blocks]
+  int32_t white;        // backward: e = kbar = Bm (no -g a terms: they are part of a1bar)
 };
 // TS: tile edge, 64 or 32 (small launches — the 512 x 512 tile of a 784-pixel first layer is 64 tiles of 64 x 64 on 256 CUs, each a
 // chain of 784 staged dimensions — take 32 x 32 tiles: four times the workgroups, a quarter of the chain each)
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(256) void k_kuf(const KufArgs a) {
         a.K[(int64_t)m * a.ld + r] = ok ? kern_val<KIND>(r2[i][j], s2) : 0.0;
       } else {
         const double av = avs[i][j];
-        const double e = bvs[i][j] - gs[j] * av;
-        const double kbar = e - gs[j] * av;
+        const double e = a.white ? bvs[i][j] : bvs[i][j] - gs[j] * av;
+        const double kbar = a.white ? e : e - gs[j] * av;
         double k, dk;
         kern_val_grad<KIND>(r2[i][j], s2, k, dk);
         sv += ok ? kbar * k : 0.0;
@@ -828,7 +831,7 @@ static int kuf_launch(dsdgp_ctx* ctx, int kern_kind, const KufArgs& k) {
   return DSDGP_OK;
 }
 
-int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, const GemmLayerWs& ws) {
+int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white, const GemmLayerWs& ws) {
   ProfScope ps(ctx, "layer_fwd");
   const int64_t ld = a.ldA;
   const int Dout = a.D_out, tiles_m = ceil_div(Mp, PT);
@@ -850,15 +853,18 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
                      ws.qmuT);
   DS_HIP(hipGetLastError());
   // a1 = Lu^-1 K (layers.py:186), |a1|^2 per tile row.  a = Lu^-T a1 (layers.py:188) goes straight to Asave when the pass keeps it.
-  double* Aout = a.Asave ? a.Asave : ws.T1;      // (K is dead once a1 exists)
+  // white = True (layers.py:186-188 without the second solve): a1 takes a's place in everything below
+  double* Aout = a.Asave ? a.Asave : (white ? ws.T2 : ws.T1);      // (K is dead once a1 exists)
   PGemm P{};
-  P.W = a.Linv; P.B = ws.T1; P.C = ws.T2; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
+  P.W = a.Linv; P.B = ws.T1; P.C = white ? Aout : ws.T2; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
   P.tri = 2; P.store = 1; P.alpha = 1.0; P.colsq = ws.colsq; P.ldq = ld;
   DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
-  P = PGemm{};
-  P.W = a.LinvT; P.B = ws.T2; P.C = Aout; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
-  P.tri = 8; P.store = 1; P.alpha = 1.0;
-  DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
+  if (!white) {
+    P = PGemm{};
+    P.W = a.LinvT; P.B = ws.T2; P.C = Aout; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp; P.batch = 1;
+    P.tri = 8; P.store = 1; P.alpha = 1.0;
+    DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
+  }
   // c_d = q_sqrt_d^T a for every output in one launch: |c_d|^2 per tile row; c_d itself only when the reverse pass wants it
   P = PGemm{};
   P.W = a.TpT; P.sW = MM; P.B = Aout; P.sB = 0; P.C = a.Csave; P.sC = ML; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
@@ -891,7 +897,19 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   return DSDGP_OK;
 }
 
-int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, const GemmLayerWs& ws) {
+// white = True: abar (Mp x ld, in place) -= 2 (sum_d vbar_d[r]) a1[m][r]; grid (256-column blocks, row groups)
+__global__ __launch_bounds__(256) void k_gl_white_abar(double* __restrict__ T, const double* __restrict__ A1, const double* __restrict__ VB, int Mp,
+                                                       int64_t ld, int Dout) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= ld) return;
+  double g = 0.0;
+#pragma unroll 4
+  for (int d = 0; d < Dout; ++d) g += VB[(int64_t)d * ld + r];
+  g *= 2.0;
+  for (int m = blockIdx.y; m < Mp; m += gridDim.y) T[(int64_t)m * ld + r] -= g * A1[(int64_t)m * ld + r];
+}
+
+int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int kern_kind, int white, const GemmLayerWs& ws) {
   ProfScope ps(ctx, "layer_bwd");
   const int64_t ld = b.ldA;
   const int Dout = b.D_out, Din = b.D_in;
@@ -920,14 +938,21 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
     hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2, (int64_t)0, (int64_t)0);
     DS_HIP(hipGetLastError());
   }
-  P = PGemm{};        // b = Ku^-1 abar
-  P.W = b.Kinv; P.B = ws.T2; P.C = ws.T1; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
+  P = PGemm{};        // b = Ku^-1 abar   |   white: kbar = Lu^-T a1bar,  a1bar = abar - 2 (sum_d vbar_d) a1 (the -|a1|^2 term of the variance)
+  if (white) {
+    hipLaunchKernelGGL(k_gl_white_abar, dim3(ceil_div(ld, 256), std::min(Mp / 16, 64)), dim3(256), 0, st, ws.T2, b.Asave, b.VB, Mp, ld, Dout);
+    DS_HIP(hipGetLastError());
+    P.W = b.LinvT; P.tri = 8;
+  } else {
+    P.W = b.Kinv;
+  }
+  P.B = ws.T2; P.C = ws.T1; P.ldw = Mp; P.ldb = ld; P.ldc = ld; P.m = Mp; P.n = (int)ld; P.k = Mp;
   P.batch = 1; P.store = 1; P.alpha = 1.0;
   DS_TRY(pgemm_split(ctx, P, ws.Pb, ws.pb_doubles));
   // e, kbar, GW (+ E) with the kernel recomputed
   KufArgs k{};
   k.Zs = b.Zs; k.X = b.X; k.hyp = b.hyp; k.Rin = b.Rin; k.ld = ld; k.M = b.M; k.Mp = Mp; k.D_in = Din; k.D_out = Dout;
-  k.A = b.Asave; k.Bm = ws.T1; k.VB = b.VB; k.E = b.E; k.GW = b.GW; k.svar = ws.svar;
+  k.A = b.Asave; k.Bm = ws.T1; k.VB = b.VB; k.E = b.E; k.GW = b.GW; k.svar = ws.svar; k.white = white;
   DS_TRY(kuf_launch<true>(ctx, kern_kind, k));
   const int kts = kuf_tile(ld, Mp);
   const int nsv = ceil_div(ld, kts) * ceil_div(Mp, kts);

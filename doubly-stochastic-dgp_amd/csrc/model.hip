@@ -27,10 +27,10 @@ static int validate_desc(const dsdgp_model_desc* d) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
     DS_CHECK_ARG(y.kern_kind == DSDGP_KERN_RBF || y.kern_kind == DSDGP_KERN_MATERN52);
-    // the chain kernels hold a row block's activations in LDS and are built up to Mp = 1024; the GEMM-formulated passes
-    // (layer_gemm.hip) have no such limit, but carry no white = True variant
-    if (pad_M(y.M) > 1024 && (d->white || pad_M(y.M) > DSDGP_MAX_MP)) {
-      dsdgp_set_error("layer %d: M=%d inducing points: white = True is built up to M = 1024, white = False up to M = %d", l, y.M, DSDGP_MAX_MP);
+    // the chain kernels hold a row block's activations in LDS and are built up to Mp = 1024; above it the GEMM-formulated passes
+    // (layer_gemm.hip) are the only form
+    if (pad_M(y.M) > DSDGP_MAX_MP) {
+      dsdgp_set_error("layer %d: M=%d inducing points: built up to M = %d", l, y.M, DSDGP_MAX_MP);
       return DSDGP_ERR_UNSUPPORTED;
     }
     DS_CHECK_ARG(y.input_prop_dim >= 0 && y.input_prop_dim <= y.D_in);
@@ -418,7 +418,7 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
-  if (St.gemm && a.ldA <= St.ld_max) return layer_fwd_gemm_launch(m->ctx, a, v.Mp, v.kern_kind, m->gws);
+  if (St.gemm && a.ldA <= St.ld_max) return layer_fwd_gemm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws);
   return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
 }
 

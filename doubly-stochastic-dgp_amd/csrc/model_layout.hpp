@@ -80,7 +80,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
       const int alg_env = m->force.alg_g;   // -1: heuristic, 0: never, 1: always
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
       v.alg_g = (!D.white && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
-      v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp) || (!D.white && m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp)) ? 1 : 0;
+      v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp) || (m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp)) ? 1 : 0;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }
@@ -113,7 +113,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.part_big = b.take<double>((size_t)S.nsplit_big_max * (1 + d.D_out) * Mw * Mw);
     S.part_thin = b.take<double>((size_t)S.nsplit_big_max * Mw * (v.DP16 + v.DinP16));
     S.part_mean = S.mean_grad ? b.take<double>((size_t)S.nsplit_big_max * mrows * v.DP16) : nullptr;
-    S.gemm = !D.white && m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp;
+    S.gemm = m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp;
     S.hyp_part = b.take<double>((size_t)(std::max<int64_t>(std::max<int64_t>(sm_hyp_parts(S.ld_max, v.Mp, d.D_in), layer_gemm_hyp_parts(S.ld_max, v.Mp)),
                                                            8 * 160) + 16) * (d.D_in + 2));
     // d-split of the backward chain on small launches (at most 1024 workgroups): partial abar tiles + arrival counters

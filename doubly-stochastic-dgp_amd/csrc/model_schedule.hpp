@@ -247,7 +247,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
         *lik_nblocks = St.gemm ? layer_gemm_lik_blocks(Rin, v.D_out) : (int)nblk * a.d_split;
       }
     }
-    if (St.gemm) DS_TRY(layer_fwd_gemm_launch(ctx, a, v.Mp, v.kern_kind, m->gws));
+    if (St.gemm) DS_TRY(layer_fwd_gemm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
     else DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white || wf));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
@@ -511,7 +511,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
     if (skip_chain) { /* nothing downstream of this layer's chain is wanted */ }
-    else if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->gws));
+    else if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
     else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, ctx->stream));

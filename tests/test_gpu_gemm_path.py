@@ -1,11 +1,11 @@
 """The GEMM-formulated layer passes (csrc/layer_gemm.hip: the default from Mp = 512) forced onto oracle-checkable shapes.
 
-`DSDGP_FORCE=gemm_mp=16` (read when the device model is created) routes EVERY non-white layer through layer_fwd_gemm_launch /
+`DSDGP_FORCE=gemm_mp=16` (read when the device model is created) routes EVERY layer (white = False and True) through layer_fwd_gemm_launch /
 layer_bwd_gemm_launch: the K(Z, X) tile kernel, the triangular / batched / reduce-mode k_pgemm launches with their column-norm
 epilogues, the thin products, the forward epilogue, the element-wise reverse kernel and the per-row kernel — at the shapes of the
 golden fixtures, where every layer mean / variance / sample, the ELBO and every gradient block have oracle values.  The same path at
 its production sizes is covered by tests/test_gpu_full_size.py (config-4 and config-5 shards) and the large-M tests of
-test_gpu_parity.py / test_gpu_round2.py; white = True models keep the chains (the fallback is part of what is checked here).
+test_gpu_parity.py / test_gpu_round2.py.
 
 Tolerances as in tests/test_golden.py: 1e-9 (1e-7 where the demo's q_sqrt * 1e-5 makes the variance cancellation-dominated), gradients
 1e-7 (1e-5) of the block's largest entry."""

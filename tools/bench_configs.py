@@ -31,6 +31,10 @@ CONFIGS = [
 EXTRA = [
     dict(name="x6: 3-layer, M=2048, S=20, mb=250 (GEMM-formulated passes only)", n=7372, D=8, widths=[8, 8, 8], M=2048, S=20, mb=250, steps=5),
     dict(name="x7: 2-layer, M=1536, S=10, mb=1000", n=7372, D=8, widths=[8, 8], M=1536, S=10, mb=1000, steps=5),
+    dict(name="x8: config-5 shape with white=True (no natural-gradient step)", n=7372, D=8, widths=[8, 8, 8], M=1024, S=50, mb=125, steps=5,
+         white=True),
+    dict(name="x9: config-4 shape with white=True", n=6000, D=784, widths=[784, 30, 30], M=512, S=10, mb=512, steps=10, classes=10, var=2.0,
+         ls=2.0, white=True),
 ]
 
 
@@ -52,7 +56,8 @@ def _build(cfg):
         lik = Gaussian()
     Z = X[rng.permutation(n)[:cfg["M"]]] + 0.01 * rng.standard_normal((cfg["M"], D))
     kernels = [RBF(w, variance=cfg.get("var", 1.0), lengthscales=cfg.get("ls", 1.0)) for w in cfg["widths"]]
-    model = DGP(X, Y, Z, kernels, lik, num_outputs=cfg.get("classes"), num_samples=cfg["S"], minibatch_size=cfg["mb"])
+    model = DGP(X, Y, Z, kernels, lik, num_outputs=cfg.get("classes"), num_samples=cfg["S"], minibatch_size=cfg["mb"],
+                white=cfg.get("white", False))
     for layer in model.layers[:-1]:
         layer.q_sqrt = layer.q_sqrt.value * 1e-5
     last = model.layers[-1]
