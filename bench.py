@@ -200,7 +200,8 @@ def sub_rooflines(ctx):
         tf = fl / (us * 1e-6) / 1e12
         out["trsm"].append(dict(n=M, nrhs=R, us=round(us, 1), algorithmic_gflop=round(fl / 1e9, 3), bound="mfma", achieved=round(tf, 3),
                                 peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                                note="16 x 16 diagonal inverses + 128-row panels (one wave per 16 columns) + MFMA GEMM updates"))
+                                note="16 x 16 diagonal inverses + 128-row panels (one wave per 16 columns) + MFMA GEMM updates"
+                                     + ("; left-looking: one LDS-tiled product over the solved rows per panel" if M >= 256 and R >= 2048 else "")))
     return out
 
 

@@ -45,7 +45,7 @@ struct PGemm {
   const double* W2;
   const double* B2;
   int64_t ldw, ldb, ldc, sW, sB, sC, sS, ldq, sCg, ldw2;
-  int32_t m, n, k, batch, reduce_batch, groups, tri, store, k2, pad;      // (pad: alignment)
+  int32_t m, n, k, batch, reduce_batch, groups, tri, store, k2, accum;      // accum: C += alpha W B (dsdgp_trsm's panel updates)      // (pad: alignment)
   int32_t tiles_m, tiles_n;
   double alpha, bs_mul;     // bs_mul multiplies the column scales
 };
@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wr * 64 + ib * 16 + g + 4 * r;
           const int col = n0 + wc * (TN / 2) + jb * 16 + c;
-          if (row < P.m && col < P.n) C[(int64_t)row * P.ldc + col] = P.alpha * acc[ib][jb][r];
+          if (row < P.m && col < P.n) {
+            const double v = P.alpha * acc[ib][jb][r];
+            C[(int64_t)row * P.ldc + col] = P.accum ? C[(int64_t)row * P.ldc + col] + v : v;
+          }
         }
   }
   if (P.colsq) {
@@ -332,6 +335,14 @@ static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
 // order by k_gl_sum; the column sums of squares then come from the sum (k_gl_colsq).  Plain launch when the tiles fill a good part of
 // the chip or k is short.
 static int pgemm_split(dsdgp_ctx* ctx, PGemm P, double* pb, int64_t pb_doubles);
+// C (m x n) += alpha W (m x k) B (k x n), row-major, through the LDS-tiled kernel (linalg.hpp: the panel updates of dsdgp_trsm).
+// 16-byte staging loads: W, B 16-byte aligned, even leading dimensions, n a multiple of 8.
+int pgemm_accum(dsdgp_ctx* ctx, const double* W, int64_t ldw, const double* B, int64_t ldb, double* C, int64_t ldc, int m, int n, int k, double alpha) {
+  DS_CHECK_ARG(W && B && C && m > 0 && n > 0 && k > 0 && (n & 7) == 0 && (ldw & 1) == 0 && (ldb & 1) == 0 && (((uintptr_t)W | (uintptr_t)B) & 15) == 0);
+  PGemm P{};
+  P.W = W; P.B = B; P.C = C; P.ldw = ldw; P.ldb = ldb; P.ldc = ldc; P.m = m; P.n = n; P.k = k; P.batch = 1; P.store = 1; P.alpha = alpha; P.accum = 1;
+  return pgemm_launch(ctx, P);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Kuf tile kernel.  64 x 64 outputs per workgroup, thread (ty, tx) owns rows ty + 16 i, columns tx + 16 j; Z / l and x / l of the tile

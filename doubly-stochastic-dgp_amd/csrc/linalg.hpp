@@ -46,6 +46,9 @@ int gemm_plan(GemmProblem* host, int nprob, int allow_big = 1);     // 0: 64 x 6
 int gemm_plan_lpt(GemmProblem* host, int nprob, std::vector<int32_t>& order, int allow_big = 1);
 // Launch over problems already resident in device memory (`dev`), described by the planned `host` copy.
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream = nullptr);
+// layer_gemm.hip: C (m x n) += alpha W (m x k) B (k x n), row-major, 128 x 128 (or 128 x 64) LDS-tiled fp64-MFMA tiles over the whole k
+// range (W, B 16-byte aligned, even leading dimensions, n a multiple of 8)
+int pgemm_accum(dsdgp_ctx* ctx, const double* W, int64_t ldw, const double* B, int64_t ldb, double* C, int64_t ldc, int m, int n, int k, double alpha);
 // n_max: largest (padded) matrix order among the items; <= 128 selects the LDS-resident variant
 int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_max);
 // batched inverse of padded lower-triangular matrices (n multiple of 16, identity pad), one workgroup each

@@ -126,10 +126,57 @@ __global__ __launch_bounds__(256) void k_trsm_panel(const TrsmPanel P) {
 }
 
 // batched entry: L matrices strideL apart (0: one L shared by the batch, as the tiled Lu of layers.py:173,239), B matrices strideB apart
+// full transpose (n x n, row-major) through 32 x 32 LDS tiles
+__global__ __launch_bounds__(256) void k_trsm_transpose(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ T) {
+  __shared__ double tl[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) tl[r][tx] = (i0 + r < n && j0 + tx < n) ? L[(int64_t)(i0 + r) * ldl + j0 + tx] : 0.0;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (j0 + r < n && i0 + tx < n) T[(int64_t)(j0 + r) * n + i0 + tx] = tl[tx][r];
+}
+
+// One large system (n >= 256, thousands of right-hand sides): LEFT-looking.  Panel p first takes the contributions of all solved panels
+// as ONE long product through the LDS-tiled 128-row kernel of the layer passes (pgemm_accum: k = the rows solved so far, each
+// right-hand-side row read once per panel), then k_trsm_panel solves its 128 rows.  The right-looking form below updates ALL remaining
+// rows after every panel with a K = 128 product: (n / 128)^2 / 2 read-modify-write passes over 128-row slabs of B (2.9 GB at
+// n = 1024, nrhs = 50 000) on the LDS-free short-K kernel — 23 TFLOP/s there, 26 - 30 here (measured no better: 256-row
+// super-panels, whose products take the kernel's 128-wide tiles but fill the chip 1.5 times).  trans = 1 walks the panels upwards on a transposed copy
+// of L (the tiled kernel reads its left operand along rows).
+static int trsm_left_looking(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, const double* L, int64_t ldl, double* B, int64_t ldb) {
+  const int nb = ceil_div(n, 16), npanel = ceil_div(n, TRSM_PANEL);
+  void* scr;
+  const size_t dbytes = round_up((size_t)nb * 256 * sizeof(double), 256);
+  DS_TRY(ctx_scratch(ctx, dbytes + (trans ? (size_t)n * n * sizeof(double) : 0), &scr));
+  double* Dinv = (double*)scr;
+  double* LT = (double*)((char*)scr + dbytes);
+  hipLaunchKernelGGL(k_trsm_diag, dim3(nb, 1), dim3(64), 0, ctx->stream, L, ldl, (int64_t)0, n, Dinv, (int64_t)nb * 256);
+  if (trans) hipLaunchKernelGGL(k_trsm_transpose, dim3(ceil_div(n, 32), ceil_div(n, 32)), dim3(256), 0, ctx->stream, L, ldl, n, LT);
+  DS_HIP(hipGetLastError());
+  for (int pi = 0; pi < npanel; ++pi) {
+    const int p = trans ? npanel - 1 - pi : pi;
+    const int r0 = p * TRSM_PANEL, pn = std::min(TRSM_PANEL, n - r0);
+    if (!trans && r0 > 0)            // B_p -= L[p rows, : r0] X[: r0]
+      DS_TRY(pgemm_accum(ctx, L + (int64_t)r0 * ldl, ldl, B, ldb, B + (int64_t)r0 * ldb, ldb, pn, (int)nrhs, r0, -1.0));
+    if (trans && r0 + pn < n)        // B_p -= L[r0 + pn :, p columns]^T X[r0 + pn :]
+      DS_TRY(pgemm_accum(ctx, LT + (int64_t)r0 * n + r0 + pn, n, B + (int64_t)(r0 + pn) * ldb, ldb, B + (int64_t)r0 * ldb, ldb, pn, (int)nrhs,
+                         n - (r0 + pn), -1.0));
+    TrsmPanel P{L, ldl, 0, Dinv, 0, B, ldb, 0, n, r0, pn, nrhs, trans ? 1 : 0};
+    ProfScope ps(ctx, "trsm");
+    hipLaunchKernelGGL(k_trsm_panel, dim3(ceil_div(nrhs, 64), 1), dim3(256), 0, ctx->stream, P);
+    DS_HIP(hipGetLastError());
+  }
+  return DSDGP_OK;
+}
+
 extern "C" int dsdgp_trsm_batched(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, int batch, const double* L, int64_t ldl,
                                   int64_t strideL, double* B, int64_t ldb, int64_t strideB) {
   DS_CHECK_ARG(ctx && L && B && n > 0 && nrhs > 0 && batch > 0 && ldl >= n && ldb >= nrhs);
   DS_CHECK_ARG(nrhs <= 0x7fffffff && ldb <= 0x7fffffff && ldl <= 0x7fffffff);      // the update GEMMs carry 32-bit extents
+  if (batch == 1 && n >= 256 && nrhs >= 2048 && (nrhs & 7) == 0 && (ldl & 1) == 0 && (ldb & 1) == 0 && (n & 1) == 0 &&
+      (((uintptr_t)L | (uintptr_t)B) & 15) == 0)
+    return trsm_left_looking(ctx, trans, n, nrhs, L, ldl, B, ldb);
   const int nb = ceil_div(n, 16);
   const int nL = strideL == 0 ? 1 : batch;
   const int npanel = ceil_div(n, TRSM_PANEL);

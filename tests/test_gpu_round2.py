@@ -155,10 +155,12 @@ def test_layer_sample_from_conditional_diag(white):
 
 # ---------------------------------------------------------------- triangular solves at the sizes cfg 4 / 5 use
 @pytest.mark.parametrize("trans", [0, 1])
-@pytest.mark.parametrize("n,nrhs", [(256, 500), (512, 300), (1024, 200)])
+@pytest.mark.parametrize("n,nrhs", [(256, 500), (512, 300), (1024, 200),
+                                    (256, 2048), (600, 2056), (1024, 4096), (1366, 2304)])      # from 2048 columns: the left-looking form
 def test_trsm_large(ctx, trans, n, nrhs):
-    """dsdgp_trsm is an explicit blocked inverse + GEMM; forward error scales with cond(L).  Well-conditioned L: rtol 1e-10;
-    the residual bar |L x - b| <= 1e-13 n |L| |x| is what a backward-stable solve would meet."""
+    """dsdgp_trsm is a blocked substitution (16 x 16 diagonal inverses, 128-row panels, MFMA GEMM updates — right-looking, or
+    left-looking through the LDS-tiled kernel for one large system with thousands of columns); forward error scales with cond(L).
+    Well-conditioned L: rtol 1e-10; the residual bar |L x - b| <= 1e-13 n |L| |x| is what a backward-stable solve would meet."""
     import scipy.linalg as sla
     from doubly_stochastic_dgp import _lib
     rng = np.random.RandomState(n)
