@@ -13,7 +13,7 @@ from doubly_stochastic_dgp.engine import Context  # noqa: E402
 ctx = Context.get()
 rng = np.random.default_rng(1)
 ls = np.ones(1)
-for (M, R, D, zero) in ((128, 20480, 8, 0), (1024, 50176, 8, 0), (1024, 50176, 8, 1), (1024, 50000, 8, 0), (512, 40960, 32, 0)):
+for (M, R, D, zero) in ((128, 20000, 8, 0), (256, 40000, 9, 0), (512, 40960, 30, 0), (1024, 50000, 8, 0), (1024, 50000, 8, 1)):
     Z = ctx.to_device(rng.standard_normal((M, D)) * (0 if zero else 1))
     X = ctx.to_device(rng.standard_normal((R, D)) * (0 if zero else 1))
     o = ctx.empty(M, R)
