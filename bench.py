@@ -57,6 +57,57 @@ def algorithmic_flops(cfg, shapes=None):
                 step=3 * (sum(fwd) + small))
 
 
+def chain_d_split(nblk, D_out):
+    """csrc/model_types.hpp chain_d_split: workgroups per row block of a forward-chain launch with few row blocks"""
+    ds = 1
+    if nblk < 256:
+        ds = min(4, max(1, 512 // nblk))
+    elif nblk < 512:
+        ds = min(1024 // nblk, D_out // 5)
+    return max(1, min(ds, D_out))
+
+
+def executed_flops_chain(M, shapes, white=False):
+    """EXECUTED v_mfma_f64_16x16x4_f64 flops (2048 per instruction) of the fused chains and the split-K weight-gradient launch at
+    padded inducing counts <= 256, counted from the loop structure of csrc/layer_sm_impl.hpp / wgrad.hip: what the pipe
+    actually issues, beside SURVEY 8d's ALGORITHMIC count — the backward d-loop is dense (2 M^2 per row and output where the contract
+    counts M^2), triangular products run at 16-row granularity, a d-split forward launch repeats its prologue per workgroup, the
+    symmetric P_d skip their upper blocks and the alg_g layers have no E A^T product."""
+    Mp = -(-M // 16) * 16 if M <= 128 else -(-M // 32) * 32
+    nb = Mp // 16
+    tri = 4 * nb * (nb + 1) // 2
+    fwd = bwd = wg = 0
+    for R, Din, Dout in shapes:
+        blocks = -(-R // 16)
+        k16 = -(-Din // 16)
+        nw4 = Mp <= 128 and blocks > 160          # the 4-wave forward instance (8 waves: Mp = 256, and launches of <= 160 row blocks)
+        sq = 4 * nb * k16
+        pro = sq + tri + (0 if white else tri) + (4 * nb * -(-Dout // 16) if nw4 else 0)
+        fwd += blocks * (chain_d_split(blocks, Dout) * pro + Dout * tri)
+        dp4 = -(-Dout // 4) * 4
+        bwd += blocks * (Dout * 4 * nb * nb + (dp4 // 4) * nb + (tri if white else 4 * nb * nb) + sq + 8 * nb * k16)
+        Mw = -(-Mp // 64) * 64
+        ti = Mw // 64
+        alg_g = 4 * Dout * Mp <= R
+        dp16, dinp16 = -(-Dout // 16) * 16, -(-Din // 16) * 16
+        per_chunk = Dout * (64 * ti * (ti - 1) // 2 + 40 * ti) + ti * dp16 + ti * dinp16 + (0 if alg_g else 64 * ti * ti)
+        wg += blocks * per_chunk
+    return dict(layer_fwd=2048.0 * fwd, layer_bwd=2048.0 * bwd, wgrad=2048.0 * wg)
+
+
+def executed_profile():
+    """executed MFMA flops per step of every config shape from the committed PMC pass (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 summed over
+    one step's launches, tools/executed_flops.py) — only when the profile was taken from the kernel sources of the loaded library"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_executed_flops.json")) as f:
+            ex = json.load(f)
+        if ex.get("csrc_sha256_16") != csrc_hash():
+            return None, "profiles/r05_executed_flops.json was taken from other kernel sources than this build: not reported"
+        return ex, "profiles/r05_executed_flops.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512, serial schedule, separate run)"
+    except Exception:
+        return None, None
+
+
 def make_synthetic(n, d, seed=0):
     """kin8nm-SHAPED synthetic regression data (SURVEY §8d recipe): X ~ N(0,1), Y = standardise(sin(Xw1) + 0.1 (Xw2)^2
     + 0.1 eps) — mimics demos/datasets.py:74-83 standardisation.  Real UCI data cannot be downloaded (no network)."""
@@ -207,26 +258,57 @@ def sub_rooflines(ctx):
 
 def all_configs():
     """Throughput of the OTHER BASELINE.json configs on this one GPU (configs[0], [2] whole; [3], [4] as the per-GPU shard of their
-    8-GPU minibatch — tools/bench_configs.py): steps/s, ms/step and the fraction of the fp64 MFMA peak by SURVEY 8d's F_step of
-    that shape.  Secondary lines of the N = 1 JSON; the contract's `value` stays configs[1]."""
+    8-GPU minibatch — tools/bench_configs.py): >= 20 steps each, every step bracketed by HIP events on the launch stream (median / p10 /
+    p90) next to the wall-clock rate, kernel launches per step (dsdgp_launch_count), the fraction of the fp64 MFMA peak by SURVEY 8d's
+    F_step of that shape and — from the committed PMC pass — by the flops the MFMA pipe executed.  Secondary lines of the N = 1 JSON;
+    the contract's `value` stays configs[1]."""
     import torch
+    from doubly_stochastic_dgp import _lib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs as BC
+    ex, ex_src = executed_profile()
+    lib = _lib.load()
     out = []
     for i, c in enumerate(BC.CONFIGS):
         if i == 1:
             continue
-        r = BC.run(dict(c, steps=max(3, c["steps"] // (1 if i == 0 else 2))))
+        nsteps = max(20, c["steps"])
+        model, step = BC._build(c)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        l0 = lib.dsdgp_launch_count()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for k in range(nsteps):
+            step()
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        launches = (lib.dsdgp_launch_count() - l0) / nsteps
+        ts = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(nsteps)])
+        elbo = model.train_step(0.01, sync=True)
         widths = c["widths"]
         douts = list(widths[1:]) + [c.get("classes") or 1]
         shapes = [((c["mb"] if l == 0 else c["mb"] * c["S"]), widths[l], douts[l]) for l in range(len(widths))]
         fstep = algorithmic_flops(dict(M=c["M"]), shapes)["step"]
-        tf = fstep * r["steps_per_s"] / 1e12
-        out.append(dict(config=r["config"], steps_per_s=r["steps_per_s"], ms_per_step=r["ms_per_step"],
+        sps = nsteps / dt
+        tf = fstep * sps / 1e12
+        key = f"cfg{i + 1}"
+        exg = ex["configs"][key]["executed_gflop_per_step"] if ex and key in ex.get("configs", {}) else None
+        out.append(dict(config=c["name"], steps=nsteps, steps_per_s=round(sps, 3), ms_per_step=round(1e3 * dt / nsteps, 3),
+                        step_time=dict(median_ms=round(float(np.median(ts)), 4), p10_ms=round(float(np.percentile(ts, 10)), 4),
+                                       p90_ms=round(float(np.percentile(ts, 90)), 4)),
+                        launches_per_step=round(launches, 1),
                         algorithmic_gflop_per_step=round(fstep / 1e9, 1), achieved_tflops=round(tf, 2),
-                        frac_of_fp64_peak=round(tf / FP64_MFMA_PEAK_TFLOPS, 4), elbo_finite=r["elbo_finite"],
+                        frac_of_fp64_peak=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                        executed_gflop_per_step=exg,
+                        frac_executed=None if exg is None else round(exg * 1e9 * sps / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                        executed_source=ex_src, elbo_finite=bool(np.isfinite(elbo)),
                         note=("one optimiser step = natural-gradient evaluation + step on the last layer, then an Adam step: two forward "
                               "passes, F_step counts one" if c.get("natgrad") else None)))
+        del model, step
         torch.cuda.empty_cache()
     return out
 
@@ -375,21 +457,6 @@ def main():
             sub = sub_rooflines(ctx)
             if world == 1:
                 others = all_configs()
-        # steady-state distribution: single steps bracketed by events on the launch stream (ctx stream == torch's current stream)
-        nst = 300
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)]
-        for _ in range(20):
-            model.train_step(0.01)
-        evs[0].record()
-        for i in range(nst):
-            model.train_step(0.01)
-            evs[i + 1].record()
-        torch.cuda.synchronize()
-        ts = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nst)])
-        steady = dict(n=nst, median_ms=round(float(np.median(ts)), 4), p10_ms=round(float(np.percentile(ts, 10)), 4),
-                      p90_ms=round(float(np.percentile(ts, 90)), 4), mean_ms=round(float(ts.mean()), 4),
-                      note="per-step HIP events on the launch stream; the gradient all-reduce (N>1) is inside each step")
-
     # ---- the contract's timed region: W warm-up steps, then EXACTLY K steps
     for _ in range(args.warmup):
         model.train_step(0.01)
@@ -405,6 +472,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo = model.train_step(0.01, sync=True)
+    from doubly_stochastic_dgp import _lib
+    lib = _lib.load()
+    l0 = lib.dsdgp_launch_count()
+    for _ in range(10):
+        model.train_step(0.01)
+    torch.cuda.synchronize()
+    launches_per_step = (lib.dsdgp_launch_count() - l0) / 10.0
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU baseline (~10 s of host work) sits BETWEEN the two halves of the GPU work: the timed region above, the long
+        # steady-state loop below (a monitor sampling the GPU every few seconds sees it busy on either side)
+        cpu_base = cpu_baseline(cfg, X, Y, Z)
+    if not args.no_extras:
+        # steady-state distribution: single steps bracketed by events on the launch stream (ctx stream == torch's current stream),
+        # in batches of 300, for >= 6 s at N = 1 (about 10^4 steps) / one batch otherwise
+        budget_s = 6.0 if (world == 1 and not args.no_cpu_baseline) else 0.0
+        nb_ev = 300
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nb_ev + 1)]
+        for _ in range(20):
+            model.train_step(0.01)
+        all_ts = []
+        t_s0 = time.perf_counter()
+        while True:
+            evs[0].record()
+            for i in range(nb_ev):
+                model.train_step(0.01)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            all_ts.append(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nb_ev)]))
+            if time.perf_counter() - t_s0 >= budget_s or len(all_ts) >= 60:
+                break
+        ts = np.concatenate(all_ts)
+        steady = dict(n=int(ts.size), median_ms=round(float(np.median(ts)), 4), p10_ms=round(float(np.percentile(ts, 10)), 4),
+                      p90_ms=round(float(np.percentile(ts, 90)), 4), mean_ms=round(float(ts.mean()), 4),
+                      wall_s=round(time.perf_counter() - t_s0, 2),
+                      note="per-step HIP events on the launch stream, run after the timed region (and after the CPU baseline at N = 1); "
+                           "the gradient all-reduce (N>1) is inside each step")
     rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
@@ -416,7 +520,7 @@ def main():
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (2*FETCH + WRITE, the gfx950
     # correction of MI355X_MICROARCH.md) and labelled with its source; null when no current profile is shipped
     traffic, traffic_source = {}, None
-    for cand in ("r04_pmc_traffic.json",):
+    for cand in ("r05_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)
@@ -433,25 +537,35 @@ def main():
         except Exception:
             pass
     roof_all = {}
+    fx = executed_flops_chain(cfg["M"], layer_shapes(cfg_local))
     for name in ("layer_fwd", "layer_bwd", "wgrad"):
         if name not in prof:
             continue
         ms = prof[name]["ms_per_step"]
         ach = fl[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        achx = fx[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof_all[name] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                               frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name), traffic_source=traffic_source,
                               ms_per_step=round(ms, 4), launches_per_step=prof[name]["launches_per_step"],
-                              algorithmic_gflop_per_step=round(fl[name] / 1e9, 3))
+                              algorithmic_gflop_per_step=round(fl[name] / 1e9, 3),
+                              executed_gflop_per_step=round(fx[name] / 1e9, 3), frac_executed=round(achx / FP64_MFMA_PEAK_TFLOPS, 4),
+                              executed_note="MFMA instructions the launch issues x 2048 flops, counted from the kernels' loop structure "
+                                            "(bench.executed_flops_chain): dense backward d-loop, 16-row triangular granularity, "
+                                            "symmetric / alg_g savings of the weight-gradient products")
     if predict_fwd is not None:
         # predict_f(S = 100, 1000 test points): forward chains only, layer 0 on 1000 rows, layers 1.. on 100 000
         cfgp = dict(cfg, S=100, mb=1000)
         flp = algorithmic_flops(cfgp)["layer_fwd"]
+        fxp = executed_flops_chain(cfg["M"], layer_shapes(cfgp), white=True)["layer_fwd"]
         ach = flp / (predict_fwd["ms_per_call"] * 1e-3) / 1e12
         roof_all["predict_f_fwd"] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                          frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=None, traffic_source=None,
                                          ms_per_step=round(predict_fwd["ms_per_call"], 4),
                                          launches_per_step=predict_fwd["launches_per_call"],
-                                         algorithmic_gflop_per_step=round(flp / 1e9, 3))
+                                         algorithmic_gflop_per_step=round(flp / 1e9, 3),
+                                         executed_gflop_per_step=round(fxp / 1e9, 3),
+                                         frac_executed=round(fxp / (predict_fwd["ms_per_call"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                                         executed_note="whitened forward-only chains: one triangular product less per row block")
     roofline = None
     if roof_all:
         dominant = max((k for k in roof_all if k != "predict_f_fwd"), key=lambda k: roof_all[k]["ms_per_step"])
@@ -459,6 +573,12 @@ def main():
 
     if rank == 0:
         steps_per_s = args.steps / dt
+        ex, ex_src = executed_profile()
+        step_ex = ex["configs"]["cfg2"]["executed_gflop_per_step"] if (ex and world == 1 and "cfg2" in ex.get("configs", {})) else None
+        if step_ex is None:       # chains + weight-gradient products only (the M x M algebra and the head launch are ~3 % more at this shape)
+            step_ex = round(sum(fx.values()) / 1e9, 3)
+            ex_src = "static count of the chain + weight-gradient launches (bench.executed_flops_chain); M x M algebra and head not included"
+        step_ex_frac = round(step_ex * 1e9 * steps_per_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
         weak = args.scaling == "weak" and world > 1
         value = steps_per_s * (world if weak else 1)
         out = {
@@ -475,9 +595,10 @@ def main():
                        "gradient_exchange": ("none" if world == 1 else
                                              ("one all-reduce per layer (bucketed)" if model._dist_buckets()["on"] else "one flat all-reduce"))},
             "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "all_configs": others, "kernel_ms_per_step": prof,
-            "step_time": steady,
+            "step_time": steady, "launches_per_step": launches_per_step,
             "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world
                                                 / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+            "step_executed_gflop": step_ex, "step_fraction_executed": step_ex_frac, "step_executed_source": ex_src,
             "elbo_evals_per_s": None if evals_per_s is None else round(evals_per_s, 2),
             "elbo_evals_note": "forward-only ELBO at FIXED parameters: the factorisation of Ku and the parameter-side products are "
                                "kept between evaluations (dsdgp_model_track_theta) and the chains run in whitened coordinates; the "
@@ -485,8 +606,8 @@ def main():
             "predict_f_rows_per_s": None if predict_rows_per_s is None else round(predict_rows_per_s, 1),
             "final_elbo": elbo,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, X, Y, Z)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

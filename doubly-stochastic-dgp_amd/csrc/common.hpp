@@ -33,6 +33,16 @@ void dsdgp_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// every kernel launch of the library goes through this: a process-wide count of launches (dsdgp_launch_count: launches per step in
+// bench.py's line; a relaxed atomic add, nothing else)
+#include <atomic>
+extern std::atomic<long long> g_dsdgp_launches;
+#define DS_LAUNCH(...)                                                   \
+  do {                                                                   \
+    g_dsdgp_launches.fetch_add(1, std::memory_order_relaxed);            \
+    hipLaunchKernelGGL(__VA_ARGS__);                                     \
+  } while (0)
+
 #define DS_TRY(call)            \
   do {                          \
     int rc__ = (call);          \

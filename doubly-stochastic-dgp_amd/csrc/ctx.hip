@@ -111,6 +111,9 @@ extern "C" int dsdgp_prof_enable(dsdgp_ctx* ctx, int on) {
   return DSDGP_OK;
 }
 
+std::atomic<long long> g_dsdgp_launches{0};
+extern "C" int64_t dsdgp_launch_count(void) { return (int64_t)g_dsdgp_launches.load(std::memory_order_relaxed); }
+
 extern "C" int dsdgp_prof_read(dsdgp_ctx* ctx, const char* name, double* total_ms, int64_t* launches, int reset) {
   DS_CHECK_ARG(ctx && name);
   DS_HIP(hipStreamSynchronize(ctx->stream));

@@ -14,7 +14,7 @@ extern "C" int dsdgp_gather_rows(dsdgp_ctx* ctx, const double* src, int64_t cols
                                  int64_t idx_offset, double* dst) {
   DS_CHECK_ARG(ctx && src && idx && dst && n > 0 && cols > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(n * cols, 256));
-  hipLaunchKernelGGL(k_gather_rows, dim3(nb), dim3(256), 0, ctx->stream, src, cols, idx + idx_offset, n, dst);
+  DS_LAUNCH(k_gather_rows, dim3(nb), dim3(256), 0, ctx->stream, src, cols, idx + idx_offset, n, dst);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -35,7 +35,7 @@ extern "C" int dsdgp_gather_rows2(dsdgp_ctx* ctx, const double* srcX, int64_t co
                                   int64_t colsY, double* dstY, const int64_t* idx, int64_t n, int64_t idx_offset) {
   DS_CHECK_ARG(ctx && srcX && srcY && dstX && dstY && idx && n > 0 && colsX > 0 && colsY > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(n * (colsX + colsY), 256));
-  hipLaunchKernelGGL(k_gather_rows2, dim3(nb), dim3(256), 0, ctx->stream, srcX, colsX, dstX, srcY, colsY, dstY, idx + idx_offset, n);
+  DS_LAUNCH(k_gather_rows2, dim3(nb), dim3(256), 0, ctx->stream, srcX, colsX, dstX, srcY, colsY, dstY, idx + idx_offset, n);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -77,7 +77,7 @@ static int gauss_over_samples(dsdgp_ctx* ctx, const double* mean, const double* 
                               int DY, double s2, int mode, const double* sw, double* out) {
   DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && s2 > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
-  hipLaunchKernelGGL(k_gauss_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, s2, mode, sw, out);
+  DS_LAUNCH(k_gauss_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, s2, mode, sw, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -125,7 +125,7 @@ extern "C" int dsdgp_bernoulli_var_exp(dsdgp_ctx* ctx, const double* mean, const
   DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && (mode == 0 || mode == 1));
   DS_CHECK_ARG(mode == 0 || !sample_w);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
-  hipLaunchKernelGGL(k_bern_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, mode, sample_w, out);
+  DS_LAUNCH(k_bern_over_samples, dim3(nb), dim3(256), 0, ctx->stream, mean, var, Y, n, S, DY, mode, sample_w, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -141,7 +141,7 @@ extern "C" int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const
                                        double* out_var) {
   DS_CHECK_ARG(ctx && mean && var && out_mean && out_var && count > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
-  hipLaunchKernelGGL(k_bern_predict, dim3(nb), dim3(256), 0, ctx->stream, mean, var, count, out_mean, out_var);
+  DS_LAUNCH(k_bern_predict, dim3(nb), dim3(256), 0, ctx->stream, mean, var, count, out_mean, out_var);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -153,7 +153,7 @@ __global__ void k_add_scalar(const double* __restrict__ in, double v, int64_t co
 extern "C" int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out) {
   DS_CHECK_ARG(ctx && in && out && count > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
-  hipLaunchKernelGGL(k_add_scalar, dim3(nb), dim3(256), 0, ctx->stream, in, value, count, out);
+  DS_LAUNCH(k_add_scalar, dim3(nb), dim3(256), 0, ctx->stream, in, value, count, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256) void k_thin(const double* __restrict__ W, int6
 static int thin_launch(dsdgp_ctx* ctx, const double* W, int64_t ldw, const double* B, int64_t ldb, double* C, int64_t ldc, int mt, int n, int k,
                        int accumulate = 0) {
   DS_CHECK_ARG((n & 1) == 0 && (ldb & 1) == 0 && ((uintptr_t)B & 15) == 0);        // (padded row counts: multiples of 16)
-  if (mt > 16) hipLaunchKernelGGL(k_thin<2>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
-  else hipLaunchKernelGGL(k_thin<1>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
+  if (mt > 16) DS_LAUNCH(k_thin<2>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
+  else DS_LAUNCH(k_thin<1>, dim3(ceil_div(n, THC)), dim3(256), 0, ctx->stream, W, ldw, B, ldb, C, ldc, mt, n, k, accumulate);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -324,8 +324,8 @@ static int pgemm_launch(dsdgp_ctx* ctx, PGemm P) {
   P.tiles_n = ceil_div(P.n, narrow ? 64 : PT);
   const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * Z;
   if (blocks <= 0) return DSDGP_OK;
-  if (narrow) hipLaunchKernelGGL(k_pgemm<64>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
-  else hipLaunchKernelGGL(k_pgemm<128>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  if (narrow) DS_LAUNCH(k_pgemm<64>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  else DS_LAUNCH(k_pgemm<128>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -702,9 +702,9 @@ static int pgemm_split(dsdgp_ctx* ctx, PGemm P, double* pb, int64_t pb_doubles) 
   // the sum goes to the product's own output, or (not stored: only the norms are wanted) over the first piece of each output
   double* sum = P.store ? P.C : pb;
   const int64_t sum_stride = P.store ? P.sC : (int64_t)G * one;
-  hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(one / 2, 256), Z0), dim3(256), 0, ctx->stream, pb, G, one, one / 2, sum, (int64_t)G * one, sum_stride);
+  DS_LAUNCH(k_gl_sum, dim3(ceil_div(one / 2, 256), Z0), dim3(256), 0, ctx->stream, pb, G, one, one / 2, sum, (int64_t)G * one, sum_stride);
   if (P.colsq)
-    hipLaunchKernelGGL(k_gl_colsq, dim3(ceil_div(P.n, 64), tiles_m, Z0), dim3(256), 0, ctx->stream, sum, sum_stride, P.ldc, P.m, P.n, P.colsq, P.ldq);
+    DS_LAUNCH(k_gl_colsq, dim3(ceil_div(P.n, 64), tiles_m, Z0), dim3(256), 0, ctx->stream, sum, sum_stride, P.ldc, P.m, P.n, P.colsq, P.ldq);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -832,11 +832,11 @@ static int kuf_launch(dsdgp_ctx* ctx, int kern_kind, const KufArgs& k) {
   const int ts = kuf_tile(k.ld, k.Mp);
   const dim3 grid(ceil_div(k.ld, ts), ceil_div(k.Mp, ts));
   if (kern_kind == DSDGP_KERN_RBF) {
-    if (ts == KT) hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
-    else hipLaunchKernelGGL((k_kuf<DSDGP_KERN_RBF, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
+    if (ts == KT) DS_LAUNCH((k_kuf<DSDGP_KERN_RBF, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
+    else DS_LAUNCH((k_kuf<DSDGP_KERN_RBF, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
   } else {
-    if (ts == KT) hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
-    else hipLaunchKernelGGL((k_kuf<DSDGP_KERN_MATERN52, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
+    if (ts == KT) DS_LAUNCH((k_kuf<DSDGP_KERN_MATERN52, BWD, KT>), grid, dim3(256), 0, ctx->stream, k);
+    else DS_LAUNCH((k_kuf<DSDGP_KERN_MATERN52, BWD, 32>), grid, dim3(256), 0, ctx->stream, k);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -858,9 +858,9 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   double* XT = a.XT1 ? a.XT1 : (lin_thin ? ws.OUTt : nullptr);
   if (XT) {
     const int64_t cnt = (int64_t)(a.D_in + 1) * ld;
-    hipLaunchKernelGGL(k_gl_xt1, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, a.X, a.Rin, a.D_in, ld, XT);
+    DS_LAUNCH(k_gl_xt1, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, a.X, a.Rin, a.D_in, ld, XT);
   }
-  hipLaunchKernelGGL(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * Mp, 256)), dim3(256), 0, st, a.qmu, a.qmu_ld ? a.qmu_ld : Dout, Mp, Dout, rows16,
+  DS_LAUNCH(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * Mp, 256)), dim3(256), 0, st, a.qmu, a.qmu_ld ? a.qmu_ld : Dout, Mp, Dout, rows16,
                      ws.qmuT);
   DS_HIP(hipGetLastError());
   // a1 = Lu^-1 K (layers.py:186), |a1|^2 per tile row.  a = Lu^-T a1 (layers.py:188) goes straight to Asave when the pass keeps it.
@@ -893,16 +893,16 @@ int layer_fwd_gemm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int ker
   if (lin_thin) {
     // Linear mean function (layers.py:219; the PCA step-down of a 784-pixel first layer): MUT += mean_A^T X^T as a thin product — the
     // per-(row, output) dot product over D_in strided reads was 0.97 ms per step at config 4
-    hipLaunchKernelGGL(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * a.D_in, 256)), dim3(256), 0, st, a.mean_A, Dout, a.D_in, Dout, rows16, ws.ZZ);
+    DS_LAUNCH(k_gl_qmut, dim3(ceil_div((int64_t)rows16 * a.D_in, 256)), dim3(256), 0, st, a.mean_A, Dout, a.D_in, Dout, rows16, ws.ZZ);
     DS_HIP(hipGetLastError());
     DS_TRY(thin_launch(ctx, ws.ZZ, a.D_in, XT, ld, ws.MUT, ld, rows16, (int)ld, a.D_in, 1));
   }
   const int nb = ceil_div(ld, GL_EPI_ROWS);
   if (a.lik_Y) {
-    hipLaunchKernelGGL(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
+    DS_LAUNCH(k_gl_epilogue<true>, dim3(nb), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
   } else {
     const int ny = std::max(1, std::min(a.rep, 512 / nb));      // sample chunks of a first layer: ~512 workgroups
-    hipLaunchKernelGGL(k_gl_epilogue<false>, dim3(nb, ny), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
+    DS_LAUNCH(k_gl_epilogue<false>, dim3(nb, ny), dim3(256), 0, st, a, ws.colsq, tiles_m, ws.MUT, lin_thin ? 1 : 0);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -946,12 +946,12 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   P.W2 = b.qmu4; P.B2 = b.MB; P.k2 = b.DP4; P.ldw2 = b.DP4;
   DS_TRY(pgemm_launch(ctx, P));
   if (groups > 1) {
-    hipLaunchKernelGGL(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2, (int64_t)0, (int64_t)0);
+    DS_LAUNCH(k_gl_sum, dim3(ceil_div(ML / 2, 256)), dim3(256), 0, st, ws.Pb, groups, ML, ML / 2, ws.T2, (int64_t)0, (int64_t)0);
     DS_HIP(hipGetLastError());
   }
   P = PGemm{};        // b = Ku^-1 abar   |   white: kbar = Lu^-T a1bar,  a1bar = abar - 2 (sum_d vbar_d) a1 (the -|a1|^2 term of the variance)
   if (white) {
-    hipLaunchKernelGGL(k_gl_white_abar, dim3(ceil_div(ld, 256), std::min(Mp / 16, 64)), dim3(256), 0, st, ws.T2, b.Asave, b.VB, Mp, ld, Dout);
+    DS_LAUNCH(k_gl_white_abar, dim3(ceil_div(ld, 256), std::min(Mp / 16, 64)), dim3(256), 0, st, ws.T2, b.Asave, b.VB, Mp, ld, Dout);
     DS_HIP(hipGetLastError());
     P.W = b.LinvT; P.tri = 8;
   } else {
@@ -969,7 +969,7 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
   const int nsv = ceil_div(ld, kts) * ceil_div(Mp, kts);
   // sums over the inducing rows: OUT = ZZ^T GW
   const int nzz = 2 * Din + 1, nzz16 = (int)round_up(nzz, 16);
-  hipLaunchKernelGGL(k_gl_zz, dim3(ceil_div((int64_t)nzz16 * Mp, 256)), dim3(256), 0, st, b.Zs, b.M, Mp, Din, nzz16, ws.ZZ);
+  DS_LAUNCH(k_gl_zz, dim3(ceil_div((int64_t)nzz16 * Mp, 256)), dim3(256), 0, st, b.Zs, b.M, Mp, Din, nzz16, ws.ZZ);
   DS_HIP(hipGetLastError());
   if (nzz16 <= 32) {
     DS_TRY(thin_launch(ctx, ws.ZZ, Mp, b.GW, ld, ws.OUTt, ld, nzz16, (int)ld, Mp));
@@ -979,7 +979,7 @@ int layer_bwd_gemm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& b, int Mp, int ker
     DS_TRY(pgemm_launch(ctx, P));
   }
   const int nb = ceil_div(ld, GL_BR);
-  hipLaunchKernelGGL(k_gl_bwd_rows, dim3(nb + ceil_div(nsv, GL_BR), ceil_div(Din, GL_JC)), dim3(GL_BR), 0, st, b, ws.OUTt, ws.svar, nsv, nb);
+  DS_LAUNCH(k_gl_bwd_rows, dim3(nb + ceil_div(nsv, GL_BR), ceil_div(Din, GL_JC)), dim3(GL_BR), 0, st, b, ws.OUTt, ws.svar, nsv, nb);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

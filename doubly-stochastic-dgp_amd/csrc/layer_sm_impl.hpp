@@ -1116,7 +1116,7 @@ static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     DS_HIP(hipMalloc(&clk, (size_t)nrow * 8 * sizeof(unsigned long long)));
     LayerFwdArgs b = a;
     b.phase_clk = clk;
-    hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, b, L);
+    DS_LAUNCH((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, b, L);
     DS_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<unsigned long long> h((size_t)nrow * 8);
     DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1129,7 +1129,7 @@ static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
             ph[5] / nrow, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / nrow);
     return DSDGP_OK;
   }
-  hipLaunchKernelGGL((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
+  DS_LAUNCH((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -1146,7 +1146,7 @@ static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds&
   DS_HIP(hipMalloc(&clk, (size_t)nwg * 8 * sizeof(unsigned long long)));
   LayerBwdArgs a = a0;
   a.phase_clk = clk;
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(nwg, a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds, ctx->stream, a, L);
+  DS_LAUNCH((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(nwg, a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds, ctx->stream, a, L);
   DS_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<unsigned long long> h((size_t)nwg * 8);
   DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1183,7 +1183,7 @@ static int bwd_sm_go2(dsdgp_ctx* ctx, const LayerBwdArgs& a) {
   ProfScope ps(ctx, "layer_bwd");
   static const bool timing = getenv("DSDGP_BWD_TIMING") != nullptr;
   if (timing) return bwd_phase_timing<MPB, NW, KIND, WHITE, WIDE, CS>(ctx, a, L, lds);
-  hipLaunchKernelGGL((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds,
+  DS_LAUNCH((k_layer_bwd_sm<MPB, NW, KIND, WHITE, WIDE, CS>), dim3(ceil_div(a.ldA, 16), a.d_split > 1 ? a.d_split : 1), dim3(NW * 64), lds,
                      ctx->stream, a, L);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;

@@ -465,11 +465,11 @@ static void gemm_dispatch(const GemmProblem* dev, int nprob, int planned, hipStr
   const int total_tiles = planned & ~(GEMM_BIG_FLAG | GEMM_SMALL_FLAG);
   if (total_tiles <= 0) return;
   if (big)
-    hipLaunchKernelGGL(k_gemm_big, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+    DS_LAUNCH(k_gemm_big, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
   else if (small)
-    hipLaunchKernelGGL(k_gemm_small, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+    DS_LAUNCH(k_gemm_small, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
   else
-    hipLaunchKernelGGL(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
+    DS_LAUNCH(k_gemm_grouped, dim3(total_tiles), dim3(256), 0, st, dev, nprob);
 }
 int gemm_launch(dsdgp_ctx* ctx, const GemmProblem* dev, int nprob, int total_tiles, hipStream_t stream) {
   if ((total_tiles & ~(GEMM_BIG_FLAG | GEMM_SMALL_FLAG)) <= 0) return DSDGP_OK;
@@ -800,7 +800,7 @@ int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_m
           lds_set = (int)lds;
         }
       }
-    hipLaunchKernelGGL(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items, nb_max);
+    DS_LAUNCH(k_potrf_trtri<true>, dim3(nitems), dim3(256), lds, ctx->stream, dev_items, nb_max);
   } else {
     if (base > 64 * 1024)
       {
@@ -810,7 +810,7 @@ int potrf_launch(dsdgp_ctx* ctx, const PotrfItem* dev_items, int nitems, int n_m
           lds_set = (int)base;
         }
       }
-    hipLaunchKernelGGL(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items, nb_max);
+    DS_LAUNCH(k_potrf_trtri<false>, dim3(nitems), dim3(256), base, ctx->stream, dev_items, nb_max);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -856,7 +856,7 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
     items[b] = PotrfItem{P + (size_t)b * np * np, nullptr, nullptr, scal_d + 2 * b, np, np, n, 0, 0, 0};
   }
   DS_TRY(ctx_upload(ctx, items_d, items.data(), batch * sizeof(PotrfItem)));   // asynchronous (pinned staging ring)
-  hipLaunchKernelGGL(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
+  DS_LAUNCH(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
   if (np >= 512 && np % 64 == 0) {
     // large matrices: multi-workgroup blocked path; the plan of the last call is kept in the context (the model path pre-builds its plans)
     const int64_t key[4] = {(int64_t)(uintptr_t)P, np, batch, n};
@@ -879,7 +879,7 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   } else {
     DS_TRY(potrf_launch(ctx, items_d, batch, np));
   }
-  hipLaunchKernelGGL(k_unpad, dim3(ceil_div(n * n, 256), batch), dim3(256), 0, ctx->stream, P, np, A, lda, stride, n);
+  DS_LAUNCH(k_unpad, dim3(ceil_div(n * n, 256), batch), dim3(256), 0, ctx->stream, P, np, A, lda, stride, n);
   DS_HIP(hipGetLastError());
   if (info) {
     std::vector<double> sc(2 * batch);
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_trtri_only(double* __restrict__ Wb, dou
 }
 
 int trtri_launch(dsdgp_ctx* ctx, double* W, double* Linv, int n, int64_t stride, int batch) {
-  hipLaunchKernelGGL(k_trtri_only, dim3(batch), dim3(256), 0, ctx->stream, W, Linv, n, stride);
+  DS_LAUNCH(k_trtri_only, dim3(batch), dim3(256), 0, ctx->stream, W, Linv, n, stride);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -1222,20 +1222,20 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
       lds_set = true;
     }
     for (int p = 0; p < nb; ++p) {
-      hipLaunchKernelGGL(k_chol_block, dim3(batch), dim3(CHOL_THREADS), lds, ctx->stream, P.diag_items + (size_t)p * batch);
+      DS_LAUNCH(k_chol_block, dim3(batch), dim3(CHOL_THREADS), lds, ctx->stream, P.diag_items + (size_t)p * batch);
       if (p + 1 < nb) {
         launch(gi++);
         launch(gi++);
       }
     }
-    hipLaunchKernelGGL(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);
+    DS_LAUNCH(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);
   } else if (P.want_inverse) {
-    hipLaunchKernelGGL(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
+    DS_LAUNCH(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
   }
   if (P.want_inverse) {
     while (gi < (int)P.tiles.size()) launch(gi++);
     if (P.LinvT)
-      hipLaunchKernelGGL(k_transpose_lower, dim3(256, batch), dim3(256), 0, ctx->stream, P.Linv, P.LinvT, P.n, P.stride);
+      DS_LAUNCH(k_transpose_lower, dim3(256, batch), dim3(256), 0, ctx->stream, P.Linv, P.LinvT, P.n, P.stride);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;

@@ -290,13 +290,14 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   if (!ctx->side) DS_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   m->side = ctx->side;
 
+  const unsigned evf = hipEventDisableTiming;   // (+ hipEventDisableSystemFence measured neutral in round 5: 0.558 ms either way)
   for (int l = 0; l < L; ++l) {
-    DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], hipEventDisableTiming));
+    DS_HIP(hipEventCreateWithFlags(&m->ev_bwd[l], evf));
   }
-  DS_HIP(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
-  DS_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-  DS_HIP(hipEventCreateWithFlags(&m->ev_prep_side, hipEventDisableTiming));
-  DS_HIP(hipEventCreateWithFlags(&m->ev_z, hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_side, evf));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_fork, evf));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_prep_side, evf));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_z, evf));
   m->prepared = false;
   m->plan_n = -1;
   m->plan_S = -1;
@@ -397,7 +398,7 @@ extern "C" int dsdgp_model_theta_changed(dsdgp_model* m) {
 extern "C" int dsdgp_model_layer_kl(dsdgp_model* m, int32_t l, double* out) {
   DS_CHECK_ARG(m && out && l >= 0 && l < m->desc.L);
   if (!m->prepared) DS_TRY(prepare_async(m));
-  hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(256), 0, m->ctx->stream, m->layers_dev, m->desc.L);
+  DS_LAUNCH(k_kl_final, dim3(1), dim3(256), 0, m->ctx->stream, m->layers_dev, m->desc.L);
   DS_HIP(hipGetLastError());
   DS_HIP(hipMemcpyAsync(out, m->L[l].dev.klv, sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
   return DSDGP_OK;
@@ -418,7 +419,23 @@ extern "C" int dsdgp_model_layer_conditional(dsdgp_model* m, int32_t l, const do
   a.n_inner = n;
   a.mean = mean; a.var = var;
   a.ldA = round_up(n, 16);
-  if (St.gemm && a.ldA <= St.ld_max) return layer_fwd_gemm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws);
+  if (St.gemm) {
+    // the GEMM-formulated pass works in the model's scratch (gws: sized for ld_max rows): more rows than that go through in chunks —
+    // rows are independent (layers.py:71-74), mean / var are row-major, and above Mp = 1024 no chain instance exists to fall back on
+    const int64_t chunk = St.ld_max - St.ld_max % 16;
+    DS_CHECK_ARG(chunk > 0);
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      LayerFwdArgs c = a;
+      c.Rin = std::min<int64_t>(chunk, n - r0);
+      c.n_inner = c.Rin;
+      c.X = X + r0 * v.D_in;
+      c.mean = mean + r0 * v.D_out;
+      c.var = var + r0 * v.D_out;
+      c.ldA = round_up(c.Rin, 16);
+      DS_TRY(layer_fwd_gemm_launch(m->ctx, c, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
+    }
+    return DSDGP_OK;
+  }
   return layer_fwd_sm_launch(m->ctx, a, v.Mp, v.kern_kind, m->desc.white);
 }
 
@@ -426,7 +443,7 @@ extern "C" int dsdgp_reparameterize(dsdgp_ctx* ctx, const double* mean, const do
                                     int64_t count, double* out) {
   DS_CHECK_ARG(ctx && mean && var && z && out && count > 0);
   const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
-  hipLaunchKernelGGL(k_reparam, dim3(nb), dim3(256), 0, ctx->stream, mean, var, z, jitter, count, out);
+  DS_LAUNCH(k_reparam, dim3(nb), dim3(256), 0, ctx->stream, mean, var, z, jitter, count, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

@@ -111,23 +111,23 @@ extern "C" int dsdgp_model_natgrad_step(dsdgp_model* m, int32_t l, double gamma,
   const int nb = (int)std::min<int64_t>(1024, ceil_div(v.D_out * MM, 256));
   // Tp / qmu must reflect the current theta
   if (!m->prepared) DS_TRY(prepare_async(m));
-  hipLaunchKernelGGL(k_ng_prep, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad);
+  DS_LAUNCH(k_ng_prep, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad);
   DS_HIP(hipGetLastError());
   if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngT));
   else DS_TRY(trtri_launch(ctx, v.ngTI, v.ngTinv, v.Mp, MM, v.D_out));
   DS_TRY(gemm_launch(ctx, St.ng_gp, 2, St.ng_t1));
-  hipLaunchKernelGGL(k_ng_phi, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l);
+  DS_LAUNCH(k_ng_phi, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l);
   DS_TRY(gemm_launch(ctx, St.ng_gp + 2, 1, St.ng_t2));
   DS_TRY(gemm_launch(ctx, St.ng_gp + 3, 1, St.ng_t3));
-  hipLaunchKernelGGL(k_ng_assemble, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, gamma);
-  hipLaunchKernelGGL(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
+  DS_LAUNCH(k_ng_assemble, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, gamma);
+  DS_LAUNCH(k_ng_theta1, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->grad,
                      gamma);
   DS_HIP(hipGetLastError());
   if (St.big) DS_TRY(bigchol_run(ctx, St.big_ngA));
   else DS_TRY(potrf_launch(ctx, St.ng_items, v.D_out, v.Mp));
-  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 0);
-  hipLaunchKernelGGL(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 1);
-  hipLaunchKernelGGL(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
+  DS_LAUNCH(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 0);
+  DS_LAUNCH(k_ng_mu, dim3(ceil_div(v.D_out * v.M, 4)), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta, 1);
+  DS_LAUNCH(k_ng_write, dim3(nb), dim3(256), 0, ctx->stream, m->layers_dev, l, m->theta);
   DS_HIP(hipGetLastError());
   m->prepared = false;
   m->q_dirty = (m->q_dirty == -1 || m->q_dirty == l) ? l : -2;     // Z and the kernel hyper-parameters are untouched: kuu_valid stays
@@ -230,14 +230,14 @@ extern "C" int dsdgp_model_layer_conditional_full(dsdgp_model* m, int32_t l, con
   g3 = {pp};
   DS_TRY(run_gemms(ctx, g3, gp));
   const int nb = (int)std::min<int64_t>(2048, ceil_div(NN * D, 256));
-  hipLaunchKernelGGL(k_fullcov_combine, dim3(nb), dim3(256), 0, ctx->stream, Kff, Q, P, n, D, var);
-  hipLaunchKernelGGL(k_add_mean_fn, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, mean, X, n, v.D_in, D,
+  DS_LAUNCH(k_fullcov_combine, dim3(nb), dim3(256), 0, ctx->stream, Kff, Q, P, n, D, var);
+  DS_LAUNCH(k_add_mean_fn, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, mean, X, n, v.D_in, D,
                      St.d.mean_kind, St.meanA, St.meanb);
   DS_HIP(hipGetLastError());
   if (v.has_white) {
     // add the White variance on the diagonal of every output's covariance (Kff of a Sum kernel)
     extern __global__ void k_add_diag_dev(double*, int64_t, int, const double*);
-    hipLaunchKernelGGL(k_add_diag_dev, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, var, n, D, v.hyp + HYP_WVAR);
+    DS_LAUNCH(k_add_diag_dev, dim3(ceil_div(n * D, 256)), dim3(256), 0, ctx->stream, var, n, D, v.hyp + HYP_WVAR);
     DS_HIP(hipGetLastError());
   }
   return DSDGP_OK;
@@ -278,12 +278,12 @@ extern "C" int dsdgp_reparameterize_full(dsdgp_ctx* ctx, const double* mean, con
   double* Lc = nullptr;
   DS_HIP(hipMallocAsync((void**)&Lc, nmat * n * n * sizeof(double), ctx->stream));
   const int nb = (int)std::min<int64_t>(4096, ceil_div(nmat * n * n, 256));
-  hipLaunchKernelGGL(k_fullcov_gather, dim3(nb), dim3(256), 0, ctx->stream, var, n, D, S, jitter, Lc);
+  DS_LAUNCH(k_fullcov_gather, dim3(nb), dim3(256), 0, ctx->stream, var, n, D, S, jitter, Lc);
   DS_HIP(hipGetLastError());
   int info = 0;
   int rc = dsdgp_potrf(ctx, (int)nmat, (int)n, Lc, n, n * n, &info);
   if (rc == DSDGP_OK) {
-    hipLaunchKernelGGL(k_fullcov_sample, dim3(ceil_div((int64_t)S * n * D, 256)), dim3(256), 0, ctx->stream, Lc, mean, z, n, D, S,
+    DS_LAUNCH(k_fullcov_sample, dim3(ceil_div((int64_t)S * n * D, 256)), dim3(256), 0, ctx->stream, Lc, mean, z, n, D, S,
                        out);
     if (hipGetLastError() != hipSuccess) rc = DSDGP_ERR_HIP;
   }

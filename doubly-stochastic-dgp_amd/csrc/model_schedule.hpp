@@ -54,13 +54,14 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     // with a side stream the launch carries the fork event itself (hipExtLaunchKernel attaches it to the dispatch's completion signal):
     // a separate hipEventRecord puts a marker packet on this stream that the next kernel queues behind (~6 us, profiles/r03_timeline_*)
     head_event = side && m->force.ext_ev != 0;
+    g_dsdgp_launches.fetch_add(1, std::memory_order_relaxed);
     hipExtLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk + gq.nblk, L), dim3(HEAD_THREADS), (uint32_t)lds, ctx->stream, nullptr,
                           head_event ? m->ev_fork : nullptr, 0, (const double*)m->theta, (const LayerDev*)m->layers_dev, m->lik_const,
                           (int64_t)m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep,
                           keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r, gq);
     DS_HIP(hipGetLastError());
   } else if (!unchanged) {
-    hipLaunchKernelGGL(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
+    DS_LAUNCH(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
                        m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
                        m->prep_blocks, keep_kuu ? 1 : 0);
     DS_HIP(hipGetLastError());
@@ -104,10 +105,10 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
   } else if (lf >= 0) {
     LayerState& Sq = m->L[lf];
     DS_TRY(gemm_launch(ctx, Sq.lq, Sq.lq_nf, Sq.lq_tf, st));
-    hipLaunchKernelGGL(k_kl_part, dim3(klb, 1), dim3(256), 0, st, m->layers_dev + lf);
+    DS_LAUNCH(k_kl_part, dim3(klb, 1), dim3(256), 0, st, m->layers_dev + lf);
   } else {
     DS_TRY(gemm_launch(ctx, m->gp_fwd, m->n_fwd, m->t_fwd, st));
-    hipLaunchKernelGGL(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
+    DS_LAUNCH(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
   }
   DS_HIP(hipGetLastError());
   if (with_grad && !m->desc.white) {
@@ -173,7 +174,7 @@ extern "C" int dsdgp_model_prepare(dsdgp_model* m, int* info) {
 
 static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t count, double* out, hipStream_t st = nullptr) {
   const int nb = (int)std::min<int64_t>(2048, ceil_div((count + 1) / 2, 256));
-  hipLaunchKernelGGL(k_randn, dim3(nb > 0 ? nb : 1), dim3(256), 0, st ? st : ctx->stream, seed, stream, count, out);
+  DS_LAUNCH(k_randn, dim3(nb > 0 ? nb : 1), dim3(256), 0, st ? st : ctx->stream, seed, stream, count, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -231,7 +232,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     // layer is a latency-bound launch) and enough outputs for the halved d-loop to matter
     // (from Mp = 512 one output's product outlasts the staging latency even on a handful of row blocks: always)
     St.c_used = save_l && St.C && sm_cs_built(v.Mp) &&
-                (v.Mp > 256 || ((Rin + 15) / 16 > m->force.cs_min_blocks && v.D_out >= m->force.cs_min_dout));
+                (v.Mp > 256 || ((Rin + 15) / 16 > m->force.cs_min_blocks && v.D_out >= m->force.cs_min_dout && v.D_out <= m->force.cs_max_dout));
     if (St.gemm) St.c_used = save_l && St.C != nullptr;      // the triangular abar product halves the largest GEMM of the reverse pass
     // (q, q_sqrt)-only gradients: the lowest layer of the reverse pass runs no backward chain (backward_layers), so it keeps neither
     const bool q_lowest = save_l && m->grad_q_only && !m->desc.white && l == m->grad_first;
@@ -253,7 +254,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
     if (St.prop && !last) {
       const int64_t R = (int64_t)S * n, cnt = R * (v.D_out + St.prop);
-      hipLaunchKernelGGL(k_concat_prop, dim3((int)std::min<int64_t>(4096, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream, Xin, Rin,
+      DS_LAUNCH(k_concat_prop, dim3((int)std::min<int64_t>(4096, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream, Xin, Rin,
                          v.D_in, St.prop, a.F, v.D_out, R, St.Xcat);
       DS_HIP(hipGetLastError());
       Xin = St.Xcat;
@@ -396,7 +397,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
 }
 
 static int launch_finalize(dsdgp_model* m, hipStream_t st) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, m->layers_dev, m->desc.L, m->lik_part, m->fin.nblocks, m->fin.w,
+  DS_LAUNCH(k_finalize, dim3(1), dim3(256), 0, st, m->layers_dev, m->desc.L, m->lik_part, m->fin.nblocks, m->fin.w,
                      m->fin.kl_weight, m->lik_const, m->grad,
                      m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.with_grad, m->fin.out);
   DS_HIP(hipGetLastError());
@@ -426,17 +427,17 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool pipelined = bucketed || (overlap && m->force.pipe_tail != 0 && !m->desc.white);
   // split-K reduction + P_d T_d / GS_d products of one layer right behind its weight-gradient products (pipelined tail)
   auto layer_tail = [&](LayerState& St, hipStream_t st) -> int {
-    hipLaunchKernelGGL(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
+    DS_LAUNCH(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
     DS_HIP(hipGetLastError());
     DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st));
     if (bucketed) {
       const int l = (int)(&St - m->L);
       const LayerDev* lay1 = m->layers_dev + l;
-      hipLaunchKernelGGL(k_asm_rows, dim3(St.dev.M, 1), dim3(256), (size_t)m->mp_max_all * sizeof(double), st, lay1, m->grad, kl_weight,
+      DS_LAUNCH(k_asm_rows, dim3(St.dev.M, 1), dim3(256), (size_t)m->mp_max_all * sizeof(double), st, lay1, m->grad, kl_weight,
                          m->mp_max_all);
       FinArgs F{};
       AdamArgs A{};
-      hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, st, m->layers_dev, l, 1, m->grad, F, A);
+      DS_LAUNCH(k_tail, dim3(1), dim3(256), 0, st, m->layers_dev, l, 1, m->grad, F, A);
       DS_HIP(hipGetLastError());
       // this layer's parameters are one contiguous segment of theta: [off_Z, next layer's off_Z) (the last layer's ends where the
       // likelihood variance or the vector ends)
@@ -471,7 +472,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     const bool in_chain = !fused && !last && !skip_chain && m->force.adj_fuse != 0 && !St.c_used && !St.gemm &&
                           sm_adj_fusable(v.Mp, ld / 16, v.D_in, v.D_out);
     if (!fused && !in_chain)
-      hipLaunchKernelGGL(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
+      DS_LAUNCH(k_adj_prep, dim3(ceil_div(ld, 256), std::max(v.DP16, v.DinP16)), dim3(256), 0, ctx->stream, last ? nullptr : St.dF,
                          last ? m->lik_dmean : nullptr, last ? m->lik_dvar : nullptr, St.z_used, St.zs_s, St.zs_n,
                          St.zs_d, n, St.var, St.X_used, Rin, rep, v.D_in, v.D_out, v.DP16, v.DinP16, m->desc.jitter, ld,
                          St.MB, St.VB, St.XT1, v.D_out + St.prop, St.prop);
@@ -533,7 +534,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool red_ahead = overlap && !pipelined && gfirst == 0 && L > 1 && m->force.red_ahead != 0;
   if (red_ahead) {
     LayerState& S0 = m->L[0];
-    hipLaunchKernelGGL(k_reduce_grouped, dim3(S0.red_blkn), dim3(256), 0, ctx->stream, m->rjobs + S0.red_off, S0.red_n, S0.red_blk0);
+    DS_LAUNCH(k_reduce_grouped, dim3(S0.red_blkn), dim3(256), 0, ctx->stream, m->rjobs + S0.red_off, S0.red_n, S0.red_blk0);
     DS_HIP(hipGetLastError());
   }
   if (overlap) {
@@ -548,19 +549,19 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   if (!pipelined) {
     if (red_ahead) {
       LayerState& S1 = m->L[1];
-      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + S1.red_off,
+      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + S1.red_off,
                          m->n_red - S1.red_off, S1.red_blk0);
     } else {
       // (the partial sums of the layers below a pruned pass are stale: their jobs — ordered by layer — are left out)
       const LayerState& Sg = m->L[gfirst];
-      hipLaunchKernelGGL(k_reduce_grouped, dim3(m->red_blocks - Sg.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + Sg.red_off,
+      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - Sg.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + Sg.red_off,
                          m->n_red - Sg.red_off, Sg.red_blk0);
     }
     DS_HIP(hipGetLastError());
     if (m->desc.white) {
-      hipLaunchKernelGGL(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+      DS_LAUNCH(k_white_lbar, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
       DS_TRY(gemm_launch(ctx, m->gp_w1, 2 * L, m->t_w1));
-      hipLaunchKernelGGL(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
+      DS_LAUNCH(k_white_phi, dim3(32, L), dim3(256), 0, ctx->stream, m->layers_dev);
       DS_TRY(gemm_launch(ctx, m->gp_w2, L, m->t_w2));
       DS_TRY(gemm_launch(ctx, m->gp_w3, L, m->t_w3));
     } else if (gfirst > 0) {
@@ -581,7 +582,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
               m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{};
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, 0, 0, m->grad, F, A);
+    DS_LAUNCH(k_tail, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, 0, 0, m->grad, F, A);
     DS_HIP(hipGetLastError());
     m->fin.done = true;
     const int64_t lo = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta;
@@ -591,22 +592,22 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     return DSDGP_OK;
   }
   if (m->tail_ok) {
-    hipLaunchKernelGGL(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
+    DS_LAUNCH(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
                        kl_weight, m->mp_max_all);
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
               m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
                m->fuse_adam.eps, (m->fuse_adam.on && gfirst == 0) ? 1 : 0};
     const int nadam = A.on ? (int)std::min<int64_t>(512, ceil_div(m->desc.n_theta, 256)) : 0;
-    hipLaunchKernelGGL(k_tail, dim3(La + 1 + nadam), dim3(256), 0, ctx->stream, m->layers_dev, gfirst, La, m->grad, F, A);
+    DS_LAUNCH(k_tail, dim3(La + 1 + nadam), dim3(256), 0, ctx->stream, m->layers_dev, gfirst, La, m->grad, F, A);
     DS_HIP(hipGetLastError());
     m->fin.done = true;
     return DSDGP_OK;
   }
-  hipLaunchKernelGGL(k_asm_kbar, dim3(m->kuu_blocks, La), dim3(256), 0, ctx->stream, lay, kl_weight);
+  DS_LAUNCH(k_asm_kbar, dim3(m->kuu_blocks, La), dim3(256), 0, ctx->stream, lay, kl_weight);
   if (m->n_wz) DS_TRY(gemm_launch(ctx, m->gp_wz, m->n_wz, m->t_wz));   // (wm of the layers below gfirst is stale: their WZ is never read)
-  if (m->need_hyp_part) hipLaunchKernelGGL(k_asm_hyp_part, dim3(NPART, La), dim3(256), 0, ctx->stream, lay);
-  hipLaunchKernelGGL(k_asm_params, dim3(m->asm_blocks + 1, La), dim3(256), 0, ctx->stream, lay, m->grad, kl_weight);
+  if (m->need_hyp_part) DS_LAUNCH(k_asm_hyp_part, dim3(NPART, La), dim3(256), 0, ctx->stream, lay);
+  DS_LAUNCH(k_asm_params, dim3(m->asm_blocks + 1, La), dim3(256), 0, ctx->stream, lay, m->grad, kl_weight);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }
@@ -689,10 +690,10 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
     double* mbt = m->fused_last ? last.MB : nullptr;
     double* vbt = m->fused_last ? last.VB : nullptr;
     if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN)
-      hipLaunchKernelGGL(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
+      DS_LAUNCH(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
                          w, m->sample_w, m->lik_part, dm, dv, mbt, vbt, ldt);
     else
-      hipLaunchKernelGGL(k_lik_bern, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, w, m->sample_w,
+      DS_LAUNCH(k_lik_bern, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, w, m->sample_w,
                          m->lik_part, dm, dv, mbt, vbt, ldt);
   } else {
     // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
@@ -702,11 +703,11 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
                              with_grad ? m->lik_dvar : nullptr, -1));
     if (m->sample_w) {
       const int64_t cnt = R * DY;
-      hipLaunchKernelGGL(k_scale_by_sample, dim3((int)std::min<int64_t>(2048, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream,
+      DS_LAUNCH(k_scale_by_sample, dim3((int)std::min<int64_t>(2048, ceil_div(cnt, 256))), dim3(256), 0, ctx->stream,
                          m->sample_w, n, S, DY, R, last.F, with_grad ? m->lik_dmean : nullptr, with_grad ? m->lik_dvar : nullptr);
     }
     nblocks = ceil_div(R, 256);
-    hipLaunchKernelGGL(k_partial_sum, dim3(nblocks), dim3(256), 0, ctx->stream, last.F, R, m->lik_part);
+    DS_LAUNCH(k_partial_sum, dim3(nblocks), dim3(256), 0, ctx->stream, last.F, R, m->lik_part);
   }
   DS_HIP(hipGetLastError());
   m->fin.nblocks = nblocks; m->fin.w = w; m->fin.kl_weight = kl_weight; m->fin.with_grad = with_grad; m->fin.out = out;
@@ -746,7 +747,7 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
   const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   const int64_t n = m->desc.n_theta;
   const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));
-  hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
+  DS_LAUNCH(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
                      lr_t, beta1, beta2, eps);
   DS_HIP(hipGetLastError());
   m->prepared = false;

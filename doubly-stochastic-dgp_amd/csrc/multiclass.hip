@@ -125,7 +125,7 @@ int multiclass_launch(dsdgp_ctx* ctx, const double* mean, const double* var, con
     return DSDGP_ERR_UNSUPPORTED;
   }
   DS_TRY(ensure_gh(ctx->stream));
-  hipLaunchKernelGGL(k_multiclass, dim3(ceil_div(R, MC_RW)), dim3(MC_T), 0, ctx->stream, mean, var, Y, n, R, K, 1e-3, mode,
+  DS_LAUNCH(k_multiclass, dim3(ceil_div(R, MC_RW)), dim3(MC_T), 0, ctx->stream, mean, var, Y, n, R, K, 1e-3, mode,
                      wgt, out, dmean, dvar, y_override);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -155,7 +155,7 @@ extern "C" int dsdgp_multiclass_var_exp(dsdgp_ctx* ctx, const double* mean, cons
   void* scr;
   DS_TRY(ctx_scratch(ctx, (size_t)S * n * sizeof(double), &scr));
   DS_TRY(multiclass_launch(ctx, mean, var, Y, n, (int64_t)S * n, K, mode, 0.0, (double*)scr, nullptr, nullptr, -1));
-  hipLaunchKernelGGL(k_over_samples, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const double*)scr, n, S, mode,
+  DS_LAUNCH(k_over_samples, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const double*)scr, n, S, mode,
                      mode == 0 ? sample_w : nullptr, out);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
@@ -181,8 +181,8 @@ extern "C" int dsdgp_multiclass_predict(dsdgp_ctx* ctx, const double* mean, cons
   const int nb = (int)std::min<int64_t>(2048, ceil_div(R, 256));
   for (int k = 0; k < K; ++k) {
     DS_TRY(multiclass_launch(ctx, mean, var, nullptr, R, R, K, 1, 0.0, (double*)scr, nullptr, nullptr, k));
-    hipLaunchKernelGGL(k_scatter_col, dim3(nb), dim3(256), 0, ctx->stream, (const double*)scr, out_mean, R, K, k);
-    hipLaunchKernelGGL(k_exp_inplace, dim3(nb), dim3(256), 0, ctx->stream, out_mean, out_var, R, K, k);
+    DS_LAUNCH(k_scatter_col, dim3(nb), dim3(256), 0, ctx->stream, (const double*)scr, out_mean, R, K, k);
+    DS_LAUNCH(k_exp_inplace, dim3(nb), dim3(256), 0, ctx->stream, out_mean, out_var, R, K, k);
   }
   DS_HIP(hipGetLastError());
   return DSDGP_OK;

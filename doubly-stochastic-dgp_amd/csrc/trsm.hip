@@ -151,8 +151,8 @@ static int trsm_left_looking(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, con
   DS_TRY(ctx_scratch(ctx, dbytes + (trans ? (size_t)n * n * sizeof(double) : 0), &scr));
   double* Dinv = (double*)scr;
   double* LT = (double*)((char*)scr + dbytes);
-  hipLaunchKernelGGL(k_trsm_diag, dim3(nb, 1), dim3(64), 0, ctx->stream, L, ldl, (int64_t)0, n, Dinv, (int64_t)nb * 256);
-  if (trans) hipLaunchKernelGGL(k_trsm_transpose, dim3(ceil_div(n, 32), ceil_div(n, 32)), dim3(256), 0, ctx->stream, L, ldl, n, LT);
+  DS_LAUNCH(k_trsm_diag, dim3(nb, 1), dim3(64), 0, ctx->stream, L, ldl, (int64_t)0, n, Dinv, (int64_t)nb * 256);
+  if (trans) DS_LAUNCH(k_trsm_transpose, dim3(ceil_div(n, 32), ceil_div(n, 32)), dim3(256), 0, ctx->stream, L, ldl, n, LT);
   DS_HIP(hipGetLastError());
   for (int pi = 0; pi < npanel; ++pi) {
     const int p = trans ? npanel - 1 - pi : pi;
@@ -164,7 +164,7 @@ static int trsm_left_looking(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs, con
                          n - (r0 + pn), -1.0));
     TrsmPanel P{L, ldl, 0, Dinv, 0, B, ldb, 0, n, r0, pn, nrhs, trans ? 1 : 0};
     ProfScope ps(ctx, "trsm");
-    hipLaunchKernelGGL(k_trsm_panel, dim3(ceil_div(nrhs, 64), 1), dim3(256), 0, ctx->stream, P);
+    DS_LAUNCH(k_trsm_panel, dim3(ceil_div(nrhs, 64), 1), dim3(256), 0, ctx->stream, P);
     DS_HIP(hipGetLastError());
   }
   return DSDGP_OK;
@@ -186,7 +186,7 @@ extern "C" int dsdgp_trsm_batched(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs
   double* Dinv = (double*)scr;
   GemmProblem* gp = (GemmProblem*)((char*)scr + dbytes);
   const int64_t strideD = strideL == 0 ? 0 : (int64_t)nb * 256;
-  hipLaunchKernelGGL(k_trsm_diag, dim3(nb, nL), dim3(64), 0, ctx->stream, L, ldl, strideL, n, Dinv, (int64_t)nb * 256);
+  DS_LAUNCH(k_trsm_diag, dim3(nb, nL), dim3(64), 0, ctx->stream, L, ldl, strideL, n, Dinv, (int64_t)nb * 256);
   DS_HIP(hipGetLastError());
   // the GEMM descriptors of all panels in one upload
   std::vector<GemmProblem> probs(npanel);
@@ -217,7 +217,7 @@ extern "C" int dsdgp_trsm_batched(dsdgp_ctx* ctx, int trans, int n, int64_t nrhs
     TrsmPanel P{L, ldl, strideL, Dinv, strideD, B, ldb, strideB, n, p * TRSM_PANEL, std::min(TRSM_PANEL, n - p * TRSM_PANEL), nrhs, trans ? 1 : 0};
     {
       ProfScope ps(ctx, "trsm");
-      hipLaunchKernelGGL(k_trsm_panel, dim3(ceil_div(nrhs, 64), batch), dim3(256), 0, ctx->stream, P);
+      DS_LAUNCH(k_trsm_panel, dim3(ceil_div(nrhs, 64), batch), dim3(256), 0, ctx->stream, P);
       DS_HIP(hipGetLastError());
     }
     if (probs[pi].m > 0) DS_TRY(gemm_launch(ctx, gp + pi, 1, tiles[pi]));

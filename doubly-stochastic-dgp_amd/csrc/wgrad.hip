@@ -153,7 +153,7 @@ int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_
   if (total_tasks <= 0) return DSDGP_OK;
   hipStream_t st = stream ? stream : ctx->stream;
   ProfScope ps(ctx, "wgrad", st);
-  hipLaunchKernelGGL((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
+  DS_LAUNCH((k_wgrad_coop<4, 4>), dim3(total_tasks), dim3(256), 0, st, jobs_dev, njobs, nsplit, ld, Rp, total_tasks);
   DS_HIP(hipGetLastError());
   return DSDGP_OK;
 }

@@ -63,6 +63,7 @@ _PROTOS = {
     "dsdgp_sync": (C.c_int, [C.c_void_p]),
     "dsdgp_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dsdgp_prof_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "dsdgp_launch_count": (C.c_int64, []),
     "dsdgp_gram": (C.c_int, [C.c_void_p, C.POINTER(KernelSpec), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                              C.c_double, C.c_void_p, C.c_int64]),
     "dsdgp_potrf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int)]),

@@ -61,6 +61,9 @@ int dsdgp_sync(dsdgp_ctx* ctx);
  * {"layer_fwd","layer_bwd","wgrad","gram","potrf","gemm"}. */
 int dsdgp_prof_enable(dsdgp_ctx* ctx, int on);
 int dsdgp_prof_read(dsdgp_ctx* ctx, const char* name, double* total_ms, int64_t* launches, int reset);
+/* Kernel launches this library has enqueued in this process so far (all contexts; memsets / copies not counted): the difference
+ * around a loop of steps is that loop's launches per step (bench.py `launches_per_step`).  No reference counterpart: measurement aid. */
+int64_t dsdgp_launch_count(void);
 
 /* ---- primitives (north_star: Gram assembly, blocked Cholesky, trsm) ----------------------------------- */
 /* Kernel hyper-parameters, host side.  lengthscales: host pointer to 1 (ard=0) or input_dim (ard=1) values. */
@@ -181,7 +184,8 @@ int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, double beta2,
  * update applied by the last launch of the reverse pass instead of a launch of its own.  Same arguments and `out` as
  * dsdgp_model_elbo; `grad` holds the gradient the update used.  Single-process training only: a data-parallel step needs the
  * all-reduce between the two halves (dsdgp_model_elbo, dsdgp_allreduce, dsdgp_model_adam_step).  DSDGP_ERR_BAD_ARG while
- * dsdgp_model_set_grad_first_layer restricts the reverse pass. */
+ * dsdgp_model_set_grad_first_layer / dsdgp_model_set_grad_q_only restrict the reverse pass (the caller lifts the restriction first:
+ * the step does not do it on the caller's behalf). */
 int dsdgp_model_train_step(dsdgp_model* m, const double* X, const double* Y, int64_t n, int32_t S, const double* const* zs,
                            const int64_t* zstride, uint64_t seed, double data_scale, double kl_weight, double lr, double beta1,
                            double beta2, double eps, int64_t t, double* out);
@@ -211,8 +215,10 @@ int dsdgp_model_set_grad_first_layer(dsdgp_model* m, int32_t first);
  * NatGradOptimizer.minimize always passes (demos/demo_regression_UCI.ipynb:360-366, tests/test_collapsed.py:100): TensorFlow's reverse
  * pass then never visits Kuf / Kuu of the lowest layer in var_list (their adjoints feed Z, the kernel hyper-parameters and the layers
  * below only).  on != 0: dsdgp_model_elbo(with_grad=1) leaves complete (q_mu, q_sqrt) entries for the layers >= first
- * (dsdgp_model_set_grad_first_layer) and UNDEFINED values in their other entries; dsdgp_model_adam_step / _train_step fail with
- * DSDGP_ERR_BAD_ARG until a full gradient has been evaluated again.  on = 0 restores the full gradient.  Ignored for white=True models. */
+ * (dsdgp_model_set_grad_first_layer) and UNDEFINED values in their other entries.  dsdgp_model_adam_step fails with DSDGP_ERR_BAD_ARG
+ * until a full gradient has been evaluated again; dsdgp_model_train_step[_minibatch] (which would evaluate its own gradient under
+ * the restriction) fails with DSDGP_ERR_BAD_ARG for as long as the restriction is set: call dsdgp_model_set_grad_q_only(m, 0) and
+ * dsdgp_model_set_grad_first_layer(m, 0) first.  on = 0 restores the full gradient.  Ignored for white=True models. */
 int dsdgp_model_set_grad_q_only(dsdgp_model* m, int32_t on);
 
 /* Optional contract for callers that alternate optimisers (demo_regression_UCI.ipynb:360-366: one Adam step on the hyper-parameters,
