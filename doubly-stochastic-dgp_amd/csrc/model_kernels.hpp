@@ -515,6 +515,48 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     return;
   }
   const int rwave = threadIdx.x >> 6;
+  if (J.ways == 64) {
+    // symmetric result with ONE or TWO splits (large M: the weight-gradient launch has more tiles than the chip has workgroup slots,
+    // choose_nsplit returns 1 — configs 4 / 5): nothing to reduce, the job is a copy of the lower 64 x 64 tiles plus their mirror.
+    // One tile per workgroup, 16-byte loads along rows, the tile parked in LDS (odd stride), both stores along rows.  The 16 x 16 form
+    // below moved 2 KB per workgroup with three of its four waves adding zeros: 226 us per step at config 4 (1.3 TB/s).
+    // Same sums as that form (p0, or p0 + p1): bit-identical.
+    __shared__ double t64[64][65];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int t = bx - J.blk_start, ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+    const double* __restrict__ src = J.part + (int64_t)(64 * ti + r) * J.in_ld + 64 * tj + c0;
+    d2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const d2*>(src + 2 * u);
+    if (J.nsplit == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += *reinterpret_cast<const d2*>(src + J.pstride + 2 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      t64[r][c0 + 2 * u] = v[u][0];
+      t64[r][c0 + 2 * u + 1] = v[u][1];
+    }
+    __syncthreads();
+    double* __restrict__ o = J.out + (int64_t)(64 * ti + r) * J.out_ld + 64 * tj + c0;
+    const bool diag = ti == tj;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      d2 w = v[u];
+      // diagonal tile: its 16 x 16 blocks above the block diagonal were not computed — they mirror the blocks below
+      if (diag && ((c0 + 2 * u) >> 4) > (r >> 4)) w = (d2){t64[c0 + 2 * u][r], t64[c0 + 2 * u + 1][r]};
+      *reinterpret_cast<d2*>(o + 2 * u) = w;
+    }
+    if (!diag) {
+      double* __restrict__ om = J.out + (int64_t)(64 * tj + r) * J.out_ld + 64 * ti + c0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<d2*>(om + 2 * u) = (d2){t64[c0 + 2 * u][r], t64[c0 + 2 * u + 1][r]};
+    }
+    return;
+  }
   if (J.ways == 16) {
     // symmetric result, one 16 x 16 tile on or below the diagonal per workgroup: each wave sums a quarter of the splits for the whole
     // tile (16-byte loads, four splits in flight per wave), the four partial tiles meet in LDS, and the tile goes out twice —

@@ -373,9 +373,13 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     const int64_t rows = r.out_ld > 0 ? r.count / r.out_ld : 0;
     const bool tiled = !r.wide && r.sym_n > 0 && r.sym_tile == 16 && r.out_ld > 0 && rows == r.out_ld && rows % 16 == 0 && even;
     if (tiled) r.ways = 16;
+    // one or two splits of a symmetric result on whole 64-tiles: the copy-and-mirror form (one 64 x 64 tile per workgroup)
+    const bool tiled64 = tiled && r.nsplit <= 2 && rows % 64 == 0 && r.sym_n % 64 == 0 && ((uintptr_t)r.out & 15) == 0;
+    if (tiled64) r.ways = 64;
     r.blk_start = blocks;
     blocks += r.wide ? (int)r.count
-                     : (tiled ? (int)((rows / 16) * (rows / 16 + 1) / 2) : ceil_div(r.count, r.ways == 8 ? 128 : (r.ways == 4 ? 64 : 256)));
+                     : (tiled64 ? (int)((rows / 64) * (rows / 64 + 1) / 2)
+                                : (tiled ? (int)((rows / 16) * (rows / 16 + 1) / 2) : ceil_div(r.count, r.ways == 8 ? 128 : (r.ways == 4 ? 64 : 256))));
   }
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
