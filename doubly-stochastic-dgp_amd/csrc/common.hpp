@@ -104,6 +104,13 @@ struct ProfScope {
   }
 };
 
+// A thread's wave index is the same in all 64 lanes of its wave, but `threadIdx.x >> 6` is a per-lane value to the compiler: loops whose
+// bounds depend on it (the triangular k ranges of the chains, the row ranges of the split-K products) become DIVERGENT loops — exec-mask
+// loop control, no unrolling (the "loop not unrolled" warnings), 64-bit VALU address arithmetic per load, load -> wait -> MFMA per
+// k-block.  Read through an SGPR the index is uniform: scalar loop control and the requested unrolling / prefetch distance.
+#ifdef __HIPCC__
+#define DS_WAVE_ID(tid) __builtin_amdgcn_readfirstlane((int)(tid) >> 6)
+#endif
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -53,6 +53,49 @@ __device__ __forceinline__ d4 chain_block(const double* __restrict__ WR, const d
   return acc;
 }
 
+// acc += sum_{kb = lo}^{hi - 1} W-block(ib, kb) . act-block(kb): the triangular products of the forward chain (k ranges that depend on
+// the wave's row block, i.e. run-time trip counts).  Scalar operand order (Mp <= 256): SOFTWARE-PIPELINED by hand, two k-blocks deep —
+// the four weight loads of block kb + 1 are issued before the four MFMAs of block kb.  Left to `#pragma unroll 4` the compiler keeps
+// one k-block per iteration (the loop is divergent to it: its bounds depend on threadIdx.x >> 6; "loop not unrolled" warnings) and
+// every block is load x 4 -> s_waitcnt -> MFMA x 4: one L1 / L2 round trip in front of every four MFMAs, hidden only by the other waves
+// of the SIMD (profiles/r05_fwd_chain_isa.md: 47 TFLOP/s executed in the forward chain at M = 256 against 68 in the backward chain,
+// whose loops have compile-time bounds and come out twelve loads deep).
+template <int Mp, bool D4>
+__device__ __forceinline__ d4 chain_range(const double* __restrict__ WR, const double* __restrict__ WT,
+                                          const double* __restrict__ actb, int ib, int lo, int hi, int g, int c, d4 acc) {
+  if constexpr (D4) {
+#pragma unroll 4
+    for (int kb = lo; kb < hi; ++kb) acc = chain_block<Mp, true>(WR, WT, actb, ib, kb, g, c, acc);
+    return acc;
+  } else {
+    if (lo >= hi) return acc;
+    const double* __restrict__ w = WT + (int64_t)g * Mp + 16 * ib + c;      // + (16 kb + 4 s) Mp
+    double wa[4], wb[4];
+    int kb = lo;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa[s] = w[(int64_t)(16 * kb + 4 * s) * Mp];
+    while (kb + 1 < hi) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wb[s] = w[(int64_t)(16 * (kb + 1) + 4 * s) * Mp];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_f64(wa[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
+      ++kb;
+      if (kb + 1 < hi) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wa[s] = w[(int64_t)(16 * (kb + 1) + 4 * s) * Mp];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_f64(wb[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
+      ++kb;
+    }
+    if (kb < hi) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_f64(wa[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
+    }
+    return acc;
+  }
+}
+
 template <int MPB, int NW>
 struct Own {
   // NQ row blocks per wave; MPB need not be a multiple of NW (inducing counts padded to 16 / 32 / 64 / 128 instead of powers of
@@ -258,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
   constexpr bool ILV = D4 || (MPB >= 16);   // interleave the NQ row-block chains inside the k loop (measured: helps from NQ = 4)
   const int Din = a.D_in, Dout = a.D_out;
   const int qld = a.qmu_ld ? a.qmu_ld : Dout;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = DS_WAVE_ID(tid);
   const int g = lane >> 4, c = lane & 15;
   double* xs = smem + L.xs;
   double* actb = smem + L.act;                            // single in-place activation buffer ([k][16 rows])
@@ -335,8 +378,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
     for (int q = 0; q < NQ; ++q) {
       const int ib = Own<MPB, NW>::ib(wave, q);
       if (Own<MPB, NW>::skip(ib)) continue;
-#pragma unroll 4
-      for (int kb = 0; kb <= ib; ++kb) acc[q] = chain_block<Mp, D4>(a.Linv, a.LinvT, actb, ib, kb, g, c, acc[q]);
+      acc[q] = chain_range<Mp, D4>(a.Linv, a.LinvT, actb, ib, 0, ib + 1, g, c, acc[q]);
     }
   }
   {
@@ -369,8 +411,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
       for (int q = 0; q < NQ; ++q) {
         const int ib = Own<MPB, NW>::ib(wave, q);
         if (Own<MPB, NW>::skip(ib)) continue;
-#pragma unroll 4
-        for (int kb = ib; kb < MPB; ++kb) acc[q] = chain_block<Mp, D4>(a.LinvT, a.Linv, actb, ib, kb, g, c, acc[q]);
+        acc[q] = chain_range<Mp, D4>(a.LinvT, a.Linv, actb, ib, ib, MPB, g, c, acc[q]);
       }
     }
     __syncthreads();   // a1 fully consumed -> overwrite with a
@@ -441,8 +482,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
         for (int q = 0; q < NQ; ++q) {
           const int ib = Own<MPB, NW>::ib(wave, q);
           if (Own<MPB, NW>::skip(ib)) continue;
-#pragma unroll 4
-          for (int kb = ib; kb < MPB; ++kb) cacc[q] = chain_block<Mp, D4>(TdT, Td, actb, ib, kb, g, c, cacc[q]);
+          cacc[q] = chain_range<Mp, D4>(TdT, Td, actb, ib, ib, MPB, g, c, cacc[q]);
         }
       }
       double p = 0.0, mu = 0.0;
