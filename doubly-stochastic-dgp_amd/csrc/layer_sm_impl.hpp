@@ -69,20 +69,23 @@ __device__ __forceinline__ d4 chain_range(const double* __restrict__ WR, const d
     return acc;
   } else {
     if (lo >= hi) return acc;
-    const double* __restrict__ w = WT + (int64_t)g * Mp + 16 * ib + c;      // + (16 kb + 4 s) Mp
+    // address = uniform row base (SGPR pair: kb, s are wave-uniform) + a 32-bit per-lane offset: the scalar-base form of global_load,
+    // no 64-bit VALU address arithmetic and no address registers per load
+    const unsigned off = (unsigned)(g * Mp + 16 * ib + c);
+    auto wld = [&](int kbx, int s) { return (WT + (size_t)(16 * kbx + 4 * s) * Mp)[off]; };
     double wa[4], wb[4];
     int kb = lo;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wa[s] = w[(int64_t)(16 * kb + 4 * s) * Mp];
+    for (int s = 0; s < 4; ++s) wa[s] = wld(kb, s);
     while (kb + 1 < hi) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) wb[s] = w[(int64_t)(16 * (kb + 1) + 4 * s) * Mp];
+      for (int s = 0; s < 4; ++s) wb[s] = wld(kb + 1, s);
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = mfma_f64(wa[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
       ++kb;
       if (kb + 1 < hi) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wa[s] = w[(int64_t)(16 * (kb + 1) + 4 * s) * Mp];
+        for (int s = 0; s < 4; ++s) wa[s] = wld(kb + 1, s);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = mfma_f64(wb[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
@@ -93,6 +96,53 @@ __device__ __forceinline__ d4 chain_range(const double* __restrict__ WR, const d
       for (int s = 0; s < 4; ++s) acc = mfma_f64(wa[s], actb[(16 * kb + 4 * s + g) * 16 + c], acc);
     }
     return acc;
+  }
+}
+
+// The same for the TWO row blocks a wave owns (NQ = 2: ib0 = wave, ib1 = 2 NW - 1 - wave), interleaved: where both k ranges overlap the
+// wave runs two independent accumulator chains on ONE activation fragment per k-step (half the LDS reads, eight weight loads in flight
+// ahead of eight MFMAs), before that the longer range alone.  UPPER: k ranges [ib, hi) (Lu^-T, q_sqrt^T products); else [0, ib + 1).
+template <int Mp, bool UPPER>
+__device__ __forceinline__ void chain_range2(const double* __restrict__ WT, const double* __restrict__ actb, int ib0, int ib1, int nkb,
+                                             int g, int c, d4& acc0, d4& acc1) {
+  // ib0 < ib1.  UPPER: chain 0 covers [ib0, nkb), chain 1 [ib1, nkb): chain 0 alone on [ib0, ib1), both on [ib1, nkb).
+  //             else : chain 0 covers [0, ib0], chain 1 [0, ib1]     : both on [0, ib0], chain 1 alone on (ib0, ib1].
+  const unsigned off0 = (unsigned)(g * Mp + 16 * ib0 + c), off1 = (unsigned)(g * Mp + 16 * ib1 + c);    // (scalar row base + lane offset)
+  auto wld = [&](int kbx, int s, unsigned off) { return (WT + (size_t)(16 * kbx + 4 * s) * Mp)[off]; };
+  if constexpr (UPPER) {
+    acc0 = chain_range<Mp, false>(nullptr, WT, actb, ib0, ib0, ib1, g, c, acc0);
+  }
+  const int lo = UPPER ? ib1 : 0, hi = UPPER ? nkb : ib0 + 1;
+  if (lo < hi) {
+    // ONE register set per chain, refilled in place: the weight of k-step s of block kb + 1 is requested right behind the MFMA that
+    // consumed the one of block kb (eight loads in flight per wave; a second register set — two blocks deep — costs 16 VGPRs and with
+    // them an occupancy step at M = 128 and M = 256)
+    double a0[4], a1[4];
+    int kb = lo;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a0[s] = wld(kb, s, off0);
+      a1[s] = wld(kb, s, off1);
+    }
+    for (; kb + 1 < hi; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double bv = actb[(16 * kb + 4 * s + g) * 16 + c];
+        acc0 = mfma_f64(a0[s], bv, acc0);
+        acc1 = mfma_f64(a1[s], bv, acc1);
+        a0[s] = wld(kb + 1, s, off0);
+        a1[s] = wld(kb + 1, s, off1);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double bv = actb[(16 * kb + 4 * s + g) * 16 + c];
+      acc0 = mfma_f64(a0[s], bv, acc0);
+      acc1 = mfma_f64(a1[s], bv, acc1);
+    }
+  }
+  if constexpr (!UPPER) {
+    acc1 = chain_range<Mp, false>(nullptr, WT, actb, ib1, ib0 + 1, ib1 + 1, g, c, acc1);
   }
 }
 
@@ -373,12 +423,18 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
   // --- a1 = Lu^{-1} k (layers.py:186): out block ib sums k-blocks kb <= ib ; weights LinvT[k][i]
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
+  // two row blocks per wave, both real, scalar operand order: the interleaved pair (chain_range2); else one chain after the other
+  constexpr bool PAIR = (NQ == 2) && !D4 && (MPB % NW == 0);
   if (act) {
+    if constexpr (PAIR) {
+      chain_range2<Mp, false>(a.LinvT, actb, Own<MPB, NW>::ib(wave, 0), Own<MPB, NW>::ib(wave, 1), MPB, g, c, acc[0], acc[1]);
+    } else {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ib = Own<MPB, NW>::ib(wave, q);
-      if (Own<MPB, NW>::skip(ib)) continue;
-      acc[q] = chain_range<Mp, D4>(a.Linv, a.LinvT, actb, ib, 0, ib + 1, g, c, acc[q]);
+      for (int q = 0; q < NQ; ++q) {
+        const int ib = Own<MPB, NW>::ib(wave, q);
+        if (Own<MPB, NW>::skip(ib)) continue;
+        acc[q] = chain_range<Mp, D4>(a.Linv, a.LinvT, actb, ib, 0, ib + 1, g, c, acc[q]);
+      }
     }
   }
   {
@@ -407,11 +463,15 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = (d4){0, 0, 0, 0};
     if (act) {
+      if constexpr (PAIR) {
+        chain_range2<Mp, true>(a.Linv, actb, Own<MPB, NW>::ib(wave, 0), Own<MPB, NW>::ib(wave, 1), MPB, g, c, acc[0], acc[1]);
+      } else {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int ib = Own<MPB, NW>::ib(wave, q);
-        if (Own<MPB, NW>::skip(ib)) continue;
-        acc[q] = chain_range<Mp, D4>(a.LinvT, a.Linv, actb, ib, ib, MPB, g, c, acc[q]);
+        for (int q = 0; q < NQ; ++q) {
+          const int ib = Own<MPB, NW>::ib(wave, q);
+          if (Own<MPB, NW>::skip(ib)) continue;
+          acc[q] = chain_range<Mp, D4>(a.LinvT, a.Linv, actb, ib, ib, MPB, g, c, acc[q]);
+        }
       }
     }
     __syncthreads();   // a1 fully consumed -> overwrite with a
@@ -478,11 +538,15 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
       if (act) {
         const double* __restrict__ TdT = a.TpT + (int64_t)d * Mp * Mp;
         const double* __restrict__ Td = a.Tp + (int64_t)d * Mp * Mp;
+        if constexpr (PAIR) {
+          chain_range2<Mp, true>(Td, actb, Own<MPB, NW>::ib(wave, 0), Own<MPB, NW>::ib(wave, 1), MPB, g, c, cacc[0], cacc[1]);
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int ib = Own<MPB, NW>::ib(wave, q);
-          if (Own<MPB, NW>::skip(ib)) continue;
-          cacc[q] = chain_range<Mp, D4>(TdT, Td, actb, ib, ib, MPB, g, c, cacc[q]);
+          for (int q = 0; q < NQ; ++q) {
+            const int ib = Own<MPB, NW>::ib(wave, q);
+            if (Own<MPB, NW>::skip(ib)) continue;
+            cacc[q] = chain_range<Mp, D4>(TdT, Td, actb, ib, ib, MPB, g, c, cacc[q]);
+          }
         }
       }
       double p = 0.0, mu = 0.0;
