@@ -133,6 +133,13 @@ __device__ __forceinline__ void chain_range2(const double* __restrict__ WT, cons
         a0[s] = wld(kb + 1, s, off0);
         a1[s] = wld(kb + 1, s, off1);
       }
+      // pin the interleave: two MFMAs, then the two loads that refill their weight registers, four times.  Without it the scheduler
+      // sinks all eight loads to the end of the block (behind the eighth MFMA) and the next block starts by waiting for them.
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
