@@ -13,6 +13,53 @@
 #define GK 16
 #define GLD 81  // odd LDS row stride (doubles): conflict-free k-major writes, <=2-way on the fragment reads
 
+// Interior tiles of k_gemm_grouped (the whole 64 x 64 tile and every 16-step of its k range inside the matrices, even leading
+// dimensions, 16-byte aligned bases): the (batch, k-tile) pipeline with the operand orientation as template parameters and ONE 32-byte
+// load per operand, thread and step.  The generic loop below decides the orientation per element at run time and guards every element:
+// eight 8-byte loads per thread and step, each behind its own branch, and ~250 VALU instructions of index arithmetic per sixteen MFMAs
+// (profiles/r05_gemm_grouped_isa.md) — 33 TFLOP/s on the 1024 x 1024 x 1024 products of config 5.
+template <bool TA, bool TB>
+__device__ __forceinline__ void gg_interior(const GemmProblem& P, int m0, int n0, int b0, int ks_lo, int ksteps, int nsteps, double* As,
+                                            double* Bs, int tid, int g, int c, int wr, int wc, d4 (&acc)[2][2]) {
+  typedef const d4 __attribute__((address_space(1)))* gd4;
+  // A tile 64 (m) x 16 (k): row-major A (!TA): thread -> row tid >> 2, k offset 4 (tid & 3); A^T stored (TA): row k = tid >> 4, m offset 4 (tid & 15)
+  const int ar = TA ? (tid >> 4) : (tid >> 2), ao = TA ? 4 * (tid & 15) : 4 * (tid & 3);
+  const int br = TB ? (tid >> 2) : (tid >> 4), bo = TB ? 4 * (tid & 3) : 4 * (tid & 15);
+  d4 ra, rb;
+  auto gload = [&](int step) {
+    const int b = b0 + step / ksteps, k0 = (ks_lo + step % ksteps) * GK;
+    gcptr A = (gcptr)(P.A + (int64_t)b * P.sA);
+    gcptr B = (gcptr)(P.B + (int64_t)b * P.sB);
+    ra = TA ? *reinterpret_cast<gd4>(A + (int64_t)(k0 + ar) * P.lda + m0 + ao) : *reinterpret_cast<gd4>(A + (int64_t)(m0 + ar) * P.lda + k0 + ao);
+    rb = TB ? *reinterpret_cast<gd4>(B + (int64_t)(n0 + br) * P.ldb + k0 + bo) : *reinterpret_cast<gd4>(B + (int64_t)(k0 + br) * P.ldb + n0 + bo);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (TA) As[ar * GLD + ao + j] = ra[j]; else As[(ao + j) * GLD + ar] = ra[j];
+      if (TB) Bs[(bo + j) * GLD + br] = rb[j]; else Bs[br * GLD + bo + j] = rb[j];
+    }
+  };
+  gload(0);
+  for (int step = 0; step < nsteps; ++step) {
+    lstore();
+    __syncthreads();
+    if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+    for (int k4 = 0; k4 < GK; k4 += 4) {
+      const double a0 = As[(k4 + g) * GLD + wr * 32 + c];
+      const double a1 = As[(k4 + g) * GLD + wr * 32 + 16 + c];
+      const double b0v = Bs[(k4 + g) * GLD + wc * 32 + c];
+      const double b1v = Bs[(k4 + g) * GLD + wc * 32 + 16 + c];
+      acc[0][0] = mfma_f64(a0, b0v, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1v, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0v, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1v, acc[1][1]);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restrict__ probs, int nprob) {
   __shared__ double As[GK * GLD];
   __shared__ double Bs[GK * GLD];
@@ -88,6 +135,17 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
       Bs[k2 * GLD + nn] = rb[i];
     }
   };
+  const bool interior = nsteps > 0 && m0 + GT <= P.m && n0 + GT <= P.n && (ks_lo + ksteps) * GK <= P.k && ((P.lda | P.ldb) & 1) == 0 &&
+                        ((P.sA | P.sB | P.lda | P.ldb) & 3) == 0 && (((uintptr_t)P.A | (uintptr_t)P.B) & 31) == 0;
+  if (interior) {
+    if (P.transA) {
+      if (P.transB) gg_interior<true, true>(P, m0, n0, b0, ks_lo, ksteps, nsteps, As, Bs, tid, g, c, wr, wc, acc);
+      else gg_interior<true, false>(P, m0, n0, b0, ks_lo, ksteps, nsteps, As, Bs, tid, g, c, wr, wc, acc);
+    } else {
+      if (P.transB) gg_interior<false, true>(P, m0, n0, b0, ks_lo, ksteps, nsteps, As, Bs, tid, g, c, wr, wc, acc);
+      else gg_interior<false, false>(P, m0, n0, b0, ks_lo, ksteps, nsteps, As, Bs, tid, g, c, wr, wc, acc);
+    }
+  } else {
   if (nsteps > 0) gload(0);
   for (int step = 0; step < nsteps; ++step) {
     lstore();
@@ -106,7 +164,22 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
     }
     __syncthreads();
   }
+  }
   gptr C = (gptr)(P.C + (P.batch_reduce ? 0 : (int64_t)b0 * P.sC));
+  // beta C: all sixteen values requested together (clamped addresses), not one round trip per element behind its own branch
+  double cold[2][2][4];
+  if (P.beta != 0.0) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wr * 32 + ib * 16 + g + 4 * r, P.m - 1);
+          const int col = min(n0 + wc * 32 + jb * 16 + c, P.n - 1);
+          cold[ib][jb][r] = C[(int64_t)row * P.ldc + col];
+        }
+  }
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -117,7 +190,7 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
         const int col = n0 + wc * 32 + jb * 16 + c;
         if (row < P.m && col < P.n) {
           double v = P.alpha * acc[ib][jb][r];
-          if (P.beta != 0.0) v += P.beta * C[(int64_t)row * P.ldc + col];
+          if (P.beta != 0.0) v += P.beta * cold[ib][jb][r];
           C[(int64_t)row * P.ldc + col] = v;
           if ((P.tri & 16) && n0 < m0) C[(int64_t)col * P.ldc + row] = v;     // mirror of a symmetric result
         }
