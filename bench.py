@@ -198,10 +198,17 @@ def sub_rooflines(ctx):
                                           0.0, C.c_void_p(o.data_ptr()), R))
         for _ in range(3):
             call()
-        ctx.prof_read("gram")
+        # 20 launches back to back between ONE pair of events on the launch stream (the ctx stream is torch's current stream): the
+        # sustained rate of the kernel, launch boundaries included; an event pair around every launch adds its own ~3 us to a ~85 us kernel
+        import torch
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
         for _ in range(20):
             call()
-        ms, cnt = ctx.prof_read("gram")
+        g1.record()
+        torch.cuda.synchronize()
+        ms, cnt = g0.elapsed_time(g1), 20
+        ctx.prof_read("gram")
         nbytes = 8 * M * R + 8 * D * (M + R)
         gbs = nbytes / (ms / cnt * 1e-3) / 1e9
         out["gram"].append(dict(n=M, n2=R, D=D, us_per_launch=round(1e3 * ms / cnt, 2), algorithmic_MB=round(nbytes / 1e6, 1),
