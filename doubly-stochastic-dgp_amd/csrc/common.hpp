@@ -141,6 +141,20 @@ typedef const double __attribute__((address_space(1)))* gcptr;
 typedef double __attribute__((address_space(1)))* gptr;
 typedef double __attribute__((address_space(3)))* lptr;
 
+// Index of the segment a workgroup belongs to in a launch built from a device-resident list (jobs / problems with ascending start
+// offsets): bisection, log2(n) dependent (scalar) loads.  The linear walk every grouped kernel started with costs one dependent L2 round
+// trip per list entry — up to ~35 of them (the split-K reduction of a three-layer model) in front of a 20 us launch's last workgroups.
+#define DS_FIND_SEGMENT(idx, list, n, field, key)            \
+  do {                                                       \
+    int lo__ = 0, hi__ = (n)-1;                              \
+    while (lo__ < hi__) {                                    \
+      const int mid__ = (lo__ + hi__ + 1) >> 1;              \
+      if ((key) >= (list)[mid__].field) lo__ = mid__;        \
+      else hi__ = mid__ - 1;                                 \
+    }                                                        \
+    idx = lo__;                                              \
+  } while (0)
+
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), wave64.
 //   lane l: g = l>>4, c = l&15.   A operand = A[i=c][k=g];  B operand = B[k=g][j=c];
 //   D reg t (0..3) = D[row = g + 4t][col = c].

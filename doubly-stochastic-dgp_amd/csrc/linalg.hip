@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_gemm_grouped(const GemmProblem* __restr
     p = probs[0].order[2 * bid];
     t = probs[0].order[2 * bid + 1];
   } else {
-    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    DS_FIND_SEGMENT(p, probs, nprob, tile_start, bid);
     t = bid - probs[p].tile_start;
   }
   const GemmProblem P = probs[p];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmProblem* __restrict_
     p = probs[0].order[2 * bid];
     t = probs[0].order[2 * bid + 1];
   } else {
-    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    DS_FIND_SEGMENT(p, probs, nprob, tile_start, bid);
     t = bid - probs[p].tile_start;
   }
   const GemmProblem P = probs[p];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_gemm_small(const GemmProblem* __restric
     p = probs[0].order[2 * bid];
     t = probs[0].order[2 * bid + 1];
   } else {
-    while (p + 1 < nprob && bid >= probs[p + 1].tile_start) ++p;
+    DS_FIND_SEGMENT(p, probs, nprob, tile_start, bid);
     t = bid - probs[p].tile_start;
   }
   const GemmProblem P = probs[p];

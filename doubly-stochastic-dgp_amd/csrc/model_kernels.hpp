@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
   __shared__ double sh[4];
   const int bx = (int)blockIdx.x + blk0;
   int jb = 0;
-  while (jb + 1 < njobs && bx >= jobs[jb + 1].blk_start) ++jb;
+  DS_FIND_SEGMENT(jb, jobs, njobs, blk_start, bx);
   const RedJob J = jobs[jb];
   if (J.wide) {
     const int64_t i = bx - J.blk_start;     // one workgroup per output element

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
   const int g = lane >> 4, c = lane & 15;
   const int w = blockIdx.x;
   int jb = 0;
-  while (jb + 1 < njobs && w >= jobs[jb + 1].task_start) ++jb;
+  DS_FIND_SEGMENT(jb, jobs, njobs, task_start, w);
   const WgradJob J = jobs[jb];
   int local = w - J.task_start;
   int split, tile_i, tile_j, ns_eff = nsplit;
