@@ -30,7 +30,7 @@ Environment recipe (the versions README.md:4 of the reference names; none of thi
     # DESIGN.md section 3 / README then say "pinned by reference-generated fixtures" instead of "parity unpinned"
 
 `--dry-run` walks the same comparison / writing code with the ORACLE standing in for the reference and a scratch output directory
-(tests/test_golden_generator.py runs it): it proves the plumbing, not parity.
+(not exercised by the test suite since round 5: this script cannot run in the build container): it proves the plumbing, not parity.
 """
 import argparse
 import os
