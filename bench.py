@@ -198,17 +198,10 @@ def sub_rooflines(ctx):
                                           0.0, C.c_void_p(o.data_ptr()), R))
         for _ in range(3):
             call()
-        # 20 launches back to back between ONE pair of events on the launch stream (the ctx stream is torch's current stream): the
-        # sustained rate of the kernel, launch boundaries included; an event pair around every launch adds its own ~3 us to a ~85 us kernel
-        import torch
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        g0.record()
+        ctx.prof_read("gram")
         for _ in range(20):
             call()
-        g1.record()
-        torch.cuda.synchronize()
-        ms, cnt = g0.elapsed_time(g1), 20
-        ctx.prof_read("gram")
+        ms, cnt = ctx.prof_read("gram")        # HIP events around every launch on the launch stream (ProfScope), mean of 20
         nbytes = 8 * M * R + 8 * D * (M + R)
         gbs = nbytes / (ms / cnt * 1e-3) / 1e9
         out["gram"].append(dict(n=M, n2=R, D=D, us_per_launch=round(1e3 * ms / cnt, 2), algorithmic_MB=round(nbytes / 1e6, 1),

@@ -521,7 +521,8 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
     // One tile per workgroup, 16-byte loads along rows, the tile parked in LDS (odd stride), both stores along rows.  The 16 x 16 form
     // below moved 2 KB per workgroup with three of its four waves adding zeros: 226 us per step at config 4 (1.3 TB/s).
     // Same sums as that form (p0, or p0 + p1): bit-identical.
-    __shared__ double t64[64][65];
+    extern __shared__ __attribute__((aligned(16))) double red_dyn[];      // 64 x 65 doubles, only launches whose plan has such jobs carry it
+    double (*t64)[65] = reinterpret_cast<double (*)[65]>(red_dyn);
     typedef double d2 __attribute__((ext_vector_type(2)));
     int t = bx - J.blk_start, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;

@@ -365,6 +365,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     DS_HIP(hipStreamSynchronize(ctx->stream));
   }
   int blocks = 0;
+  bool any64 = false;
   for (auto& r : red) {
     r.ways = (!r.wide && r.nsplit >= 12) ? 4 : 0;
     const bool even = r.count % 2 == 0 && r.pstride % 2 == 0 && r.in_ld % 2 == 0 && r.out_ld % 2 == 0 && r.sym_tile % 2 == 0 &&
@@ -375,7 +376,10 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     if (tiled) r.ways = 16;
     // one or two splits of a symmetric result on whole 64-tiles: the copy-and-mirror form (one 64 x 64 tile per workgroup)
     const bool tiled64 = tiled && r.nsplit <= 2 && rows % 64 == 0 && r.sym_n % 64 == 0 && ((uintptr_t)r.out & 15) == 0;
-    if (tiled64) r.ways = 64;
+    if (tiled64) {
+      r.ways = 64;
+      any64 = true;
+    }
     r.blk_start = blocks;
     blocks += r.wide ? (int)r.count
                      : (tiled64 ? (int)((rows / 64) * (rows / 64 + 1) / 2)
@@ -395,6 +399,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
   DS_HIP(hipStreamSynchronize(ctx->stream));
   m->n_red = (int)red.size();
   m->red_blocks = blocks;
+  m->red_lds = any64 ? 64 * 65 * sizeof(double) : 0;      // dynamic LDS of k_reduce_grouped: the 64 x 64 copy-and-mirror tile
   m->plan_n = n;
   m->plan_S = S;
   return DSDGP_OK;
@@ -431,7 +436,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool pipelined = bucketed || (overlap && m->force.pipe_tail != 0 && !m->desc.white);
   // split-K reduction + P_d T_d / GS_d products of one layer right behind its weight-gradient products (pipelined tail)
   auto layer_tail = [&](LayerState& St, hipStream_t st) -> int {
-    DS_LAUNCH(k_reduce_grouped, dim3(St.red_blkn), dim3(256), 0, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
+    DS_LAUNCH(k_reduce_grouped, dim3(St.red_blkn), dim3(256), m->red_lds, st, m->rjobs + St.red_off, St.red_n, St.red_blk0);
     DS_HIP(hipGetLastError());
     DS_TRY(gemm_launch(ctx, St.lq + St.lq_nf + St.lq_n1 + St.lq_n2, St.lq_np, St.lq_tp, st));
     if (bucketed) {
@@ -538,7 +543,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const bool red_ahead = overlap && !pipelined && gfirst == 0 && L > 1 && m->force.red_ahead != 0;
   if (red_ahead) {
     LayerState& S0 = m->L[0];
-    DS_LAUNCH(k_reduce_grouped, dim3(S0.red_blkn), dim3(256), 0, ctx->stream, m->rjobs + S0.red_off, S0.red_n, S0.red_blk0);
+    DS_LAUNCH(k_reduce_grouped, dim3(S0.red_blkn), dim3(256), m->red_lds, ctx->stream, m->rjobs + S0.red_off, S0.red_n, S0.red_blk0);
     DS_HIP(hipGetLastError());
   }
   if (overlap) {
@@ -553,12 +558,12 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   if (!pipelined) {
     if (red_ahead) {
       LayerState& S1 = m->L[1];
-      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + S1.red_off,
+      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - S1.red_blk0), dim3(256), m->red_lds, ctx->stream, m->rjobs + S1.red_off,
                          m->n_red - S1.red_off, S1.red_blk0);
     } else {
       // (the partial sums of the layers below a pruned pass are stale: their jobs — ordered by layer — are left out)
       const LayerState& Sg = m->L[gfirst];
-      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - Sg.red_blk0), dim3(256), 0, ctx->stream, m->rjobs + Sg.red_off,
+      DS_LAUNCH(k_reduce_grouped, dim3(m->red_blocks - Sg.red_blk0), dim3(256), m->red_lds, ctx->stream, m->rjobs + Sg.red_off,
                          m->n_red - Sg.red_off, Sg.red_blk0);
     }
     DS_HIP(hipGetLastError());

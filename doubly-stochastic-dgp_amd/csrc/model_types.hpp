@@ -144,6 +144,7 @@ struct dsdgp_model {
   struct { int nblocks; double w, kl_weight; int with_grad; double* out; bool done; } fin;   // some layer does not fold its Ku-side hyper-parameter partials into k_asm_kbar
   RedJob* rjobs;       // device: split reductions of every layer, rebuilt when (n, S) changes
   int rjobs_cap, n_red, red_blocks;
+  size_t red_lds = 0;
   int64_t plan_n;
   int plan_S;
   bool prepared;

@@ -54,6 +54,9 @@ for c in 3 4 5; do
   [ -n "$DB" ] && python $R/tools/launch_table.py $DB pgemm kuf thin gl_ layer_ wgrad gemm_grouped chol > $P/r05_launch_shapes_cfg$c.md
   grep "^{" $O/run$c.log >> $P/r05_ab_kernels.txt
 done
+rm -rf /tmp/pg; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pg -o p -- python $R/tools/gram_time.py > $P/r05_gram_time.txt 2>&1)
+DB=$(find /tmp/pg -name "*results.db" | head -1)
+[ -n "$DB" ] && python $R/tools/launch_table.py $DB gram > $P/r05_gram_launches.md
 rm -rf /tmp/pp; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp -o p -- python $R/tools/potrf_prof.py 1024 > $O/potrf.log 2>&1)
 DB=$(find /tmp/pp -name "*results.db" | head -1)
 [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $P/r05_potrf_n1024_stats.md "round 5: dsdgp_potrf n = 1024, 6 calls, then torch.linalg.cholesky (rocSOLVER) of the same matrix once" > /dev/null
