@@ -15,12 +15,18 @@ int layer_bwd_sm_c(dsdgp_ctx*, const LayerBwdArgs&, int, int, int, int);
 // waves per 16-row block.  Launches with few row blocks (the N-row first layer: 63 blocks at N = 1000) are latency-bound —
 // one dependent MFMA chain per wave on a mostly idle chip — so they take twice the waves per block (half the chain each).
 #define SM_SMALL_BLOCKS 160
+#define SM_BWD_RESIDENT_8W 768
 static inline bool sm_small(int Mp, int64_t nblk, int D_in, bool bwd) {
   // measured (tools/ab_kernels.py): M = 256 — the 8-wave form (two row blocks per wave instead of four) wins at every size
-  // (-7 % on both chains); M = 128 — it wins for the backward chain at every size, for the forward chain only on small launches
-  // (the 4-wave forward instance has the early-mean specialisation)
+  // (-7 % on both chains); M = 128 — it wins for the backward chain while one round of it holds the launch (see below), for the
+  // forward chain only on small launches (the 4-wave forward instance has the early-mean specialisation)
   // Mp = 160 .. 224 follow the M = 256 rule (tools/bench_padding.py: with 4 waves M = 224 ran no faster than M = 256 with 8)
-  const int64_t lim = (Mp > 128 || bwd) ? ((int64_t)1 << 40) : SM_SMALL_BLOCKS;
+  // round 5, backward chain at M = 128: the 8-wave instance holds 77 VGPRs = three workgroups per CU = 768 resident row blocks; a
+  // launch with more runs in two rounds, the second one latency-bound on a third of the chip (config 2: 1250 blocks, 482 late
+  // starters, 139 us).  The 4-wave instance with the paired d-loop (96 VGPRs, five workgroups per CU) keeps 1280 blocks resident with
+  // the MFMA pipe saturated in the d-loop: 124 us.  (DSDGP_SM_BWD_LIM128: A/B aid.)
+  static const int64_t bwd_lim128 = getenv("DSDGP_SM_BWD_LIM128") ? atoll(getenv("DSDGP_SM_BWD_LIM128")) : SM_BWD_RESIDENT_8W;
+  const int64_t lim = Mp > 128 ? ((int64_t)1 << 40) : (bwd ? bwd_lim128 : SM_SMALL_BLOCKS);
   return Mp >= 128 && Mp <= 256 && nblk <= lim && D_in <= XCH;
 }
 // waves per row block of the instance that a launch of this shape takes

@@ -135,6 +135,8 @@ __device__ __forceinline__ void chain_range2(const double* __restrict__ WT, cons
       }
       // pin the interleave: two MFMAs, then the two loads that refill their weight registers, four times.  Without it the scheduler
       // sinks all eight loads to the end of the block (behind the eighth MFMA) and the next block starts by waiting for them.
+      // (A full scheduling barrier per step with the activation fragment requested one step ahead — the backward d-loop's form —
+      // measured slower here: +2 registers per chain, config 2 0.542 -> 0.551 ms per step.)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -150,6 +152,38 @@ __device__ __forceinline__ void chain_range2(const double* __restrict__ WT, cons
   }
   if constexpr (!UPPER) {
     acc1 = chain_range<Mp, false>(nullptr, WT, actb, ib1, ib0 + 1, ib1 + 1, g, c, acc1);
+  }
+}
+
+// Dense product for the two row blocks of a wave (k-blocks 0 .. MPB - 1 of both, compile-time trip count): the paired form of
+// chain_range2 without the triangular heads / tails.
+template <int Mp, int MPB>
+__device__ __forceinline__ void chain_dense2(const double* __restrict__ WT, const double* __restrict__ actb, int ib0, int ib1, int g, int c,
+                                             d4& acc0, d4& acc1) {
+  const unsigned off0 = (unsigned)(g * Mp + 16 * ib0 + c), off1 = (unsigned)(g * Mp + 16 * ib1 + c);
+  auto wld = [&](int kbx, int s, unsigned off) { return (WT + (size_t)(16 * kbx + 4 * s) * Mp)[off]; };
+  double a0[4], a1[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    a0[s] = wld(0, s, off0);
+    a1[s] = wld(0, s, off1);
+  }
+  double bv = actb[g * 16 + c];
+#pragma unroll
+  for (int kb = 0; kb < MPB; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kn = (s == 3) ? (kb + 1) % MPB : kb, sn = (s + 1) & 3;
+      const double bvn = actb[(16 * kn + 4 * sn + g) * 16 + c];
+      acc0 = mfma_f64(a0[s], bv, acc0);
+      acc1 = mfma_f64(a1[s], bv, acc1);
+      if (kb + 1 < MPB) {
+        a0[s] = wld(kb + 1, s, off0);
+        a1[s] = wld(kb + 1, s, off1);
+      }
+      bv = bvn;
+      if (kb + 1 < MPB) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -347,11 +381,35 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
   sqdist_finish<NQ>(zx, zsq, xx, scratch, wave, g, c, r2);
 }
 
+// debug aid of the phase-clock launches: launch span, dispatch delays and the workgroups' own durations, in shader clocks.  The s_memtime
+// bases differ between the XCDs; workgroup w of a launch runs on XCD w % 8, so everything is taken per XCD (slot 0 / slot `last_slot`).
+static inline void phase_span_report(const std::vector<unsigned long long>& h, int nwg, int last_slot) {
+  unsigned long long t0[8], t1[8];
+  for (int x = 0; x < 8; ++x) { t0[x] = ~0ull; t1[x] = 0; }
+  for (int w = 0; w < nwg; ++w) {
+    t0[w & 7] = std::min(t0[w & 7], h[(size_t)w * 8]);
+    t1[w & 7] = std::max(t1[w & 7], h[(size_t)w * 8 + last_slot]);
+  }
+  double span = 0;
+  for (int x = 0; x < 8 && x < nwg; ++x) span = std::max(span, (double)(t1[x] - t0[x]));
+  double dur = 0, start = 0, start_max = 0, dur_max = 0, late = 0;
+  int nlate = 0;
+  for (int w = 0; w < nwg; ++w) {
+    const double s = (double)(h[(size_t)w * 8] - t0[w & 7]), d = (double)(h[(size_t)w * 8 + last_slot] - h[(size_t)w * 8]);
+    dur += d; start += s;
+    start_max = std::max(start_max, s); dur_max = std::max(dur_max, d);
+    if (s > 0.25 * span) { ++nlate; late += d; }
+  }
+  fprintf(stderr, "[span] %d wgs, K clocks: launch %.1f | wg duration avg %.1f max %.1f | start avg %.1f max %.1f | %d late starters (avg duration %.1f)\n",
+          nwg, span * 1e-3, dur / nwg * 1e-3, dur_max * 1e-3, start / nwg * 1e-3, start_max * 1e-3, nlate, nlate ? late / nlate * 1e-3 : 0.0);
+}
 #define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-// LIK: the Gaussian variational expectations + adjoints in the epilogue (LayerFwdArgs::lik_Y) — its own instance: carried by every
-// instance the extra live values cost the 4-wave forward chain an occupancy step (85 -> 111 VGPRs, 5 -> 4 waves per SIMD: +30 us per step)
+// occupancy the forward instances are held to.  The 8-wave M = 256 instance sits at 120-126 VGPRs = two workgroups per CU; unrelated
+// edits (a debug stamp) moved it to 131 = ONE workgroup per CU (config 3: forward chains 16.3 -> 20.1 ms per 5 steps) — pinned at 128.
+template <int MPB, int NW, bool WIDE, bool LIK>
+constexpr int fwd_min_waves() { return (LIK && NW == 4) ? 5 : ((NW == 8 && MPB == 16 && !WIDE && !LIK) ? 4 : 1); }
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool LIK>
-__global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
+__global__ __launch_bounds__(NW * 64, (fwd_min_waves<MPB, NW, WIDE, LIK>())) void k_layer_fwd_sm(const LayerFwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int Mp = MPB * 16, NQ = Own<MPB, NW>::NQ;
   constexpr bool D4 = (MPB > 16);
@@ -696,7 +754,7 @@ __global__ __launch_bounds__(NW * 64, (LIK && NW == 4) ? 5 : 1) void k_layer_fwd
 // occupancy the 8-wave instances are held to: 80 VGPRs = three workgroups per CU at Mp <= 128, 128 VGPRs = two at Mp <= 256 (the
 // allocator lands one to three registers above those steps otherwise, which halves the resident workgroups)
 template <int MPB, int NW, bool WIDE, bool CS>
-constexpr int bwd_min_waves() { return (NW == 8 && !WIDE && !CS) ? (MPB <= 8 ? 6 : 4) : 1; }
+constexpr int bwd_min_waves() { return (NW == 8 && !WIDE && !CS) ? (MPB <= 8 ? 6 : 4) : ((NW == 4 && MPB == 8 && !WIDE && !CS) ? 5 : 1); }
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
 __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void k_layer_bwd_sm(const LayerBwdArgs a, const SmLds L) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -768,9 +826,16 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
     const int ib = Own<MPB, NW>::ib(wave, q);
     acc[q] = av[q] = (d4){0, 0, 0, 0};
     if (Own<MPB, NW>::skip(ib)) continue;
+    // unconditional (clamped) loads, masked afterwards: behind `act && rin` every load sat in its own exec branch with an
+    // s_waitcnt vmcnt(0) in front of the next one — eight serialised round trips at the head of every workgroup
+    const bool live = act && rin;
+    const double* __restrict__ ap = a.Asave + (int64_t)(16 * (act ? ib : 0) + g) * a.ldA + (rin ? r : 0);
+    double ld[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ld[t] = ap[(int64_t)(4 * t) * a.ldA];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double v = (act && rin) ? a.Asave[(int64_t)(16 * ib + g + 4 * t) * a.ldA + r] : 0.0;
+      const double v = live ? ld[t] : 0.0;
       av[q][t] = v;
       if (!CS && act) actb[out_slot<D4>(ib, g, t) * 16 + c] = v;
     }
@@ -786,8 +851,10 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
     }
   }
   // the first two k-steps of the mean part's upstream adjoints, for the same reason
-  const double bv0 = (act && rin) ? a.MB[(int64_t)g * a.ldA + r] : 0.0;
-  const double bv1 = (act && rin && a.DP4 > 4) ? a.MB[(int64_t)(4 + g) * a.ldA + r] : 0.0;
+  const double bv0l = a.MB[(int64_t)g * a.ldA + (rin ? r : 0)];
+  const double bv1l = a.MB[(int64_t)(a.DP4 > 4 ? 4 + g : g) * a.ldA + (rin ? r : 0)];
+  const double bv0 = (act && rin) ? bv0l : 0.0;
+  const double bv1 = (act && rin && a.DP4 > 4) ? bv1l : 0.0;
   double gsum = 0.0;
   // d-split (LayerBwdArgs::d_split): this workgroup's outputs of the d-loop, and the hand-over of the partial tiles
   const int n_split = (int)gridDim.y;
@@ -934,6 +1001,62 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
     }
   } else {
   __syncthreads();
+  // NQ = 2 without the interleaved form (Mp = 128 on four waves): the two row-block chains of the wave run side by side on one
+  // activation fragment per k-step, ONE weight register set refilled in place right behind the MFMAs that consumed it, the refill
+  // crossing from the last k-block of output d into the first of d + 1 (the S_d are contiguous: k-block t = d MPB + kb of one tall
+  // matrix).  The interleave is pinned (chain_range2 has the story); 96 VGPRs = five workgroups per CU.
+  constexpr bool PAIRD = (NQ == 2) && !D4 && (MPB % NW == 0);
+  if constexpr (PAIRD) {
+    const int ib0 = Own<MPB, NW>::ib(wave, 0), ib1 = Own<MPB, NW>::ib(wave, 1);
+    const unsigned off0 = (unsigned)(g * Mp + 16 * ib0 + c), off1 = (unsigned)(g * Mp + 16 * ib1 + c);
+    const int t_last = d_hi * MPB - 1;
+    auto wld = [&](int t, int s, unsigned off) { return (a.Sd + (size_t)(16 * t + 4 * s) * Mp)[off]; };
+    double w0[4], w1[4];
+    if (d_lo < d_hi) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        w0[s] = wld(d_lo * MPB, s, off0);
+        w1[s] = wld(d_lo * MPB, s, off1);
+      }
+    }
+    // vbar_d of the NEXT output is requested inside the k loop of this one, unconditionally (clamped): at the top of the loop it sat
+    // behind an exec branch and its first use drained the whole load queue (s_waitcnt vmcnt(0)) once per output
+    const int64_t rc = rin ? r : 0;
+    const double vmask = rin ? 1.0 : 0.0;
+    double vd_next = d_lo < d_hi ? a.VB[(int64_t)d_lo * a.ldA + rc] : 0.0;
+    for (int d = d_lo; d < d_hi; ++d) {
+      const double vd = vmask * vd_next;
+      gsum += vd;
+      const double vd2 = 2.0 * vd;
+      d4 y0 = (d4){0, 0, 0, 0}, y1 = (d4){0, 0, 0, 0};
+      double bv = actb[g * 16 + c];
+#pragma unroll
+      for (int kb = 0; kb < MPB; ++kb) {
+        int tn = d * MPB + kb + 1;              // (the last refill of the launch re-reads its own block)
+        if (kb == MPB - 1 && tn > t_last) tn = t_last;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          // one step = the activation fragment of the NEXT step requested, two MFMAs, their two weight registers refilled; a full
+          // scheduling barrier behind every step: with group barriers alone the scheduler still chose WHICH loads go into a group,
+          // and on the 8-wave M = 256 instance it picked the ones needed next (queue depth 1-2 instead of 8)
+          const int kn = (s == 3) ? (kb + 1) % MPB : kb, sn = (s + 1) & 3;
+          const double bvn = actb[(16 * kn + 4 * sn + g) * 16 + c];
+          y0 = mfma_f64(w0[s], bv, y0);
+          y1 = mfma_f64(w1[s], bv, y1);
+          w0[s] = wld(tn, s, off0);
+          w1[s] = wld(tn, s, off1);
+          bv = bvn;
+          if (kb == 1 && s == 0) vd_next = a.VB[(int64_t)(d + 1 < d_hi ? d + 1 : d) * a.ldA + rc];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0][t] = fma(vd2, y0[t], acc[0][t]);
+        acc[1][t] = fma(vd2, y1[t], acc[1][t]);
+      }
+    }
+  } else
   for (int d = d_lo; d < d_hi; ++d) {
     const double vd = rin ? a.VB[(int64_t)d * a.ldA + r] : 0.0;
     gsum += vd;
@@ -1014,6 +1137,15 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
   d4 bb[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) bb[q] = (d4){0, 0, 0, 0};
+  constexpr bool PAIRK = (NQ == 2) && !D4 && !CS && (MPB % NW == 0);     // (the d-loop's paired form, see there)
+  if constexpr (PAIRK) {
+    if constexpr (WHITE) {
+      const int wu = DS_WAVE_ID(tid);                                       // run-time k ranges: wave-uniform bounds
+      chain_range2<Mp, true>(a.Linv, actb, Own<MPB, NW>::ib(wu, 0), Own<MPB, NW>::ib(wu, 1), MPB, g, c, bb[0], bb[1]);
+    } else {
+      chain_dense2<Mp, MPB>(a.Kinv, actb, Own<MPB, NW>::ib(wave, 0), Own<MPB, NW>::ib(wave, 1), g, c, bb[0], bb[1]);
+    }
+  } else
   if (act) {
     if (WHITE || !ILV) {
 #pragma unroll
@@ -1235,6 +1367,7 @@ static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     double ph[6] = {0, 0, 0, 0, 0, 0};
     for (int w = 0; w < nrow; ++w)
       for (int i = 0; i < 6; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
+    phase_span_report(h, nrow, 6);
     fprintf(stderr, "[fwd phases] Mp=%d NW=%d D_out=%d wgs=%dx%d  clocks/wg: Kuf tile %.0f | a1 %.0f | a %.0f | mean partials %.0f | per-output + epilogue %.0f | "
             "Asave %.0f | sum %.0f\n", MPB * 16, NW, a.D_out, nrow, ds, ph[0] / nrow, ph[1] / nrow, ph[2] / nrow, ph[3] / nrow, ph[4] / nrow,
             ph[5] / nrow, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / nrow);
@@ -1263,16 +1396,14 @@ static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds&
   DS_HIP(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   hipFree(clk);
   double ph[7] = {0, 0, 0, 0, 0, 0, 0};
-  unsigned long long first = ~0ull, last = 0;
   for (int w = 0; w < nwg; ++w) {
     for (int i = 0; i < 7; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
-    first = std::min(first, h[(size_t)w * 8]);
-    last = std::max(last, h[(size_t)w * 8 + 7]);
   }
+  phase_span_report(h, nwg, 7);
   fprintf(stderr, "[bwd phases] Mp=%d NW=%d D_out=%d wgs=%d  clocks/wg: A-tile %.0f | d-loop %.0f | mean+abar %.0f | Kinv %.0f | x-stage %.0f | "
-          "kernel+E/GW %.0f | hyp+dX %.0f | sum %.0f   launch span %.0f\n", MPB * 16, NW, a.D_out, nwg, ph[0] / nwg, ph[1] / nwg,
+          "kernel+E/GW %.0f | hyp+dX %.0f | sum %.0f\n", MPB * 16, NW, a.D_out, nwg, ph[0] / nwg, ph[1] / nwg,
           ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg, ph[6] / nwg,
-          (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) / nwg, (double)(last - first));
+          (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) / nwg);
   return DSDGP_OK;
 }
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>

@@ -205,3 +205,24 @@ def test_largest_inducing_count_mp_2048():
     for k in g:
         assert np.max(np.abs(-g[k] - grads[k])) <= 1e-6 * (np.max(np.abs(g[k])) + 1e-12), k
     assert np.isfinite(model.train_step(0.01, X=X, Y=Y, zs=zs, sync=True))
+
+
+# ---------------------------------------------------------------- backward chain at M = 128 on more row blocks than one round of the
+# 8-wave instance holds (> 768): the 4-wave instance with the paired d-loop (layer_sm.hip: SM_BWD_RESIDENT_8W)
+@pytest.mark.parametrize("white", [False, True])
+def test_backward_chain_m128_beyond_one_resident_round(white):
+    """(S n)/16 = 782 row blocks for the inner layers: dl/d(everything) against the oracle's reverse pass (layers.py:71-114 through
+    dgp.py:139-147), RBF and Matern52 layers, D_out = 5 / 5 / 2."""
+    rng = np.random.RandomState(53 + int(white))
+    N, D, M, S = 1250, 5, 128, 10
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = X[:M] + 0.05 * rng.randn(M, D)
+    specs = [kern_spec("rbf", D, 1.1, 0.9), kern_spec("matern52", D, 0.8, 1.2), kern_spec("rbf", D, 0.9, 1.0)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=4 * N, white=white)
+    zs = [rng.randn(S, N, D), rng.randn(S, N, D), rng.randn(S, N, 2)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=4 * N)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:                                     # EVERY parameter block of every layer
+        assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-7 * (np.max(np.abs(g[k])) + 1e-12), k

@@ -1,9 +1,12 @@
 #!/bin/bash
-# kernel timeline of the headline step: busy/idle per step, largest gaps, per-kernel time (profiles/*_timeline_gaps.txt)
-mkdir -p gpurun_out
+# one training step's kernel timeline of config 2 in the production (overlapped) schedule: gpurun_out/timeline/{step,gaps}.txt
+cd "$GRAFT_REPO_ROOT" || exit 1
 R=$PWD
-rm -rf $R/gpurun_out/prof_gap
-cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_gap -o bench -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_gap.json 2> $R/gpurun_out/prof_gap.err
-cd $R
-python tools/gap_analysis.py $(find gpurun_out/prof_gap -name "*.db" | head -1) k_adam | tee gpurun_out/gap.txt | head -60
+O=$R/gpurun_out/timeline; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tl -o t -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $O/prod.json 2> $O/prod.err
+DB=$(find /tmp/tl -name "*.db" | head -1)
+python $R/tools/gap_analysis.py $DB k_tail > $O/gaps.txt
+python $R/tools/timeline_dump.py $DB k_tail 3 > $O/step.txt
+cat $O/step.txt
