@@ -466,6 +466,12 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     if (q_only && &Sx == &m->L[gfirst]) return wgrad_launch(ctx, Sx.wj, Sx.njobsA, Sx.totA, Sx.ns_big, ldx, ldx, st);
     return wgrad_launch(ctx, Sx.wj, Sx.njobs, Sx.tot_big, Sx.ns_big, ldx, ldx, st);
   };
+  // Deep models (round 5): only the products of layer gfirst + 1 go to the side stream (they run under the lowest chain, the one launch
+  // with too few row blocks to fill the chip); those of the layers above follow the lowest layer's products on the main stream — no
+  // event record / wait pair per layer (6 + 12 us) and no products squeezed in beside a chain that saturates the MFMA pipe anyway.
+  // 5-layer config 3: 7.60 -> 7.37 ms per step; the 3-layer configs (one deferred launch) are within +-1 %, so the rule starts at
+  // four layers in the pass.  (DSDGP_FORCE wg_defer = 0 / 2: off / on at any depth.)
+  const bool defer_upper = overlap && !pipelined && (m->force.wg_defer == 2 || (m->force.wg_defer < 0 && L - gfirst >= 4));
   for (int l = L - 1; l >= gfirst; --l) {
     LayerState& St = m->L[l];
     const LayerDev& v = St.dev;
@@ -525,9 +531,12 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, ctx->stream));
+      if (defer_upper)
+        for (int lu = gfirst + 2; lu < L; ++lu) DS_TRY(launch_wgrad(m->L[lu], ctx->stream));
       if (pipelined) DS_TRY(layer_tail(St, ctx->stream));
       continue;
     }
+    if (defer_upper && l >= gfirst + 2) continue;
     // ONE event per chain boundary (an event record costs the recording stream ~6 us): behind it the side stream takes this layer's
     // products, which then run under the NEXT layer's backward chain.  Measured slower and removed in round 3: the products of a layer
     // ahead of its own chain's end (they need only the upstream adjoints), completion events attached to the chain / product launches

@@ -161,7 +161,7 @@ struct dsdgp_model {
   // ext_ev = 0: plain event record behind the head launch; red_ahead = 0: one split-K reduction after the stream join;
   // white_fwd = 0: forward-only evaluations in plain coordinates.  gemm_mp: smallest padded inducing count whose layers take the
   // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -180,6 +180,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "cs_min_blocks") m->force.cs_min_blocks = v;
       else if (k == "cs_min_dout") m->force.cs_min_dout = v;
       else if (k == "cs_max_dout") m->force.cs_max_dout = v;
+      else if (k == "wg_defer") m->force.wg_defer = v;
       else if (k == "alg_g") m->force.alg_g = v;
       else if (k == "bwd_split") m->force.bwd_split = v;
       else if (k == "red_ahead") m->force.red_ahead = v;

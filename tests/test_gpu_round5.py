@@ -226,3 +226,36 @@ def test_backward_chain_m128_beyond_one_resident_round(white):
     grads = model.engine().gradient_dict()
     for k in g:                                     # EVERY parameter block of every layer
         assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-7 * (np.max(np.abs(g[k])) + 1e-12), k
+
+
+# ---------------------------------------------------------------- reverse pass of a deep model: the upper layers' weight-gradient
+# products follow the lowest layer's on the main stream (model_schedule.hpp: defer_upper, from four layers in the pass)
+@pytest.mark.parametrize("force", ["wg_defer=0", "wg_defer=2", ""])
+def test_five_layer_reverse_pass_in_both_product_schedules(monkeypatch, force):
+    """n S Mp = 512 x 8 x 256 = 2^20: the stream-overlapped schedule is on.  Five layers (dgp.py:139-147 looped over the layers), every
+    gradient block against the oracle's reverse pass with the products of layers 2 .. 4 launched the old way (side stream, behind an
+    event at the end of each layer's chain), deferred, and by the default rule (deferred: five layers >= four)."""
+    if force:
+        monkeypatch.setenv("DSDGP_FORCE", force)
+    else:
+        monkeypatch.delenv("DSDGP_FORCE", raising=False)
+    rng = np.random.RandomState(61)
+    N, D, M, S, L = 512, 4, 256, 8, 5
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = X[rng.permutation(N)[:M]] + 0.05 * rng.randn(M, D)
+    kinds = ["rbf", "matern52", "rbf", "rbf", "matern52"]
+    specs = [kern_spec(k, D, 0.9 + 0.1 * i, 1.0 + 0.05 * i) for i, k in enumerate(kinds)]
+    spec, state, model = make_case(X, Y, Z, specs, S=S, num_data=3 * N)
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 1)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=3 * N)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-7 * (np.max(np.abs(g[k])) + 1e-12), k
+    # a second evaluation (the plan and every buffer reused) returns the same bits
+    got2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    grads2 = model.engine().gradient_dict()
+    assert got2 == got
+    for k in g:
+        assert np.array_equal(np.asarray(grads[k]), np.asarray(grads2[k])), k
