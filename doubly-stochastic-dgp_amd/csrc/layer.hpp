@@ -33,7 +33,7 @@ struct LayerFwdArgs {
   int64_t ldA;
   int32_t d_split;      // split-M kernels: gridDim.y workgroups share a row block, each taking D_out/d_split outputs
   double* XT1;          // split-M kernels, training: (DinP16 x ldA) [X^T ; 1] for the Z-gradient product, or NULL
-  unsigned long long* phase_clk;   // debug aid (DSDGP_FWD_TIMING): [workgroup][8] shader-clock stamps of the forward chain's phases, or NULL
+  unsigned long long* phase_clk;   // debug aid (DSDGP_FWD_TIMING): [workgroup][8] s_memrealtime (100 MHz) stamps of the forward chain's phases, or NULL
   // last layer of a training step with the Gaussian likelihood: [UPSTREAM] Gaussian.variational_expectations (dgp.py:89-90) and its
   // adjoints in this chain's epilogue (k_lik_gauss's job: one launch less between the forward and the reverse pass).  lik_Y NULL: off.
   const double* lik_Y;             // (n_inner x D_out) targets
@@ -79,7 +79,7 @@ struct LayerBwdArgs {
   const double* varp;   // the previous layer's variances (Rin x Dp)
   int32_t Dp, prop;     // previous layer's D_out, input_prop_dim
   double jitter;
-  unsigned long long* phase_clk;   // debug aid (DSDGP_BWD_TIMING): [workgroup][8] shader-clock stamps of the backward chain's phases, or NULL
+  unsigned long long* phase_clk;   // debug aid (DSDGP_BWD_TIMING): [workgroup][8] s_memrealtime (100 MHz) stamps of the backward chain's phases, or NULL
   // split-M kernels, small launches: gridDim.y = d_split workgroups share a row block, each takes D_out / d_split outputs of the d-loop
   // and leaves its partial abar tile (+ its share of sum_d vbar_d) in `part` ([row block][d_split][Mp * 16 + 16]); the workgroup that
   // arrives last (ticket from part_cnt[row block], reset by it) adds the partials in split order — a fixed order, whoever is

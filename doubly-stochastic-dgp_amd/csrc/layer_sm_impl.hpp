@@ -381,29 +381,29 @@ __device__ __forceinline__ void sm_sqdist(const double* __restrict__ zs, const d
   sqdist_finish<NQ>(zx, zsq, xx, scratch, wave, g, c, r2);
 }
 
-// debug aid of the phase-clock launches: launch span, dispatch delays and the workgroups' own durations, in shader clocks.  The s_memtime
-// bases differ between the XCDs; workgroup w of a launch runs on XCD w % 8, so everything is taken per XCD (slot 0 / slot `last_slot`).
+// debug aid of the phase-clock launches.  The stamps are s_memrealtime (constant 100 MHz, one time base for the whole chip): s_memtime
+// counts shader clocks but its base differs from CU to CU (tools/xcd_probe.hip: spreads of 5e7 clocks inside one XCD), so starts and
+// ends of different workgroups could not be compared.  Reports the launch span, every workgroup's start delay and own duration, and
+// the workgroups that start late (after a quarter of the span: a second round).
 static inline void phase_span_report(const std::vector<unsigned long long>& h, int nwg, int last_slot) {
-  unsigned long long t0[8], t1[8];
-  for (int x = 0; x < 8; ++x) { t0[x] = ~0ull; t1[x] = 0; }
+  unsigned long long t0 = ~0ull, t1 = 0;
   for (int w = 0; w < nwg; ++w) {
-    t0[w & 7] = std::min(t0[w & 7], h[(size_t)w * 8]);
-    t1[w & 7] = std::max(t1[w & 7], h[(size_t)w * 8 + last_slot]);
+    t0 = std::min(t0, h[(size_t)w * 8]);
+    t1 = std::max(t1, h[(size_t)w * 8 + last_slot]);
   }
-  double span = 0;
-  for (int x = 0; x < 8 && x < nwg; ++x) span = std::max(span, (double)(t1[x] - t0[x]));
+  const double span = (double)(t1 - t0) * 0.01;
   double dur = 0, start = 0, start_max = 0, dur_max = 0, late = 0;
   int nlate = 0;
   for (int w = 0; w < nwg; ++w) {
-    const double s = (double)(h[(size_t)w * 8] - t0[w & 7]), d = (double)(h[(size_t)w * 8 + last_slot] - h[(size_t)w * 8]);
+    const double s = (double)(h[(size_t)w * 8] - t0) * 0.01, d = (double)(h[(size_t)w * 8 + last_slot] - h[(size_t)w * 8]) * 0.01;
     dur += d; start += s;
     start_max = std::max(start_max, s); dur_max = std::max(dur_max, d);
     if (s > 0.25 * span) { ++nlate; late += d; }
   }
-  fprintf(stderr, "[span] %d wgs, K clocks: launch %.1f | wg duration avg %.1f max %.1f | start avg %.1f max %.1f | %d late starters (avg duration %.1f)\n",
-          nwg, span * 1e-3, dur / nwg * 1e-3, dur_max * 1e-3, start / nwg * 1e-3, start_max * 1e-3, nlate, nlate ? late / nlate * 1e-3 : 0.0);
+  fprintf(stderr, "[span] %d wgs: launch %.1f us | wg duration avg %.1f max %.1f us | start avg %.1f max %.1f us | %d late starters (avg duration %.1f us)\n",
+          nwg, span, dur / nwg, dur_max, start / nwg, start_max, nlate, nlate ? late / nlate : 0.0);
 }
-#define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // occupancy the forward instances are held to.  The 8-wave M = 256 instance sits at 120-126 VGPRs = two workgroups per CU; unrelated
 // edits (a debug stamp) moved it to 131 = ONE workgroup per CU (config 3: forward chains 16.3 -> 20.1 ms per 5 steps) — pinned at 128.
 template <int MPB, int NW, bool WIDE, bool LIK>
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves<MPB, NW, WIDE, LIK>())) voi
 // backward (math: see layer.hip).  hyp_part gets one partial row per WAVE: index (blockIdx.x * NW + wave).
 // ------------------------------------------------------------------------------------------------------
 // CS: abar's variance part from the saved c_d (triangular q_sqrt_d products, staged through LDS) instead of dense S_d a
-#define BWD_STAMP(i) do { if (a.phase_clk && tid == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BWD_STAMP(i) do { if (a.phase_clk && tid == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // occupancy the 8-wave instances are held to: 80 VGPRs = three workgroups per CU at Mp <= 128, 128 VGPRs = two at Mp <= 256 (the
 // allocator lands one to three registers above those steps otherwise, which halves the resident workgroups)
 template <int MPB, int NW, bool WIDE, bool CS>
@@ -1354,7 +1354,7 @@ static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   int ds = a.d_split > 0 ? a.d_split : 1;
   if (ds > a.D_out) ds = a.D_out;
   static const bool timing = getenv("DSDGP_FWD_TIMING") != nullptr;
-  if (timing) {      // debug aid, synchronous: per-phase shader clocks averaged over the workgroups of this launch
+  if (timing) {      // debug aid, synchronous: per-phase times (s_memrealtime, 100 MHz) averaged over the workgroups of this launch
     unsigned long long* clk = nullptr;
     DS_HIP(hipMalloc(&clk, (size_t)nrow * 8 * sizeof(unsigned long long)));
     LayerFwdArgs b = a;
@@ -1368,9 +1368,10 @@ static int fwd_sm_go2(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
     for (int w = 0; w < nrow; ++w)
       for (int i = 0; i < 6; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
     phase_span_report(h, nrow, 6);
-    fprintf(stderr, "[fwd phases] Mp=%d NW=%d D_out=%d wgs=%dx%d  clocks/wg: Kuf tile %.0f | a1 %.0f | a %.0f | mean partials %.0f | per-output + epilogue %.0f | "
-            "Asave %.0f | sum %.0f\n", MPB * 16, NW, a.D_out, nrow, ds, ph[0] / nrow, ph[1] / nrow, ph[2] / nrow, ph[3] / nrow, ph[4] / nrow,
-            ph[5] / nrow, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / nrow);
+    const double u = 0.01 / nrow;      // 100 MHz ticks -> us per workgroup
+    fprintf(stderr, "[fwd phases] Mp=%d NW=%d D_out=%d wgs=%dx%d  us/wg: Kuf tile %.2f | a1 %.2f | a %.2f | mean partials %.2f | per-output + epilogue %.2f | "
+            "Asave %.2f | sum %.2f\n", MPB * 16, NW, a.D_out, nrow, ds, ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, ph[4] * u,
+            ph[5] * u, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) * u);
     return DSDGP_OK;
   }
   DS_LAUNCH((k_layer_fwd_sm<MPB, NW, KIND, WHITE, WIDE, LIK>), dim3(nrow, ds), dim3(NW * 64), lds, ctx->stream, a, L);
@@ -1382,7 +1383,7 @@ static int fwd_sm_go(dsdgp_ctx* ctx, const LayerFwdArgs& a) {
   if (a.lik_Y) return fwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, true>(ctx, a);
   return fwd_sm_go2<MPB, NW, KIND, WHITE, WIDE, false>(ctx, a);
 }
-// DSDGP_BWD_TIMING=1 (debug aid, synchronous): per-phase shader clocks of every backward-chain launch, averaged over its workgroups
+// DSDGP_BWD_TIMING=1 (debug aid, synchronous): per-phase times (s_memrealtime, 100 MHz) of every backward-chain launch, averaged over its workgroups
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>
 static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds& L, size_t lds) {
   const int nwg = (int)ceil_div(a0.ldA, 16);
@@ -1400,10 +1401,10 @@ static int bwd_phase_timing(dsdgp_ctx* ctx, const LayerBwdArgs& a0, const SmLds&
     for (int i = 0; i < 7; ++i) ph[i] += (double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]);
   }
   phase_span_report(h, nwg, 7);
-  fprintf(stderr, "[bwd phases] Mp=%d NW=%d D_out=%d wgs=%d  clocks/wg: A-tile %.0f | d-loop %.0f | mean+abar %.0f | Kinv %.0f | x-stage %.0f | "
-          "kernel+E/GW %.0f | hyp+dX %.0f | sum %.0f\n", MPB * 16, NW, a.D_out, nwg, ph[0] / nwg, ph[1] / nwg,
-          ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg, ph[6] / nwg,
-          (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) / nwg);
+  const double u = 0.01 / nwg;      // 100 MHz ticks -> us per workgroup
+  fprintf(stderr, "[bwd phases] Mp=%d NW=%d D_out=%d wgs=%d  us/wg: A-tile %.2f | d-loop %.2f | mean+abar %.2f | Kinv %.2f | x-stage %.2f | "
+          "kernel+E/GW %.2f | hyp+dX %.2f | sum %.2f\n", MPB * 16, NW, a.D_out, nwg, ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, ph[4] * u, ph[5] * u,
+          ph[6] * u, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) * u);
   return DSDGP_OK;
 }
 template <int MPB, int NW, int KIND, bool WHITE, bool WIDE, bool CS>

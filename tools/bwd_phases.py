@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-phase shader clocks of the forward and backward chain launches of one config shape (DSDGP_FWD_TIMING=1 / DSDGP_BWD_TIMING=1: synchronous debug aids in
+"""Per-phase times (100 MHz s_memrealtime stamps; launch span and late starters per launch) of the forward and backward chain launches of one config shape (DSDGP_FWD_TIMING=1 / DSDGP_BWD_TIMING=1: synchronous debug aids in
 csrc/layer_sm_impl.hpp).  usage: python tools/bwd_phases.py 2 [3 ...]"""
 import os
 import sys
