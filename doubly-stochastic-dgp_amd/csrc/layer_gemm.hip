@@ -20,6 +20,8 @@
 //   dX / transposed adjoints of the layer below, hyp_part k_gl_bwd_rows
 // white = True (layers.py:186-188 without the second solve): a1 stands where a does (no Lu^-T product forward); backward
 //   a1bar = abar - 2 (sum_d vbar_d) a1 (k_gl_white_abar), kbar = Lu^-T a1bar (ONE triangular k_pgemm instead of the dense Ku^-1 abar), e = kbar
+#include <type_traits>
+
 #include "layer.hpp"
 #include <algorithm>
 
@@ -99,7 +101,12 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
   double bs_q = 1.0;   // multiplier of the column scales of the chunk in flight (1 on the tail product)
   // gload only ISSUES the loads of a step; everything that consumes the loaded values (triangle mask, scales) happens in lstore,
   // i.e. after the MFMAs of the step that runs meanwhile — a use inside gload would put the memory round trip in front of them
-  auto gload = [&](int step) {
+  // FAST (the whole tile inside the matrices, every k chunk full): the loads are unconditional.  With the guards, the loaded registers
+  // met the zero-filled alternative in a phi, the compiler resolved it with register COPIES of the loaded values — and a copy needs its
+  // source: an `s_waitcnt vmcnt(0)` sat between the loads of step s + 1 and the MFMAs of step s, every step (ISA: sixteen v_mov_b64
+  // behind the wait), i.e. the memory round trip the two-stage pipeline exists to hide was paid in full.
+  auto gload = [&](int step, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const bool tail = step >= nmain;
     const int bi = tail ? 0 : step / ksteps;
     const int b = P.reduce_batch ? bi : o;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
     bs_q = tail ? 1.0 : P.bs_mul;
     {
       gcptr src = (gcptr)((tail ? P.W2 : P.W + (int64_t)b * P.sW) + (int64_t)am * ldw + k0 + ak);
-      if (a_row && k0 + ak + 8 <= kdim) {
+      if (FAST || (a_row && k0 + ak + 8 <= kdim)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
@@ -124,9 +131,9 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
       }
     }
     {
-      const bool ok = b_col && k0 + bk < kdim;
+      const bool ok = FAST || (b_col && k0 + bk < kdim);
       gcptr src = (gcptr)((tail ? P.B2 : P.B + (int64_t)b * P.sB) + (int64_t)(k0 + bk) * P.ldb + bn);
-      if (ok) {
+      if (FAST || ok) {
 #pragma unroll
         for (int u = 0; u < NB / 2; ++u) {
           const d2 v = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(src + 2 * u);
@@ -171,14 +178,16 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
 #pragma unroll
     for (int u = 0; u < NB / 2; ++u) *reinterpret_cast<d2*>(brow + 2 * u) = (d2){rb[2 * u], rb[2 * u + 1]};
   };
+  const bool fast = m0 + PT <= P.m && n0 + TN <= P.n && P.k % PK == 0 && (!(P.reduce_batch && P.k2 > 0) || P.k2 % PK == 0);
+  auto run = [&](auto fast_tag) {
   if (s_hi > s_lo) {
-    gload(s_lo);
+    gload(s_lo, fast_tag);
     lstore(0);
   }
   __syncthreads();
   for (int step = s_lo; step < s_hi; ++step) {
     const int buf = (step - s_lo) & 1;
-    if (step + 1 < s_hi) gload(step + 1);
+    if (step + 1 < s_hi) gload(step + 1, fast_tag);
 #pragma unroll
     for (int k4 = 0; k4 < PK; k4 += 4) {
       double a[4], bq[NJ];
@@ -194,6 +203,9 @@ __global__ __launch_bounds__(256) void k_pgemm(const PGemm P) {
     if (step + 1 < s_hi) lstore(buf ^ 1);     // the other buffer: its last readers passed the previous barrier
     __syncthreads();
   }
+  };
+  if (fast) run(std::true_type{});
+  else run(std::false_type{});
   if (P.store) {
     gptr C = (gptr)(P.C + (int64_t)o * P.sC + (int64_t)gidx * P.sCg);
 #pragma unroll

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves<MPB, NW, WIDE, LIK>())) voi
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = 16 * ib + g + 4 * t;
-          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
+          const double kv = kern_val<KIND>(r2[q][t], s2);      // unconditional: behind `m < M` every exp sat in its own exec branch
+          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kv : 0.0;
         }
       }
     }
@@ -476,7 +477,8 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves<MPB, NW, WIDE, LIK>())) voi
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = 16 * ib + g + 4 * t;
-          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kern_val<KIND>(r2[q][t], s2) : 0.0;
+          const double kv = kern_val<KIND>(r2[q][t], s2);      // unconditional: behind `m < M` every exp sat in its own exec branch
+          actb[act_slot<D4>(m) * 16 + c] = (m < a.M) ? kv : 0.0;
         }
       }
     }
