@@ -45,6 +45,57 @@ __device__ __forceinline__ void wgrad_loop(gcptr Pp, gcptr Qp, gcptr scale, int6
 }
 
 
+// The same K loop with the operands refilled IN PLACE, half a chunk at a time (round 5).  A lane's 32-byte fragment is two 16-byte
+// halves: k-steps t = 0, 1 read the first, t = 2, 3 the second.  The loop above loads a whole chunk, waits, and runs its 64 MFMAs — with
+// two waves per SIMD (236 VGPRs) nothing but the other wave covers the round trip, and a second register set for prefetching does not
+// fit.  Here the first halves of chunk ch + 1 are requested right behind the MFMAs of t = 0, 1 of chunk ch (into the registers those
+// just read) and are due 32 MFMAs later, the second halves likewise: half a chunk of loads is always in flight under half a chunk of
+// MFMAs, with the register count of the plain loop.  Every phase is fenced with a full scheduling barrier (left to the scheduler the
+// refill form came out at 360 registers).  DIAG: no Q loads — the Q registers hold the scaled copies of P.  Non-GUARD tiles only.
+typedef double wd2 __attribute__((ext_vector_type(2)));
+template <int NI, int NJ, bool DIAG>
+__device__ __forceinline__ void wgrad_loop_rolling(gcptr Pp, gcptr Qp, gcptr scale, int64_t ld, int64_t c_lo, int64_t c_hi, int g,
+                                                   d4 (&acc)[NI][NJ]) {
+  if (c_lo >= c_hi) return;
+  typedef const wd2 __attribute__((address_space(1)))* h2ptr;
+  wd2 p[2][NI], q[2][NJ], sc[2];
+  auto request = [&](int64_t ch, int h) {
+    const int64_t rb = ch * 16 + 2 * h;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) p[h][ii] = *reinterpret_cast<h2ptr>(Pp + (int64_t)16 * ii * ld + rb);
+    if constexpr (!DIAG) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) q[h][jj] = *reinterpret_cast<h2ptr>(Qp + (int64_t)16 * jj * ld + rb);
+    }
+    if (scale) sc[h] = *reinterpret_cast<h2ptr>(scale + rb + 4 * g);
+  };
+  request(c_lo, 0);
+  request(c_lo, 1);
+  for (int64_t ch = c_lo; ch < c_hi; ++ch) {
+    const int64_t nx = ch + 1 < c_hi ? ch + 1 : ch;        // (the last chunk re-requests itself: unused)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (DIAG) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) q[h][jj] = scale ? p[h][jj] * sc[h] : p[h][jj];
+      } else if (scale) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) q[h][jj] *= sc[h];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+            if (!DIAG || jj <= ii) acc[ii][jj] = mfma_f64(p[h][ii][t], q[h][jj][t], acc[ii][jj]);
+      __builtin_amdgcn_sched_barrier(0);
+      request(nx, h);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // ONE WORKGROUP per (job, split, tile) task; its four waves take a quarter of the split's row range each and reduce their
 // accumulators through LDS in a fixed order ((w0 + w2) + (w1 + w3)) before wave 0 stores the partial: a quarter of the split-K
 // partials of a one-wave-per-task form at the same wave-level parallelism (fp64 MFMA needs >= 2 waves per SIMD for its pipe rate).
@@ -95,9 +146,9 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
   gcptr Qp = (gcptr)(J.Q + (int64_t)(16 * NJ * tile_j + c) * ld + 4 * g);
   const bool diag = J.sym && tile_i == tile_j && NI == NJ;
   if (diag)
-    wgrad_loop<NI, NJ, false, true>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop_rolling<NI, NJ, true>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, acc);
   else if (njv == NJ)
-    wgrad_loop<NI, NJ, false, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
+    wgrad_loop_rolling<NI, NJ, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, acc);
   else
     wgrad_loop<NI, NJ, true, false>(Pp, Qp, (gcptr)J.scale, ld, c_lo, c_hi, g, njv, acc);
   // fixed-order tree over the four waves: slot s of a wave's accumulator lives at red[region][s][lane]
