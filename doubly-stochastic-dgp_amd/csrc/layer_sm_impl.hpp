@@ -402,6 +402,20 @@ static inline void phase_span_report(const std::vector<unsigned long long>& h, i
   }
   fprintf(stderr, "[span] %d wgs: launch %.1f us | wg duration avg %.1f max %.1f us | start avg %.1f max %.1f us | %d late starters (avg duration %.1f us)\n",
           nwg, span, dur / nwg, dur_max, start / nwg, start_max, nlate, nlate ? late / nlate : 0.0);
+  if (nwg >= 512) {      // mean duration by launch slot (w >> 8: the order in which a CU received its workgroups) and by XCD (w & 7)
+    double ds[8] = {0}, dx[8] = {0};
+    int ns[8] = {0}, nx[8] = {0};
+    for (int w = 0; w < nwg; ++w) {
+      const double d = (double)(h[(size_t)w * 8 + last_slot] - h[(size_t)w * 8]) * 0.01;
+      const int k = std::min(w >> 8, 7);
+      ds[k] += d; ++ns[k]; dx[w & 7] += d; ++nx[w & 7];
+    }
+    fprintf(stderr, "[span]   mean duration by slot w >> 8:");
+    for (int k = 0; k < 8 && ns[k]; ++k) fprintf(stderr, " %.1f", ds[k] / ns[k]);
+    fprintf(stderr, " | by XCD w & 7:");
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", dx[x] / std::max(nx[x], 1));
+    fprintf(stderr, "\n");
+  }
 }
 #define FWD_STAMP(i) do { if (a.phase_clk && tid == 0 && blockIdx.y == 0) a.phase_clk[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // occupancy the forward instances are held to.  The 8-wave M = 256 instance sits at 120-126 VGPRs = two workgroups per CU; unrelated
