@@ -930,18 +930,63 @@ __device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
   iso = block_sum_256(iso, sh);
   if (!v.ard && threadIdx.x == 0) grad[v.off_kls] = iso * v.hyp[HYP_ILS + Din];
 }
+// Adam over entries [0, n) whose mask equals `want` (0: any non-zero mask), grid-stride over PAIRS: every array is read with one
+// 16-byte load per pair, all five loads of an iteration in flight before the first use (the element-at-a-time form tested the mask
+// first — two dependent round trips per element, one element in flight per thread: 2.6 TB/s on the 8.7 M parameters of config 4).
+// All arrays are 16-byte aligned (workspace / caller allocations) and index 2 k is even.
+__device__ __forceinline__ void adam_sweep(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
+                                           double* __restrict__ v, const double* __restrict__ mask, int64_t n, double lr_t, double b1,
+                                           double b2, double eps, double want, int64_t first, int64_t nthreads) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int64_t npair = n >> 1;
+  for (int64_t k = first; k < npair; k += nthreads) {
+    const d2 mk = *reinterpret_cast<const d2*>(mask + 2 * k), g = *reinterpret_cast<const d2*>(grad + 2 * k);
+    d2 mm = *reinterpret_cast<const d2*>(m + 2 * k), vv = *reinterpret_cast<const d2*>(v + 2 * k), th = *reinterpret_cast<const d2*>(theta + 2 * k);
+    bool on[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      on[e] = want == 0.0 ? mk[e] != 0.0 : mk[e] == want;
+      if (on[e]) {
+        const double mi = b1 * mm[e] + (1.0 - b1) * g[e];
+        const double vi = b2 * vv[e] + (1.0 - b2) * g[e] * g[e];
+        mm[e] = mi;
+        vv[e] = vi;
+        th[e] -= lr_t * mi / (sqrt(vi) + eps);
+      }
+    }
+    // an entry that is not this sweep's is NOT written back: in k_tail its owner (a hyper-parameter / likelihood block) updates it concurrently
+    if (on[0] && on[1]) {
+      *reinterpret_cast<d2*>(m + 2 * k) = mm;
+      *reinterpret_cast<d2*>(v + 2 * k) = vv;
+      *reinterpret_cast<d2*>(theta + 2 * k) = th;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (on[e]) {
+          m[2 * k + e] = mm[e];
+          v[2 * k + e] = vv[e];
+          theta[2 * k + e] = th[e];
+        }
+    }
+  }
+  if ((n & 1) && first == 0) {
+    const int64_t i = n - 1;
+    const bool on = want == 0.0 ? mask[i] != 0.0 : mask[i] == want;
+    if (on) {
+      const double gi = grad[i];
+      const double mi = b1 * m[i] + (1.0 - b1) * gi;
+      const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      theta[i] -= lr_t * mi / (sqrt(vi) + eps);
+    }
+  }
+}
 __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
                        double* __restrict__ v, const double* __restrict__ mask, int64_t n, double lr_t, double b1,
                        double b2, double eps) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (mask[i] == 0.0) continue;
-    const double g = grad[i];
-    const double mi = b1 * m[i] + (1.0 - b1) * g;
-    const double vi = b2 * v[i] + (1.0 - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    theta[i] -= lr_t * mi / (sqrt(vi) + eps);
-  }
+  adam_sweep(theta, grad, m, v, mask, n, lr_t, b1, b2, eps, 0.0, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+             (int64_t)gridDim.x * blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1112,7 +1157,6 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
     }
     return;
   }
-  const int64_t nth = (int64_t)(gridDim.x - La - nf) * 256;
-  for (int64_t i = (int64_t)(b - La - nf) * 256 + threadIdx.x; i < A.n; i += nth)
-    if (A.mask[i] == 1.0) adam_one(A, i, grad[i]);
+  adam_sweep(A.theta, grad, A.m, A.v, A.mask, A.n, A.lr_t, A.b1, A.b2, A.eps, 1.0, (int64_t)(b - La - nf) * 256 + threadIdx.x,
+             (int64_t)(gridDim.x - La - nf) * 256);
 }

@@ -616,7 +616,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
               m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
                m->fuse_adam.eps, (m->fuse_adam.on && gfirst == 0) ? 1 : 0};
-    const int nadam = A.on ? (int)std::min<int64_t>(512, ceil_div(m->desc.n_theta, 256)) : 0;
+    const int nadam = A.on ? (int)std::min<int64_t>(2048, ceil_div(m->desc.n_theta, 512)) : 0;      // a thread per pair of entries, eight workgroups per CU
     DS_LAUNCH(k_tail, dim3(La + 1 + nadam), dim3(256), 0, ctx->stream, m->layers_dev, gfirst, La, m->grad, F, A);
     DS_HIP(hipGetLastError());
     m->fin.done = true;
@@ -764,7 +764,7 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
   }
   const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   const int64_t n = m->desc.n_theta;
-  const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));
+  const int nb = (int)std::min<int64_t>(2048, ceil_div(n, 512));      // a thread per pair of entries (adam_sweep), eight workgroups per CU
   DS_LAUNCH(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
                      lr_t, beta1, beta2, eps);
   DS_HIP(hipGetLastError());
