@@ -1,5 +1,6 @@
 // Dispatch of the SVGP_Layer chain kernels (layer_sm_impl.hpp).  The instances are compiled in three parts
-// (layer_sm_a / _b / _c.hip: padded inducing counts 32..112, 128..256, 320..1024) so that they build in parallel.
+// (layer_sm_{fwd,bwd}_{a,b,c}.hip: padded inducing counts 32..112, 128..256, 320..1024, each direction on its own) so that they
+// build in parallel.
 #include <stdlib.h>
 
 #include "layer.hpp"
