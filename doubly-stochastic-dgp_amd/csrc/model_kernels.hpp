@@ -575,18 +575,26 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u][0] = s[u][1] = (d2){0, 0};
     int sp = rwave;
-    for (; sp + 12 < J.nsplit; sp += 16) {          // four splits = eight 16-byte loads in flight per lane
+    // EIGHT splits = sixteen 16-byte loads in flight per lane and pass (round 5; four before): the splits beyond the end are clamped
+    // to the last one and masked, so that every pass is one batch of loads — config 2's 23 splits were a batch of four and two more
+    // round trips one after the other, on the critical path at the end of the step.  Accumulator u still takes the splits
+    // rwave + 4 (u + 4 k): the sums are the same numbers in the same order.
+    for (; sp < J.nsplit; sp += 32) {
+      d2 x[8][2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double* __restrict__ p = src + (int64_t)(sp + 4 * u) * J.pstride;
-        s[u][0] += *reinterpret_cast<const d2*>(p);
-        s[u][1] += *reinterpret_cast<const d2*>(p + estep);
+      for (int u = 0; u < 8; ++u) {
+        const int spu = sp + 4 * u;
+        const double* __restrict__ p = src + (int64_t)(spu < J.nsplit ? spu : J.nsplit - 1) * J.pstride;
+        x[u][0] = *reinterpret_cast<const d2*>(p);
+        x[u][1] = *reinterpret_cast<const d2*>(p + estep);
       }
-    }
-    for (int u = 0; sp < J.nsplit; sp += 4, ++u) {   // at most three more: into the accumulator their position in a full group would use
-      const double* __restrict__ p = src + (int64_t)sp * J.pstride;
-      s[u][0] += *reinterpret_cast<const d2*>(p);
-      s[u][1] += *reinterpret_cast<const d2*>(p + estep);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (sp + 4 * u < J.nsplit) {
+          s[u & 3][0] += x[u][0];
+          s[u & 3][1] += x[u][1];
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -636,7 +644,18 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
 #pragma unroll
       for (int u = 0; u < 8; ++u) s[u] += *reinterpret_cast<const d2*>(J.part + (int64_t)(sp + u * 4) * J.pstride + i);
     }
-    for (; sp < J.nsplit; sp += 4) s[0] += *reinterpret_cast<const d2*>(J.part + (int64_t)sp * J.pstride + i);
+    if (sp < J.nsplit) {      // the remainder (up to seven splits) as ONE batch of clamped loads, added to s[0] in the old order — the loop
+                              // they used to be walked one round trip after the other (all of config 2's 23 splits: six per wave)
+      d2 x[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int spu = sp + 4 * u;
+        x[u] = *reinterpret_cast<const d2*>(J.part + (int64_t)(spu < J.nsplit ? spu : J.nsplit - 1) * J.pstride + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u)
+        if (sp + 4 * u < J.nsplit) s[0] += x[u];
+    }
     sh2[rwave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (rwave == 0 && live) {
@@ -673,7 +692,17 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const RedJob* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] += J.part[(int64_t)(sp + u * st) * J.pstride + i];
   }
-  for (; sp < J.nsplit; sp += st) s[0] += J.part[(int64_t)sp * J.pstride + i];
+  if (sp < J.nsplit) {        // (remainder as one batch of clamped loads, same order of additions: see ways == 8)
+    double x[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int spu = sp + u * st;
+      x[u] = J.part[(int64_t)(spu < J.nsplit ? spu : J.nsplit - 1) * J.pstride + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (sp + u * st < J.nsplit) s[0] += x[u];
+  }
   const double tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   if (!four) {
     J.out[o] = tot;
