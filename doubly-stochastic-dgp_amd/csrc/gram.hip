@@ -464,6 +464,9 @@ static void gram_mfma2_go(hipStream_t st, int ks, const double* X, int64_t n, co
     DS_LAUNCH((k_gram_mfma2<KIND, 8, 4>), grid, dim3(256), lds, st, X, n, X2, n2, D, hyp, diag_add, symmetric, out, ld, ct);
 }
 
+#ifndef DSDGP_GRAM_STREAM_VALIDATED
+#define DSDGP_GRAM_STREAM_VALIDATED 0
+#endif
 int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const double* X2, int64_t n2, int D,
                 const double* hyp_dev, double diag_add, int symmetric, double* out, int64_t ld) {
   ProfScope ps(ctx, "gram");
@@ -472,7 +475,13 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
     // tools/gram_time.py: 1024 x 50 000 x 8: 83 - 84 us against 93 - 94; 128 x 20 000 x 8: 16.2 against 14.1; 256 x 40 000 x 9: 30.7
     // against 26.9; 512 x 40 960 x 30: 75 against 69.5)
     const int ks = ceil_div(D, 4);
-    const bool stream = ks <= 2 && (int64_t)ceil_div(n2, 32) * ceil_div(n, 64) >= 8192;
+    // The streaming form waits for its prefetched column values with a HAND-COUNTED s_waitcnt (k_gram_mfma3: the loads are inline
+    // assembly, the compiler does not know they are in flight).  That is only as good as the ISA the compiler emitted around it, so the
+    // form is on by default only in a library built with the compiler it was validated with (Makefile: DSDGP_GRAM_STREAM_VALIDATED — the
+    // bitwise test of both forms, tests/test_gpu_round5.py::test_gram_both_forms_agree_bitwise_on_a_shared_block, green with that hipcc);
+    // DSDGP_GRAM_STREAM=0 / 1 overrides either way (1 after running that test with the new compiler).
+    static const bool stream_ok = getenv("DSDGP_GRAM_STREAM") ? atoi(getenv("DSDGP_GRAM_STREAM")) != 0 : (DSDGP_GRAM_STREAM_VALIDATED != 0);
+    const bool stream = stream_ok && ks <= 2 && (int64_t)ceil_div(n2, 32) * ceil_div(n, 64) >= 8192;
     if (kind == DSDGP_KERN_RBF) {
       if (stream) gram_mfma3_go<DSDGP_KERN_RBF>(ctx->stream, ks, X, n, X2, n2, D, hyp_dev, diag_add, symmetric, out, ld);
       else gram_mfma2_go<DSDGP_KERN_RBF>(ctx->stream, ks, X, n, X2, n2, D, hyp_dev, diag_add, symmetric, out, ld);

@@ -30,7 +30,7 @@ __device__ __forceinline__ void head_factor(const LayerDev& v, const double* __r
   const int g = lane >> 4, c = lane & 15;
   if (tid == 0) s_info = 0;
   long long tlast = timing ? __builtin_amdgcn_s_memtime() : 0;
-  const double var = softplus_d(theta[v.off_kvar]) + SOFTPLUS_LOWER;
+  const double var = kvar_of(v, theta);
   const double wvar = v.has_white ? softplus_d(theta[v.off_wvar]) + SOFTPLUS_LOWER : 0.0;
   // ---- Z / lengthscale, zero-padded to 16 columns (row stride 17): the Z loads are in flight while 16 threads transform the lengthscales
   double zreg[HEAD_MAX_N * 16 / HEAD_THREADS];

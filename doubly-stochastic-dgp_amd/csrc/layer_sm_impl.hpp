@@ -1038,10 +1038,9 @@ __global__ __launch_bounds__(NW * 64, (bwd_min_waves<MPB, NW, WIDE, CS>())) void
     // vbar_d of the NEXT output is requested inside the k loop of this one, unconditionally (clamped): at the top of the loop it sat
     // behind an exec branch and its first use drained the whole load queue (s_waitcnt vmcnt(0)) once per output
     const int64_t rc = rin ? r : 0;
-    const double vmask = rin ? 1.0 : 0.0;
     double vd_next = d_lo < d_hi ? a.VB[(int64_t)d_lo * a.ldA + rc] : 0.0;
     for (int d = d_lo; d < d_hi; ++d) {
-      const double vd = vmask * vd_next;
+      const double vd = rin ? vd_next : 0.0;      // (select, not a product: padded rows get an exact 0 whatever the clamped load returned)
       gsum += vd;
       const double vd2 = 2.0 * vd;
       d4 y0 = (d4){0, 0, 0, 0}, y1 = (d4){0, 0, 0, 0};

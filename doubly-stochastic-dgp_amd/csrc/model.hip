@@ -72,6 +72,8 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_CHECK_ARG(ctx && out && theta && workspace);
   DS_TRY(validate_desc(desc));
   DS_CHECK_ARG(((uintptr_t)workspace & 255) == 0);
+  // the optimiser sweeps theta / grad / adam_m / adam_v with 16-byte vector accesses (adam_sweep)
+  DS_CHECK_ARG(((uintptr_t)theta & 15) == 0 && ((uintptr_t)grad & 15) == 0 && ((uintptr_t)adam_m & 15) == 0 && ((uintptr_t)adam_v & 15) == 0);
   dsdgp_model* m = new dsdgp_model();
   parse_force(m);
   m->ctx = ctx;

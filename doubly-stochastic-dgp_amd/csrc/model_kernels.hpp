@@ -7,6 +7,12 @@
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+// kernel variance from its free variable: [UPSTREAM] transforms.positive, or the value itself for a Parameter without transform
+// (dsdgp_layer_desc::kvar_identity — tests/test_dgp.py:79-85 builds a Matern52 with variance 1e-24 that way)
+__device__ __forceinline__ double kvar_of(const LayerDev& v, const double* __restrict__ theta) {
+  const double rv = theta[v.off_kvar];
+  return v.kvar_identity ? rv : softplus_d(rv) + SOFTPLUS_LOWER;
+}
 
 // parameter transforms + padding (LowerTriangular / positive transforms of layers.py:150 and [UPSTREAM] kernels)
 // WAVE_TILES: k_prep_kuu (256 threads, large models); the head launch (512 threads, M <= 128, its LDS is the factorisation's) takes
@@ -17,7 +23,7 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
   const int tid0 = bx * blockDim.x + threadIdx.x, nth = nprep * blockDim.x;
   if (tid0 == 0) {
     const double rv = theta[v.off_kvar];
-    const double var = softplus_d(rv) + SOFTPLUS_LOWER;
+    const double var = kvar_of(v, theta);
     double wv = 0.0, dwv = 0.0;
     if (v.has_white) {
       const double rw = theta[v.off_wvar];
@@ -25,7 +31,7 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
       dwv = sigmoid_d(rw);
     }
     v.hyp[HYP_VAR] = var; v.hyp[HYP_WVAR] = wv; v.hyp[HYP_KDIAG] = var + wv;
-    v.hyp[HYP_DVAR] = sigmoid_d(rv); v.hyp[HYP_DWVAR] = dwv;
+    v.hyp[HYP_DVAR] = v.kvar_identity ? 1.0 : sigmoid_d(rv); v.hyp[HYP_DWVAR] = dwv;
     if (blockIdx.y == 0 && lik_gauss) {   // (grid y = layer)
       const double rl = theta[off_lik];
       lik_const[0] = softplus_d(rl) + SOFTPLUS_LOWER;
@@ -117,7 +123,7 @@ __device__ void kuu_body(const LayerDev& v, const double* __restrict__ theta, do
   __shared__ double Zi[16][33], Zj[16][33], ils_s[32];
   const int Mp = v.Mp, nt = Mp / 16, Din = v.D_in, M = v.M;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  const double var = softplus_d(theta[v.off_kvar]) + SOFTPLUS_LOWER;
+  const double var = kvar_of(v, theta);
   const double wvar = v.has_white ? softplus_d(theta[v.off_wvar]) + SOFTPLUS_LOWER : 0.0;
   for (int tile = bx; tile < nt * nt; tile += nbx) {
     const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
@@ -1011,9 +1017,17 @@ __device__ __forceinline__ void adam_sweep(double* __restrict__ theta, const dou
     }
   }
 }
+// A failed Kuu factorisation ([UPSTREAM] tf.cholesky raises inside session.run: the optimiser op never runs) leaves the parameters
+// and the Adam state untouched: the asynchronous step reports the pivot at the next synchronising call and the model is still usable.
+__device__ __forceinline__ bool chol_failed(const LayerDev* __restrict__ layers, int L) {
+  bool bad = false;
+  for (int l = 0; l < L; ++l) bad |= layers[l].scal[1] != 0.0;
+  return bad;
+}
 __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ grad, double* __restrict__ m,
                        double* __restrict__ v, const double* __restrict__ mask, int64_t n, double lr_t, double b1,
-                       double b2, double eps) {
+                       double b2, double eps, const LayerDev* __restrict__ layers, int L) {
+  if (chol_failed(layers, L)) return;
   adam_sweep(theta, grad, m, v, mask, n, lr_t, b1, b2, eps, 0.0, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
              (int64_t)gridDim.x * blockDim.x);
 }
@@ -1144,10 +1158,11 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
                                               const FinArgs F, const AdamArgs A) {
   __shared__ double sh[4];
   const int b = (int)blockIdx.x;
+  const bool adam_on = A.on && !chol_failed(layers_all, F.L);
   if (b < La) {
     const LayerDev v = layers_all[first + b];
     asm_hyp_final(v, grad);
-    if (A.on) {
+    if (adam_on) {
       __syncthreads();      // (the values were written by threads of this block: re-read below by the same threads that wrote them)
       const int Din = v.D_in;
       if (threadIdx.x == 0) {
@@ -1181,11 +1196,12 @@ __global__ __launch_bounds__(256) void k_tail(const LayerDev* __restrict__ layer
       if (F.off_lik >= 0) {
         const double g = -F.w * c * F.lik_const[1];
         grad[F.off_lik] = g;
-        if (A.on && A.mask[F.off_lik] != 0.0) adam_one(A, F.off_lik, g);
+        if (adam_on && A.mask[F.off_lik] != 0.0) adam_one(A, F.off_lik, g);
       }
     }
     return;
   }
+  if (!adam_on) return;
   adam_sweep(A.theta, grad, A.m, A.v, A.mask, A.n, A.lr_t, A.b1, A.b2, A.eps, 1.0, (int64_t)(b - La - nf) * 256 + threadIdx.x,
              (int64_t)(gridDim.x - La - nf) * 256);
 }

@@ -45,7 +45,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     v.DP4 = (int)round_up(d.D_out, 4); v.DP16 = (int)round_up(d.D_out, 16); v.DinP16 = (int)round_up(d.D_in + 1, 16);
     v.kern_kind = d.kern_kind; v.ard = d.ard; v.has_white = d.has_white; v.white = D.white; v.hyp_parts = -NPART;
     v.off_Z = d.off_Z; v.off_q_mu = d.off_q_mu; v.off_q_sqrt = d.off_q_sqrt;
-    v.off_kvar = d.off_kvar; v.off_kls = d.off_kls; v.off_wvar = d.off_wvar;
+    v.off_kvar = d.off_kvar; v.off_kls = d.off_kls; v.off_wvar = d.off_wvar; v.kvar_identity = d.kvar_identity ? 1 : 0;
     const size_t Mp = v.Mp, MM = Mp * Mp;
     v.Zp = b.take<double>(Mp * d.D_in);
     v.Zs = b.take<double>(Mp * d.D_in);

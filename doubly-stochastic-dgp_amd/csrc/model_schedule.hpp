@@ -766,7 +766,7 @@ extern "C" int dsdgp_model_adam_step(dsdgp_model* m, double lr, double beta1, do
   const int64_t n = m->desc.n_theta;
   const int nb = (int)std::min<int64_t>(2048, ceil_div(n, 512));      // a thread per pair of entries (adam_sweep), eight workgroups per CU
   DS_LAUNCH(k_adam, dim3(nb), dim3(256), 0, m->ctx->stream, m->theta, m->grad, m->adam_m, m->adam_v, m->mask, n,
-                     lr_t, beta1, beta2, eps);
+                     lr_t, beta1, beta2, eps, (const LayerDev*)m->layers_dev, m->desc.L);
   DS_HIP(hipGetLastError());
   m->prepared = false;
   m->kuu_valid = false;

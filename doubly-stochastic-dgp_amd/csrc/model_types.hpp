@@ -7,7 +7,7 @@
 // ------------------------------------------------------------------------------------------------------
 struct LayerDev {
   int32_t M, Mp, D_in, D_out, DP4, DP16, DinP16, kern_kind, ard, has_white, white, hyp_parts;   // rows of hyp2part per backward: > 0 written by k_asm_kbar (folded), < 0: -NPART rows by k_asm_hyp_part
-  int32_t kl_parts, pad_kl;       // partial sums k_kl_part leaves in klpart (the launch's block columns)
+  int32_t kl_parts, kvar_identity;   // partial sums k_kl_part leaves in klpart (the launch's block columns); dsdgp_layer_desc::kvar_identity
   int64_t off_Z, off_q_mu, off_q_sqrt, off_kvar, off_kls, off_wvar;
   double *Zp, *Zs, *hyp, *Tp, *TpT, *qmu, *qmu4;
   double *Kp, *Linv, *LinvT, *Kinv, *scal;

@@ -38,6 +38,7 @@ class LayerDesc(C.Structure):
                 ("trainable_kvar", C.c_int32), ("trainable_kls", C.c_int32), ("trainable_wvar", C.c_int32),
                 ("input_prop_dim", C.c_int32),
                 ("trainable_mean_A", C.c_int32), ("trainable_mean_b", C.c_int32),
+                ("kvar_identity", C.c_int32), ("reserved0", C.c_int32),
                 ("mean_A", C.c_void_p),
                 ("off_Z", C.c_int64), ("off_q_mu", C.c_int64), ("off_q_sqrt", C.c_int64),
                 ("off_kvar", C.c_int64), ("off_kls", C.c_int64), ("off_wvar", C.c_int64),

@@ -147,7 +147,10 @@ class Engine:
             ld.trainable_Z = int(add(layer.feature.Z, "id", "Z"))
             ld.trainable_q_mu = int(add(layer.q_mu, "id", "q_mu"))
             ld.trainable_q_sqrt = int(add(layer.q_sqrt, "qsqrt", "q_sqrt"))
-            ld.trainable_kvar = int(add(stat.variance, "pos", "kvar"))
+            # a variance Parameter WITHOUT the positive transform (tests/test_dgp.py:79-85: NoTransformMatern52, variance 1e-24) is
+            # its own free variable on the device too
+            ld.kvar_identity = int(getattr(stat.variance, "transform", "positive") is None)
+            ld.trainable_kvar = int(add(stat.variance, "id" if ld.kvar_identity else "pos", "kvar"))
             ld.trainable_kls = int(add(stat.lengthscales, "pos", "kls"))
             if wk is not None:
                 ld.trainable_wvar = int(add(wk.variance, "pos", "wvar"))

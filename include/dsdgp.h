@@ -111,13 +111,16 @@ typedef struct {
   int32_t trainable_Z, trainable_q_mu, trainable_q_sqrt, trainable_kvar, trainable_kls, trainable_wvar;
   int32_t input_prop_dim;          /* Layer(input_prop_dim) layers.py:36-50,105-117: the next layer sees [X[:, :p] | samples] */
   int32_t trainable_mean_A, trainable_mean_b;   /* only meaningful when the corresponding off_mean_* >= 0 */
+  int32_t kvar_identity;           /* 1: theta[off_kvar] IS the kernel variance (a Parameter without transform — the reference's own
+                                      tests build such a kernel to reach variance 1e-24, tests/test_dgp.py:79-85); 0: softplus + 1e-6 */
+  int32_t reserved0;
   const double* mean_A;            /* device, (D_in x D_out) for DSDGP_MEAN_LINEAR when fixed (layer_initializations.py:41-42);
                                       ignored when off_mean_A >= 0 */
   /* offsets (in doubles) into the flat unconstrained parameter vector theta: */
   int64_t off_Z;                   /* (M, D_in)                       feature.Z           layers.py:153 */
   int64_t off_q_mu;                /* (M, D_out)                      layers.py:146-147 */
   int64_t off_q_sqrt;              /* (D_out, M, M) dense; tril part is the free variable  layers.py:149-151 */
-  int64_t off_kvar;                /* scalar, softplus^-1(variance)   [UPSTREAM] transforms.positive */
+  int64_t off_kvar;                /* scalar, softplus^-1(variance)   [UPSTREAM] transforms.positive (the variance itself if kvar_identity) */
   int64_t off_kls;                 /* 1 or D_in values, softplus^-1(lengthscales) */
   int64_t off_wvar;                /* scalar (if has_white) */
   /* [UPSTREAM] mean_functions.Linear(A, b) as a free parameter (a user-supplied final mean function, dgp.py:187): */
@@ -140,7 +143,8 @@ typedef struct {
 
 /* Workspace needed for minibatches of up to n_max rows and s_max samples. */
 int dsdgp_model_workspace_bytes(const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max, int64_t* bytes);
-/* theta/grad/adam_m/adam_v: device, n_theta doubles each (grad/adam_* may be NULL for predict-only models). */
+/* theta/grad/adam_m/adam_v: device, n_theta doubles each, 16-byte aligned (DSDGP_ERR_BAD_ARG otherwise: the optimiser reads them as
+ * pairs); grad/adam_* may be NULL for predict-only models.  workspace: 256-byte aligned. */
 int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, int64_t n_max, int32_t s_max, double* theta,
                        double* grad, double* adam_m, double* adam_v, void* workspace, int64_t workspace_bytes,
                        dsdgp_model** out);

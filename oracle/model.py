@@ -5,7 +5,7 @@ free variables GPflow would optimise):
 
 spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass"|"bernoulli", "num_classes": K,
          "layers": [{"kind": "rbf"|"matern52", "input_dim": D_in, "ARD": bool, "has_white": bool,
-                     "mean": "zero"|"identity"|"linear", "mean_A": ndarray|None}, ...]}
+                     "mean": "zero"|"identity"|"linear", "mean_A": ndarray|None, "kvar_identity": bool (optional)}, ...]}
 state = {"l{i}.Z": (M,D_in), "l{i}.q_mu": (M,D_out), "l{i}.q_sqrt": (D_out,M,M)  [tril part is the free var],
          "l{i}.kern_variance_raw": (), "l{i}.kern_lengthscales_raw": () or (D_in,),
          "l{i}.white_variance_raw": () [if has_white], "lik_variance_raw": () [gaussian]}
@@ -36,7 +36,11 @@ def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
         state[f"l{i}.Z"] = np.array(ld["Z"], dtype=np.float64)
         state[f"l{i}.q_mu"] = np.array(ld["q_mu"], dtype=np.float64)
         state[f"l{i}.q_sqrt"] = np.array(ld["q_sqrt"], dtype=np.float64)
-        state[f"l{i}.kern_variance_raw"] = np.array(constrained_to_raw(k.variance))
+        if ld.get("kvar_identity"):
+            spec_layers[-1]["kvar_identity"] = True
+            state[f"l{i}.kern_variance_raw"] = np.array(k.variance, dtype=np.float64)
+        else:
+            state[f"l{i}.kern_variance_raw"] = np.array(constrained_to_raw(k.variance))
         ls = np.asarray(k.lengthscales, dtype=np.float64)
         if k.ARD and ls.ndim == 0:
             ls = np.full((k.input_dim,), float(ls))
@@ -54,7 +58,10 @@ def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
     for i, ls in enumerate(spec["layers"]):
         g = lambda n: xp.asarray(state[f"l{i}.{n}"])
         kern = O.Kern(ls["kind"], ls["input_dim"],
-                      variance=O.positive_forward(xp, g("kern_variance_raw")),
+                      # "kvar_identity": a variance Parameter without transform (reference tests/test_dgp.py:79-85,
+                      # NoTransformMatern52 with variance 1e-24): the state entry is the variance itself
+                      variance=(g("kern_variance_raw") if ls.get("kvar_identity")
+                                else O.positive_forward(xp, g("kern_variance_raw"))),
                       lengthscales=O.positive_forward(xp, g("kern_lengthscales_raw")),
                       ARD=ls["ARD"],
                       white_variance=(O.positive_forward(xp, g("white_variance_raw"))
