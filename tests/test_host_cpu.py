@@ -37,10 +37,10 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     _lib = _lib_or_skip()
-    # the ctypes mirrors against the sizes the C side was compiled with (LP64): dsdgp_layer_desc = 16*4 + 8 + 8*8
+    # the ctypes mirrors against the sizes the C side was compiled with (LP64): dsdgp_layer_desc = 18*4 + 8 + 8*8 (round 6: + kvar_identity, reserved0)
     lib = ctypes.CDLL(_lib.lib_path())
-    assert ctypes.sizeof(_lib.LayerDesc) == lib.dsdgp_sizeof_layer_desc() == 136
-    assert ctypes.sizeof(_lib.ModelDesc) == lib.dsdgp_sizeof_model_desc() == 48 + 16 * 136
+    assert ctypes.sizeof(_lib.LayerDesc) == lib.dsdgp_sizeof_layer_desc() == 144
+    assert ctypes.sizeof(_lib.ModelDesc) == lib.dsdgp_sizeof_model_desc() == 48 + 16 * 144
     assert ctypes.sizeof(_lib.KernelSpec) == 40
 
 
