@@ -123,6 +123,10 @@ int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_
 // chain kernels (layer_sm.hip): the NW waves of a workgroup cooperate on one block of 16 rows
 int layer_fwd_sm_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, int Mp, int kern_kind, int white);
 int layer_bwd_sm_launch(dsdgp_ctx* ctx, const LayerBwdArgs& a, int Mp, int kern_kind, int white);
+// the last layer of a training step as one launch (layer_last.hip): forward chain + Gaussian likelihood + reverse mode of the same row block
+int layer_last_built(int Mp, int D_in, int D_out);
+int layer_last_waves(int Mp);
+int layer_last_launch(dsdgp_ctx* ctx, const LayerFwdArgs& a, const LayerBwdArgs& b, int Mp, int kern_kind, int hyp_rows);
 int sm_cs_built(int Mp);     // the split-M backward chain has a Csave instance for this padded inducing count
 int64_t sm_hyp_parts(int64_t ld, int Mp, int D_in);   // number of hyp_part rows the split-M backward writes for ld padded rows
 

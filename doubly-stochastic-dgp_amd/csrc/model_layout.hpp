@@ -81,6 +81,8 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
       const int64_t R_l = (l == 0) ? m->n_max : (int64_t)m->s_max * m->n_max;
       v.alg_g = (!D.white && (alg_env == 1 || (alg_env < 0 && (int64_t)4 * d.D_out * v.Mp <= R_l))) ? 1 : 0;
       v.need_tpt = (v.Mp > 256 || save_c_enabled(m, v.Mp) || (m->force.gemm_mp > 0 && v.Mp >= m->force.gemm_mp)) ? 1 : 0;
+      // the fused last layer (layer_last.hip) forms abar's variance part as q_sqrt (q_sqrt^T a): it reads q_sqrt^T as rows
+      if (l == D.L - 1 && D.L >= 2 && !D.white && m->force.last_fuse != 0 && layer_last_built(v.Mp, d.D_in, d.D_out)) v.need_tpt = 1;
       v.KS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
       v.GS = v.alg_g ? b.take<double>(d.D_out * MM) : nullptr;
     }

@@ -179,6 +179,22 @@ static int randn_async(dsdgp_ctx* ctx, uint64_t seed, uint64_t stream, int64_t c
   return DSDGP_OK;
 }
 
+// Whether the last layer's forward chain, the Gaussian likelihood and its reverse pass run as ONE launch (layer_last.hip) in this step.
+// `a`: the forward arguments as forward_layers built them.
+static bool last_chain_fusable(const dsdgp_model* m, const LayerState& St, const LayerFwdArgs& a) {
+  const LayerDev& v = St.dev;
+  const int L = m->desc.L;
+  if (m->force.last_fuse == 0 || m->desc.white || St.gemm || L < 2) return false;
+  if (!layer_last_built(v.Mp, v.D_in, v.D_out) || !v.alg_g || !v.need_tpt) return false;
+  if (!a.lik_Y || !a.Asave || a.Csave || a.F || a.rep != 1 || a.d_split > 1 || a.qmu_ld) return false;
+  if (a.mean_kind != DSDGP_MEAN_ZERO) return false;
+  if (m->grad_q_only && m->grad_first == L - 1) return false;     // that layer runs no backward chain at all
+  if (m->force.bwd_split >= 2) return false;
+  static const bool timing = getenv("DSDGP_FWD_TIMING") || getenv("DSDGP_BWD_TIMING");      // the phase clocks are the two chains'
+  if (timing) return false;
+  return ceil_div(a.Rin, 16) >= m->force.last_min_blocks;
+}
+
 // dgp.py:61-76 propagate
 static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, const double* const* zs,
                           const int64_t* zstride, uint64_t seed, bool save, bool need_last_F, double* const* Fs,
@@ -194,6 +210,7 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
   // block, a third of the MFMA work of a D_out = 1 layer.  The training pass keeps `a` (the reverse pass is written in terms of it).
   // Mp <= 256: the larger instances read the factor transposed, which exists for q_sqrt only.
   const bool wf_ok = !m->desc.white && !save && m->force.white_fwd != 0;
+  m->last_deferred = false;
   if (wf_ok) DS_TRY(join_prep(m));          // V, nL come from the parameter products (side stream in the overlapped schedule)
   for (int l = 0; l < L; ++l) {
     LayerState& St = m->L[l];
@@ -248,7 +265,10 @@ static int forward_layers(dsdgp_model* m, const double* X, int64_t n, int S, con
         *lik_nblocks = St.gemm ? layer_gemm_lik_blocks(Rin, v.D_out) : (int)nblk * a.d_split;
       }
     }
-    if (St.gemm) DS_TRY(layer_fwd_gemm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
+    if (last && last_chain_fusable(m, St, a)) {
+      m->last_fwd = a;               // launched by backward_layers together with this layer's reverse pass
+      m->last_deferred = true;
+    } else if (St.gemm) DS_TRY(layer_fwd_gemm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
     else DS_TRY(layer_fwd_sm_launch(ctx, a, v.Mp, v.kern_kind, m->desc.white || wf));
     St.z_used = a.z; St.zs_s = a.zs_s; St.zs_n = a.zs_n; St.zs_d = a.zs_d;
     St.X_used = Xin; St.Rin_used = Rin; St.rep_used = rep; St.ld_used = a.ldA;
@@ -526,7 +546,10 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int ds = (want && St.bpart) ? chain_d_split(nblk, v.D_out) : 1;
       b.d_split = ds; b.part = St.bpart; b.part_cnt = St.bcnt;
     }
-    if (skip_chain) { /* nothing downstream of this layer's chain is wanted */ }
+    if (last && m->last_deferred) {
+      DS_TRY(layer_last_launch(ctx, m->last_fwd, b, v.Mp, v.kern_kind, (int)(sm_hyp_parts(ld, v.Mp, v.D_in) / (ld / 16))));
+      m->last_deferred = false;
+    } else if (skip_chain) { /* nothing downstream of this layer's chain is wanted */ }
     else if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
     else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
     if (!overlap || on_main) {

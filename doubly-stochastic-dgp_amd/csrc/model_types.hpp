@@ -138,6 +138,8 @@ struct dsdgp_model {
   double *Xmb = nullptr, *Ymb = nullptr;   // gathered minibatch of dsdgp_model_train_step_minibatch (n_max x D_in of layer 0 / x DY)
   bool head_ok = false;         // every layer has Mp <= 128 and D_in <= 16: parameter transforms, Ku, its factorisation and inverse
                                 // factor (and the inner layers' N(0,1) draws) in ONE launch (k_head, head_impl.hpp)
+  bool last_deferred = false;   // the last layer's forward chain was not launched by forward_layers: it runs fused with its reverse pass (layer_last.hip)
+  LayerFwdArgs last_fwd;        //   ... with these arguments
   bool fused_last = false;      // the last layer's MB / VB were written by the likelihood kernel of this step
   // arguments of the pending k_finalize (value + likelihood-variance gradient): launched on the side stream beside the
   // backward chain when streams overlap, otherwise on the main stream after it
@@ -159,9 +161,10 @@ struct dsdgp_model {
   // backward chain 0 off / 1 from Mp = 512 / 2 everywhere; pipe_tail: per-layer reduction + P_d T_d products behind each layer's
   // weight-gradient products 0 / 1; head / tail / adj_fuse / lik_fuse = 0: the unfused launches (parity tests of the fusions);
   // ext_ev = 0: plain event record behind the head launch; red_ahead = 0: one split-K reduction after the stream join;
-  // white_fwd = 0: forward-only evaluations in plain coordinates.  gemm_mp: smallest padded inducing count whose layers take the
+  // white_fwd = 0: forward-only evaluations in plain coordinates.  last_fuse = 0: the last layer of a training step as its two chains
+  // instead of the fused launch (layer_last.hip); last_min_blocks: fewest row blocks for which the fused launch is taken.  gemm_mp: smallest padded inducing count whose layers take the
   // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -192,6 +195,8 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "ext_ev") m->force.ext_ev = v;
       else if (k == "lik_fuse") m->force.lik_fuse = v;
       else if (k == "gemm_mp") m->force.gemm_mp = v;
+      else if (k == "last_fuse") m->force.last_fuse = v;
+      else if (k == "last_min_blocks") m->force.last_min_blocks = v;
     }
     pos = end + 1;
   }

@@ -167,3 +167,60 @@ def test_full_batch_training_step_with_num_data_override(L):
     # the same model without the override scales the data term by 1 instead of 5000 / 150
     spec1, state1, model1 = make_case(X, Y, Z, [kern_spec("rbf", D)] * L, S=S, num_data=None, minibatch_size=None, seed=2)
     assert_allclose(model1.compute_log_likelihood(zs=zs), OM.elbo(spec1, state1, X, Y, zs, S), rtol=1e-9)
+
+
+# ---------------------------------------------------------------- the last layer of a training step as one launch (layer_last.hip)
+@pytest.mark.parametrize("force", ["last_fuse=0", ""])
+@pytest.mark.parametrize("shape", [dict(N=203, D=8, M=128, S=4, L=3, kind="rbf"),            # ragged rows, config-2 slice
+                                   dict(N=181, D=5, M=120, S=3, L=2, kind="matern52"),       # padded inducing rows, two layers (dX path)
+                                   dict(N=270, D=9, M=256, S=4, L=3, kind="rbf"),            # the eight-wave instance (config 3's last layer)
+                                   dict(N=345, D=3, M=250, S=3, L=2, kind="matern52"),
+                                   dict(N=40, D=4, M=128, S=2, L=2, kind="rbf")])            # too few rows for the algebraic dl/dKu: the two chains
+def test_last_layer_fused_launch_against_the_oracle_and_the_two_chains(monkeypatch, force, shape):
+    """D_out = 1, Gaussian likelihood, non-white: forward chain + likelihood + reverse pass of the last layer in ONE launch (its abar
+    from the triangular pair q_sqrt (q_sqrt^T a) with c still in registers) against the oracle's autograd, with the launch on (default)
+    and off (`last_fuse=0`: the two chains).  Launch count: one fewer with the fusion."""
+    if force:
+        monkeypatch.setenv("DSDGP_FORCE", force)
+    else:
+        monkeypatch.delenv("DSDGP_FORCE", raising=False)
+    from doubly_stochastic_dgp.engine import Context
+    c = shape
+    rng = np.random.RandomState(c["N"] + c["M"])
+    N, D, M, S, L = c["N"], c["D"], c["M"], c["S"], c["L"]
+    X, Y = rng.randn(N, D), rng.randn(N, 1)
+    Z = (X[rng.permutation(N)[:M]] if M <= N else rng.randn(M, D)) + 0.02 * rng.randn(M, D)
+    spec, state, model = make_case(X, Y, Z, [kern_spec(c["kind"], D, 1.1, 1.2)] * L, S=S, num_data=4 * N, seed=4)
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 1)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=4 * N)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-7 * (np.max(np.abs(g[k])) + 1e-12), k
+    lib = Context.get().lib
+    lib.dsdgp_launch_count.restype = __import__("ctypes").c_int64
+    n0 = lib.dsdgp_launch_count()
+    got2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    n1 = lib.dsdgp_launch_count()
+    assert got2 == got                                            # same bits on a second evaluation
+    test_last_layer_fused_launch_against_the_oracle_and_the_two_chains.launches[(force, c["M"], c["N"])] = n1 - n0
+    both = test_last_layer_fused_launch_against_the_oracle_and_the_two_chains.launches
+    if ("", c["M"], c["N"]) in both and ("last_fuse=0", c["M"], c["N"]) in both:
+        # the launch is taken where the layer's dl/dKu is assembled algebraically (4 D_out Mp <= S N rows: no E store in the chain)
+        fused = 4 * (128 if M <= 128 else 256) <= S * N
+        assert both[("", c["M"], c["N"])] == both[("last_fuse=0", c["M"], c["N"])] - (1 if fused else 0)
+    # three optimiser steps through the fused launch track the oracle's Adam
+    keys = sorted(state.keys())
+    th = {k: state[k].copy() for k in keys}
+    mm = {k: np.zeros_like(state[k]) for k in keys}
+    vv = {k: np.zeros_like(state[k]) for k in keys}
+    for t in range(1, 3):
+        _, gg = OM.elbo_and_grad(spec, th, X, Y, zs, S, num_data=4 * N)
+        for k in keys:
+            O.adam_step(th[k], -gg[k], mm[k], vv[k], t, lr=0.01)
+        model.train_step(0.01, X=X, Y=Y, zs=zs)
+    assert_allclose(model.compute_log_likelihood(X, Y, zs=zs), OM.elbo(spec, th, X, Y, zs, S, num_data=4 * N), rtol=1e-7)
+
+
+test_last_layer_fused_launch_against_the_oracle_and_the_two_chains.launches = {}

@@ -33,7 +33,7 @@ def main(cfg_id):
         step()
     torch.cuda.synchronize()
     out = {"cfg": cfg_id, "ms_per_step": round(ms, 4), "ms_reps": [round(r, 4) for r in reps]}
-    for name in ("layer_fwd", "layer_bwd", "wgrad", "gemm", "potrf"):
+    for name in ("layer_fwd", "layer_bwd", "layer_last", "wgrad", "gemm", "potrf"):
         t, cnt = ctx.prof_read(name)
         out[name] = round(t / 5, 3)
     print(out)
