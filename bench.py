@@ -14,8 +14,10 @@ flat gradient is summed with one all-reduce per step and every rank applies the 
 (NO x N).  `--scaling weak` keeps 1000 rows per GPU (global batch 1000 N) and reports N x steps/s.
 
 Timing protocol: the secondary measurements (forward-only evals/s, predict_f rows/s, per-kernel HIP-event times, the
-sub-rooflines) run FIRST and bring the GPU to its steady clocks; then W untimed warm-up steps, then EXACTLY K steps between
-barrier + synchronize -> `value`.  A separate loop times >= 200 single steps with events for median / p10 / p90.
+sub-rooflines, the other configs) run FIRST and bring the GPU to its steady clocks; then W untimed warm-up steps, then EXACTLY K
+steps between barrier + synchronize -> `value`.  After the timed region: the CPU baseline (rank 0, N = 1), a fixed loop of 1200
+single steps bracketed by HIP events (median / p10 / p90 -> `step_time`), and at N = 1 the flat data-parallel step on the 500 / 250 /
+125-row shards of a 2 / 4 / 8-GPU strong-scaling run over a one-rank RCCL group (`shard_steps`: the strong-scaling ceiling).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HIP-event timed dominant kernel) and
 `cpu_baseline` (the CPU oracle — a port of the GPflow/TF op sequence, NOT TF itself — timed on this box's host cores).
@@ -54,7 +56,20 @@ def algorithmic_flops(cfg, shapes=None):
         wg.append((2 + Dout) * M * M * R)
     small = sum(M * M * (Din + 2) + M ** 3 / 3 + Dout * M ** 3 / 3 + 2 * M * M * Dout for _, Din, Dout in shapes)
     return dict(layer_fwd=sum(fwd), layer_bwd=sum(fwd), wgrad=sum(wg), small=small,
-                step=3 * (sum(fwd) + small))
+                step=3 * (sum(fwd) + small), per_layer=fwd)
+
+
+def slot_flops(fl, fx, fused_last):
+    """Algorithmic / executed flops of the timed kernel classes.  With the fused last-layer launch (csrc/layer_last.hip: forward chain +
+    likelihood + reverse pass of the D_out = 1 layer in one kernel) the `layer_fwd` / `layer_bwd` slots hold the layers below it and
+    `layer_last` both halves of the last layer (SURVEY 8d counts the reverse pass as 1 x the forward figure)."""
+    if not fused_last:
+        return ({k: fl[k] for k in ("layer_fwd", "layer_bwd", "wgrad")}, {k: fx[k] for k in ("layer_fwd", "layer_bwd", "wgrad")})
+    last = fl["per_layer"][-1]
+    a = dict(layer_fwd=fl["layer_fwd"] - last, layer_bwd=fl["layer_bwd"] - last, layer_last=2 * last, wgrad=fl["wgrad"])
+    x = dict(layer_fwd=fx["layer_fwd"] - fx["last_fwd"], layer_bwd=fx["layer_bwd"] - fx["last_bwd"], layer_last=fx["last_fused"],
+             wgrad=fx["wgrad"])
+    return a, x
 
 
 def chain_d_split(nblk, D_out):
@@ -77,33 +92,42 @@ def executed_flops_chain(M, shapes, white=False):
     nb = Mp // 16
     tri = 4 * nb * (nb + 1) // 2
     fwd = bwd = wg = 0
-    for R, Din, Dout in shapes:
+    last_fwd = last_bwd = last_fused = 0
+    for li, (R, Din, Dout) in enumerate(shapes):
         blocks = -(-R // 16)
         k16 = -(-Din // 16)
         nw4 = Mp <= 128 and blocks > 160          # the 4-wave forward instance (8 waves: Mp = 256, and launches of <= 160 row blocks)
         sq = 4 * nb * k16
         pro = sq + tri + (0 if white else tri) + (4 * nb * -(-Dout // 16) if nw4 else 0)
-        fwd += blocks * (chain_d_split(blocks, Dout) * pro + Dout * tri)
+        f_l = blocks * (chain_d_split(blocks, Dout) * pro + Dout * tri)
+        fwd += f_l
         dp4 = -(-Dout // 4) * 4
-        bwd += blocks * (Dout * 4 * nb * nb + (dp4 // 4) * nb + (tri if white else 4 * nb * nb) + sq + 8 * nb * k16)
+        b_l = blocks * (Dout * 4 * nb * nb + (dp4 // 4) * nb + (tri if white else 4 * nb * nb) + sq + 8 * nb * k16)
+        bwd += b_l
+        if li == len(shapes) - 1:
+            # the fused last-layer launch (layer_last.hip, D_out = 1): distances, a1, a, c = q_sqrt^T a | q_sqrt c (triangular, where the
+            # two chains run the dense S a), Ku^-1 abar (dense), distances again, the hyper-parameter / dX sums; mean and q_mu mbar on the VALU
+            last_fwd, last_bwd = f_l, b_l
+            last_fused = blocks * (sq + 3 * tri + tri + 4 * nb * nb + sq + 8 * nb * k16)
         Mw = -(-Mp // 64) * 64
         ti = Mw // 64
         alg_g = 4 * Dout * Mp <= R
         dp16, dinp16 = -(-Dout // 16) * 16, -(-Din // 16) * 16
         per_chunk = Dout * (64 * ti * (ti - 1) // 2 + 40 * ti) + ti * dp16 + ti * dinp16 + (0 if alg_g else 64 * ti * ti)
         wg += blocks * per_chunk
-    return dict(layer_fwd=2048.0 * fwd, layer_bwd=2048.0 * bwd, wgrad=2048.0 * wg)
+    return dict(layer_fwd=2048.0 * fwd, layer_bwd=2048.0 * bwd, wgrad=2048.0 * wg, last_fwd=2048.0 * last_fwd, last_bwd=2048.0 * last_bwd,
+                last_fused=2048.0 * last_fused)
 
 
 def executed_profile():
     """executed MFMA flops per step of every config shape from the committed PMC pass (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 summed over
     one step's launches, tools/executed_flops.py) — only when the profile was taken from the kernel sources of the loaded library"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_executed_flops.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_executed_flops.json")) as f:
             ex = json.load(f)
         if ex.get("csrc_sha256_16") != csrc_hash():
-            return None, "profiles/r05_executed_flops.json was taken from other kernel sources than this build: not reported"
-        return ex, "profiles/r05_executed_flops.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512, serial schedule, separate run)"
+            return None, "profiles/r06_executed_flops.json was taken from other kernel sources than this build: not reported"
+        return ex, "profiles/r06_executed_flops.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512, serial schedule, separate run)"
     except Exception:
         return None, None
 
@@ -313,6 +337,51 @@ def all_configs():
     return out
 
 
+def shard_steps(cfg):
+    """Strong-scaling ceiling measured on ONE GPU: the flat data-parallel training step (ELBO + gradient, one all-reduce of the whole
+    gradient buffer, Adam — doubly_stochastic_dgp.distributed) on the per-rank shards of the global 1000-row minibatch at N = 2 / 4 / 8,
+    over a ONE-RANK RCCL group: the collective is an identity, everything around it is timed.  What an N-GPU run adds is the
+    all-reduce's own latency (2.3 MB over xGMI).  200 steps, best of three."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from doubly_stochastic_dgp.distributed import attach
+    created = False
+    out = []
+    try:
+        if not dist.is_initialized():
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+            created = True
+        for world in (2, 4, 8):
+            rows = cfg["mb"] // world
+            model, _, _, _ = build_model(cfg, 0, 1, rows)
+            attach(model, 0, 1, bucketed=False)
+            for _ in range(20):
+                model.train_step(0.01)
+            reps = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    model.train_step(0.01)
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - t0) / 200 * 1e3)
+            out.append(dict(n_gpus_modelled=world, rows_per_rank=rows, ms_per_step_flat_1rank_rccl=round(min(reps), 4),
+                            steps_per_s_ceiling=round(1e3 / min(reps), 1)))
+            del model
+            torch.cuda.empty_cache()
+    except Exception as e:                      # a secondary line: never takes the contract's JSON line down
+        out.append(dict(error=f"{type(e).__name__}: {e}"))
+    finally:
+        if created:
+            dist.destroy_process_group()
+    return out
+
+
 def csrc_hash():
     """sha256 over the kernel sources: ties a committed PMC traffic profile to the build it was taken from"""
     import hashlib
@@ -446,9 +515,11 @@ def main():
         for _ in range(nprof):
             model.train_step(0.01)
         torch.cuda.synchronize()
-        for name in ("layer_fwd", "layer_bwd", "wgrad", "gemm", "potrf"):
+        for name in ("layer_fwd", "layer_bwd", "layer_last", "wgrad", "gemm", "potrf"):
             ms, cnt = ctx.prof_read(name)
             prof[name] = dict(ms_per_step=ms / nprof, launches_per_step=cnt / nprof)
+        prof["layer_last"]["note"] = ("forward chain + Gaussian likelihood + reverse pass of the last (D_out = 1) layer in one launch "
+                                      "(csrc/layer_last.hip); 0 launches: the two chains ran instead")
         prof["potrf"]["note"] = ("the fused head launch k_head: parameter transforms + Ku + Cholesky + inverse factor + N(0,1) draws + "
                                  "minibatch gather")
         ctx.prof_enable(False)
@@ -481,14 +552,11 @@ def main():
     launches_per_step = (lib.dsdgp_launch_count() - l0) / 10.0
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the CPU baseline (~10 s of host work) sits BETWEEN the two halves of the GPU work: the timed region above, the long
-        # steady-state loop below (a monitor sampling the GPU every few seconds sees it busy on either side)
         cpu_base = cpu_baseline(cfg, X, Y, Z)
     if not args.no_extras:
         # steady-state distribution: single steps bracketed by events on the launch stream (ctx stream == torch's current stream),
-        # in batches of 300, for >= 6 s at N = 1 (about 10^4 steps) / one batch otherwise
-        budget_s = 6.0 if (world == 1 and not args.no_cpu_baseline) else 0.0
-        nb_ev = 300
+        # a fixed sample of four batches of 300
+        nb_ev, n_batches = 300, 4
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nb_ev + 1)]
         for _ in range(20):
             model.train_step(0.01)
@@ -501,7 +569,7 @@ def main():
                 evs[i + 1].record()
             torch.cuda.synchronize()
             all_ts.append(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nb_ev)]))
-            if time.perf_counter() - t_s0 >= budget_s or len(all_ts) >= 60:
+            if len(all_ts) >= n_batches:
                 break
         ts = np.concatenate(all_ts)
         steady = dict(n=int(ts.size), median_ms=round(float(np.median(ts)), 4), p10_ms=round(float(np.percentile(ts, 10)), 4),
@@ -509,6 +577,9 @@ def main():
                       wall_s=round(time.perf_counter() - t_s0, 2),
                       note="per-step HIP events on the launch stream, run after the timed region (and after the CPU baseline at N = 1); "
                            "the gradient all-reduce (N>1) is inside each step")
+    shards = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        shards = shard_steps(cfg)
     rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
@@ -520,14 +591,14 @@ def main():
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (2*FETCH + WRITE, the gfx950
     # correction of MI355X_MICROARCH.md) and labelled with its source; null when no current profile is shipped
     traffic, traffic_source = {}, None
-    for cand in ("r05_pmc_traffic.json",):
+    for cand in ("r06_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)
             if pmc.pop("csrc_sha256_16", None) != csrc_hash():
                 traffic_source = f"profiles/{cand} was taken from other kernel sources than this build: traffic not reported"
                 break
-            for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("wgrad", "k_wgrad")):
+            for name, key in (("layer_fwd", "k_layer_fwd_sm"), ("layer_bwd", "k_layer_bwd_sm"), ("layer_last", "k_layer_last"), ("wgrad", "k_wgrad")):
                 hit = [v for k, v in pmc.items() if k.startswith(key)]
                 if hit:
                     n_l = sum(h["launches"] for h in hit)
@@ -538,17 +609,19 @@ def main():
             pass
     roof_all = {}
     fx = executed_flops_chain(cfg["M"], layer_shapes(cfg_local))
-    for name in ("layer_fwd", "layer_bwd", "wgrad"):
-        if name not in prof:
+    fused_last = prof.get("layer_last", {}).get("launches_per_step", 0) > 0
+    fl_slot, fx_slot = slot_flops(fl, fx, fused_last)
+    for name in ("layer_fwd", "layer_bwd", "layer_last", "wgrad"):
+        if name not in prof or name not in fl_slot:
             continue
         ms = prof[name]["ms_per_step"]
-        ach = fl[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        achx = fx[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        ach = fl_slot[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        achx = fx_slot[name] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof_all[name] = dict(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                               frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic.get(name), traffic_source=traffic_source,
                               ms_per_step=round(ms, 4), launches_per_step=prof[name]["launches_per_step"],
-                              algorithmic_gflop_per_step=round(fl[name] / 1e9, 3),
-                              executed_gflop_per_step=round(fx[name] / 1e9, 3), frac_executed=round(achx / FP64_MFMA_PEAK_TFLOPS, 4),
+                              algorithmic_gflop_per_step=round(fl_slot[name] / 1e9, 3),
+                              executed_gflop_per_step=round(fx_slot[name] / 1e9, 3), frac_executed=round(achx / FP64_MFMA_PEAK_TFLOPS, 4),
                               executed_note="MFMA instructions the launch issues x 2048 flops, counted from the kernels' loop structure "
                                             "(bench.executed_flops_chain): dense backward d-loop, 16-row triangular granularity, "
                                             "symmetric / alg_g savings of the weight-gradient products")
@@ -576,7 +649,7 @@ def main():
         ex, ex_src = executed_profile()
         step_ex = ex["configs"]["cfg2"]["executed_gflop_per_step"] if (ex and world == 1 and "cfg2" in ex.get("configs", {})) else None
         if step_ex is None:       # chains + weight-gradient products only (the M x M algebra and the head launch are ~3 % more at this shape)
-            step_ex = round(sum(fx.values()) / 1e9, 3)
+            step_ex = round(sum(fx_slot.values()) / 1e9, 3)
             ex_src = "static count of the chain + weight-gradient launches (bench.executed_flops_chain); M x M algebra and head not included"
         step_ex_frac = round(step_ex * 1e9 * steps_per_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
         weak = args.scaling == "weak" and world > 1
@@ -596,6 +669,10 @@ def main():
                                              ("one all-reduce per layer (bucketed)" if model._dist_buckets()["on"] else "one flat all-reduce"))},
             "roofline": roofline, "roofline_all": roof_all, "sub_rooflines": sub, "all_configs": others, "kernel_ms_per_step": prof,
             "step_time": steady, "launches_per_step": launches_per_step,
+            "shard_steps": shards,
+            "shard_steps_note": "flat data-parallel step of the 500 / 250 / 125-row shards (N = 2 / 4 / 8 of the global 1000-row minibatch) on "
+                                "this one GPU over a one-rank RCCL group: an N-GPU strong-scaling run cannot beat 1 / (this + the 2.3 MB "
+                                "all-reduce's latency)",
             "step_fraction_of_fp64_peak": round(algorithmic_flops(dict(cfg, mb=mb_local * world))["step"] * steps_per_s / world
                                                 / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
             "step_executed_gflop": step_ex, "step_fraction_executed": step_ex_frac, "step_executed_source": ex_src,
