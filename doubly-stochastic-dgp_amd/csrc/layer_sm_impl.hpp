@@ -256,12 +256,16 @@ template <int NQ, int MPB, int NW>
 __device__ __forceinline__ void sqdist_chunk_masked(const double* __restrict__ zs, const double* xs, int Din, int j0, int jn, int wave,
                                                     int g, int c, d4 (&zx)[NQ], double (&zsq)[NQ], double& xx) {
   for (int kk = 0; kk < jn; kk += 16) {
+    // dimension kk + 4 s + g in k-step s (round 6; 4 g + s before): a group with fewer than 16 dimensions left — D_in = 8 is two k-steps —
+    // issues only the k-steps that carry data.  With 4 g + s every step of a D_in <= 8 layer was half zeros: four MFMAs and four Z loads
+    // per row block where two do.  (Any bijection of the 16 dimensions onto (g, s) is allowed as long as A and B agree.)
+    const int ns = (jn - kk >= 16) ? 4 : (jn - kk + 3) >> 2;           // wave-uniform
     double b[4];
     int jc[4];
     bool in[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int j = kk + 4 * g + s;
+      const int j = kk + 4 * s + g;
       in[s] = j < jn;
       jc[s] = in[s] ? j : jn - 1;
       const double v = xs[c * (jn + 1) + jc[s]];
@@ -276,13 +280,17 @@ __device__ __forceinline__ void sqdist_chunk_masked(const double* __restrict__ z
       double av[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const double v = zr[jc[s]];
-        av[s] = in[s] ? v : 0.0;
+        if (s < ns) {
+          const double v = zr[jc[s]];
+          av[s] = in[s] ? v : 0.0;
+        }
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        zx[q] = mfma_f64(av[s], b[s], zx[q]);
-        zsq[q] = fma(av[s], av[s], zsq[q]);
+        if (s < ns) {
+          zx[q] = mfma_f64(av[s], b[s], zx[q]);
+          zsq[q] = fma(av[s], av[s], zsq[q]);
+        }
       }
     }
   }
@@ -291,7 +299,7 @@ __device__ __forceinline__ void sqdist_chunk_masked(const double* __restrict__ z
 template <int NQ>
 __device__ __forceinline__ void sqdist_finish(const d4 (&zx)[NQ], const double (&zsq)[NQ], double xx, double* scratch, int wave, int g,
                                               int c, d4 (&r2)[NQ]) {
-  xx = sum_groups(xx);          // lane (g, c) covered the dimensions 4 g .. 4 g + 3 of every group of 16
+  xx = sum_groups(xx);          // lane (g, c) covered the dimensions g, 4 + g, 8 + g, 12 + g of every group of 16 (4 g .. 4 g + 3 in the wide path)
   double* zrow = scratch + wave * NQ * 16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {

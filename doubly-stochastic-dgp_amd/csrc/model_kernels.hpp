@@ -1042,7 +1042,7 @@ __global__ void k_adam(double* __restrict__ theta, const double* __restrict__ gr
 // row i: sum wk, Kbar_ii, sum_j wm_ij (z_iq - z_jq)^2), then the q_mu / q_sqrt gradient rows.  One WORKGROUP per inducing row: its
 // four waves share the row of Kbar, then split the input dimensions and the (output, column) pairs of the q_sqrt rows — a wave per
 // row walked ten dependent memory round trips one after the other (30 us).  grid (M_max, layers), 256 threads, mp_max doubles of LDS.
-__global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w, int mp_max) {
+__global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ layers, double* __restrict__ grad, double kl_w, int mp_max, int pre_on) {
   extern __shared__ __attribute__((aligned(16))) double asm_dyn[];
   __shared__ double sh[4];
   const LayerDev v = layers[blockIdx.y];
@@ -1053,6 +1053,41 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
   lptr wm = (lptr)asm_dyn;
   const int64_t MM = (int64_t)Mp * Mp;
   const double kvar = v.hyp[HYP_VAR];
+  // Round 6 — small layers (M <= 128, D_in <= 8, D_out M <= 1024: configs 1 / 2): everything the LATER phases read — the Z columns and
+  // thinz of the Z-gradient phase, the q_mu row, the q_sqrt row's P_d T_d / U_d / T_d — is requested here, before the first phase
+  // computes anything, from clamped addresses.  The phases then run on registers: the launch was five dependent memory round trips per
+  // workgroup (a 12 us launch on the critical tail of the step for a few hundred KB of data), now two.
+  const bool pre = pre_on && (M <= 128) && (Din <= 8) && (Dout * M <= 1024);
+  double pz[2][2] = {{0, 0}, {0, 0}}, pzi[2] = {0, 0}, ptz[2] = {0, 0}, ptz1 = 0.0, pq_t = 0.0, pq_n = 0.0;
+  double p4p[4] = {0, 0, 0, 0}, p4u[4] = {0, 0, 0, 0}, p4t[4] = {0, 0, 0, 0};
+  if (pre) {
+    gcptr Zp = (gcptr)v.Zp, thinz = (gcptr)v.thinz, thinq = (gcptr)v.thinq, n4 = (gcptr)v.n4, PT = (gcptr)v.PT, U = (gcptr)v.U, Tp = (gcptr)v.Tp;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = wave + 4 * u, qc = q < Din ? q : Din - 1;
+      pzi[u] = Zp[i * Din + qc];
+      ptz[u] = thinz[i * v.DinP16 + qc];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int j = lane + 64 * w;
+        pz[u][w] = Zp[(j < M ? j : M - 1) * Din + qc];
+      }
+    }
+    ptz1 = thinz[i * v.DinP16 + Din];
+    const int dq = tid < Dout ? tid : Dout - 1;
+    pq_t = thinq[i * v.DP16 + dq];
+    pq_n = n4[i * v.DP4 + dq];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int e = tid + 256 * u;
+      e = e < Dout * M ? e : Dout * M - 1;
+      const int d = e / M, j = e - d * M;
+      const int64_t p = d * MM + (int64_t)i * Mp + (j <= i ? j : i);
+      p4p[u] = PT[p];
+      p4u[u] = U[p];
+      p4t[u] = Tp[p];
+    }
+  }
   double a_sum = 0.0, tr = 0.0;
   for (int j = tid; j < M; j += 256) {
     const int64_t idx = (int64_t)i * Mp + j, idt = (int64_t)j * Mp + i;
@@ -1099,6 +1134,41 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
     hp[1] = tr;
   }
   const double* __restrict__ ils = v.hyp + HYP_ILS;
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = wave + 4 * u;
+      if (q >= Din) break;
+      const double zi = pzi[u];
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int j = lane + 64 * w;
+        if (j < M) {
+          const double df = zi - pz[u][w], wj = wm[j];
+          s1 = fma(wj, df, s1);
+          s2 = fma(wj * df, df, s2);
+        }
+      }
+      s1 = sum_wave(s1);
+      s2 = sum_wave(s2);
+      if (lane == 0) {
+        const double il2 = ils[q] * ils[q];
+        grad[v.off_Z + (int64_t)i * Din + q] = 4.0 * il2 * s1 - 2.0 * il2 * (ptz[u] - zi * ptz1);
+        hp[2 + q] = s2;
+      }
+    }
+    if (tid < Dout) grad[v.off_q_mu + (int64_t)i * Dout + tid] = pq_t + kl_w * pq_n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      if (e < Dout * M) {
+        const int d = e / M, j = e - d * M;
+        const double gq = 2.0 * p4p[u] + kl_w * (p4u[u] - (i == j ? 1.0 / p4t[u] : 0.0));
+        grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = (j <= i) ? gq : 0.0;
+      }
+    }
+  } else {
   for (int q = wave; q < Din; q += 4) {
     const double zi = v.Zp[i * Din + q];
     double s1 = 0.0, s2 = 0.0;
@@ -1123,6 +1193,7 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
     const int64_t p = d * MM + (int64_t)i * Mp + (j <= i ? j : i);
     const double gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
     grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = (j <= i) ? gq : 0.0;
+  }
   }
   // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
   if (v.meanAB) {

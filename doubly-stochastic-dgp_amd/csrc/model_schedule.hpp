@@ -463,7 +463,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       const int l = (int)(&St - m->L);
       const LayerDev* lay1 = m->layers_dev + l;
       DS_LAUNCH(k_asm_rows, dim3(St.dev.M, 1), dim3(256), (size_t)m->mp_max_all * sizeof(double), st, lay1, m->grad, kl_weight,
-                         m->mp_max_all);
+                         m->mp_max_all, m->force.asm_pre);
       FinArgs F{};
       AdamArgs A{};
       DS_LAUNCH(k_tail, dim3(1), dim3(256), 0, st, m->layers_dev, l, 1, m->grad, F, A);
@@ -634,7 +634,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   }
   if (m->tail_ok) {
     DS_LAUNCH(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
-                       kl_weight, m->mp_max_all);
+                       kl_weight, m->mp_max_all, m->force.asm_pre);
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
               m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,

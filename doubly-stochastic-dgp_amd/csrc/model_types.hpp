@@ -164,7 +164,7 @@ struct dsdgp_model {
   // white_fwd = 0: forward-only evaluations in plain coordinates.  last_fuse = 0: the last layer of a training step as its two chains
   // instead of the fused launch (layer_last.hip); last_min_blocks: fewest row blocks for which the fused launch is taken.  gemm_mp: smallest padded inducing count whose layers take the
   // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1, asm_pre = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -197,6 +197,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "gemm_mp") m->force.gemm_mp = v;
       else if (k == "last_fuse") m->force.last_fuse = v;
       else if (k == "last_min_blocks") m->force.last_min_blocks = v;
+      else if (k == "asm_pre") m->force.asm_pre = v;
     }
     pos = end + 1;
   }
