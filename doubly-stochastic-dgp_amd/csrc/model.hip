@@ -300,6 +300,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
   DS_HIP(hipEventCreateWithFlags(&m->ev_fork, evf));
   DS_HIP(hipEventCreateWithFlags(&m->ev_prep_side, evf));
   DS_HIP(hipEventCreateWithFlags(&m->ev_z, evf));
+  DS_HIP(hipEventCreateWithFlags(&m->ev_kinv, evf));
   m->prepared = false;
   m->plan_n = -1;
   m->plan_S = -1;
@@ -317,7 +318,7 @@ extern "C" int dsdgp_model_destroy(dsdgp_model* m) {
     }
     hipEventDestroy(m->ev_side);
 
-    hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z);
+    hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_prep_side); hipEventDestroy(m->ev_z); hipEventDestroy(m->ev_kinv);
     for (int l = 0; l < m->desc.L; ++l) {
       if (l == 0) bigchol_free(m->big_all);
       bigchol_free(m->L[l].big_k); bigchol_free(m->L[l].big_ngA); bigchol_free(m->L[l].big_ngT);

@@ -3,13 +3,15 @@
 // Part of the model translation unit.
 #pragma once
 // Side-stream overlap pays for its cross-stream events (a few microseconds each) only when the kernels are long enough:
-// tiny models (cfg 1: 100 rows, M = 50) are launch-latency-bound and run 40 % faster on a single stream.
+// tiny models (cfg 1: 100 rows, M = 50: n S Mp = 6400) are launch-latency-bound and run 40 % faster on a single stream.  The threshold
+// (DSDGP_FORCE overlap_min, default 2^18; 2^20 until round 6) sits below the 125- and 250-row shards of config 2's strong-scaling run
+// (n S Mp = 3.2e5 / 6.4e5): overlapped they take 0.297 / 0.342 ms per data-parallel step against 0.317 / 0.368 on one stream.
 static bool overlap_on(const dsdgp_model* m, int64_t n, int S) {
   const char* no = getenv("DSDGP_NO_OVERLAP");   // read per call so that a profiler can serialise the kernels
   if (!m->overlap || (no && atoi(no))) return false;
   int mp_max = 0;
   for (int l = 0; l < m->desc.L; ++l) mp_max = std::max(mp_max, (int)m->L[l].dev.Mp);
-  return n * S * (int64_t)mp_max >= (int64_t)1 << 20;
+  return n * S * (int64_t)mp_max >= (int64_t)m->force.overlap_min;
 }
 
 // main stream waits for the parameter-only side work of the last prepare (no-op when nothing is pending)
@@ -111,6 +113,16 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     DS_LAUNCH(k_kl_part, dim3(klb, L), dim3(256), 0, st, m->layers_dev);
   }
   DS_HIP(hipGetLastError());
+  m->kinv_pending = false;
+  if (side && with_grad && !m->desc.white) {
+    // Ku^-1, S_d and Lu^-1 q_sqrt are in the launch above — everything the backward CHAINS read of the side stream's products (the
+    // rest — KS_d, U_d, n, U_d U_d^T — feeds the assembly at the end of the step).  The reverse pass waits for THIS event, long since
+    // signalled when the forward chains end; the whole side stream's work ends together with the last inner forward chain, and a
+    // just-in-time cross-stream wait there cost ~12 us of idle main stream in front of the first launch of the reverse pass
+    // (profiles/r06_timeline_step.txt).  The rest is covered by the join at the end of the reverse pass (the side stream is in order).
+    DS_HIP(hipEventRecord(m->ev_kinv, m->side));
+    m->kinv_pending = true;
+  }
   if (with_grad && !m->desc.white) {
     if (lq >= 0) {
       LayerState& Sq = m->L[lq];
@@ -447,7 +459,15 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
   const int L = m->desc.L;
   DS_TRY(ensure_plan(m, n, S));
   const bool overlap = overlap_on(m, n, S);
-  DS_TRY(join_prep(m));   // Ku^-1, S_d (and U, UU for the assembly below) come from the side stream
+  // Ku^-1, S_d (and KS, U, UU for the assembly below) come from the side stream.  In the overlapped schedule the chains wait for the event
+  // behind the first of those launches only (prepare_async: ev_kinv); the join with the side stream at the end of this function — which
+  // the assembly launches follow — covers the rest.  The per-layer tails (buckets) read KS / U inside the loop: they take the full join.
+  const int gfirst0 = m->desc.white ? 0 : m->grad_first;
+  const bool tail_in_loop = (m->bucket_fn != nullptr && m->tail_ok && gfirst0 == 0 && !m->fuse_adam.on) ||
+                            (overlap && m->force.pipe_tail != 0 && !m->desc.white);
+  const bool kinv_only = overlap && !tail_in_loop && !m->desc.white && m->kinv_pending && m->side_pending;
+  if (kinv_only) DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_kinv, 0));
+  else DS_TRY(join_prep(m));
   const int gfirst = m->desc.white ? 0 : m->grad_first;     // reverse mode stops below this layer (dsdgp_model_set_grad_first_layer)
   // data-parallel buckets: every layer's reduction, products, assembly and hyper-parameter gradients right behind its weight-gradient
   // products, then the caller's collective on that layer's segment of the gradient, on the stream the segment was produced on — the
@@ -585,6 +605,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     if (!m->fin.done && !m->tail_ok) DS_TRY(launch_finalize(m, m->side));
     DS_HIP(hipEventRecord(m->ev_side, m->side));
     DS_HIP(hipStreamWaitEvent(ctx->stream, m->ev_side, 0));
+    m->side_pending = false;      // (in order behind the parameter products: this join is theirs too)
 
   }
   if (!pipelined) {

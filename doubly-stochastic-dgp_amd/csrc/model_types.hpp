@@ -110,6 +110,8 @@ struct dsdgp_model {
   GemmProblem* gp_pt;   // P_d T_d (the only KL/q_sqrt GEMM that depends on the backward pass)
   int n_pt = 0, t_pt = 0;
   hipEvent_t ev_fork, ev_prep_side, ev_z;
+  hipEvent_t ev_kinv;           // side stream, behind the forward-side parameter products (Ku^-1 ...): all the fused last-layer launch needs of them
+  bool kinv_pending = false;
   int32_t* gemm_order = nullptr;   // device pool of the longest-processing-time tile lists of the grouped M x M launches (gemm_plan_lpt)
   int64_t gemm_order_cap = 0, gemm_order_used = 0;
   GemmLayerWs gws{};           // scratch of the GEMM-formulated layers (one set per model: the layers run one after the other)
@@ -164,7 +166,7 @@ struct dsdgp_model {
   // white_fwd = 0: forward-only evaluations in plain coordinates.  last_fuse = 0: the last layer of a training step as its two chains
   // instead of the fused launch (layer_last.hip); last_min_blocks: fewest row blocks for which the fused launch is taken.  gemm_mp: smallest padded inducing count whose layers take the
   // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1, asm_pre = 1; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1, asm_pre = 1, overlap_min = 1 << 18; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -198,6 +200,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "last_fuse") m->force.last_fuse = v;
       else if (k == "last_min_blocks") m->force.last_min_blocks = v;
       else if (k == "asm_pre") m->force.asm_pre = v;
+      else if (k == "overlap_min") m->force.overlap_min = v;
     }
     pos = end + 1;
   }

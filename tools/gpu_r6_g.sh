@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, batch g: chains wait for the Ku^-1 event only (no second join), overlap from n S Mp = 2^18: full suite, A/B, shards, timelines
+cd "$GRAFT_REPO_ROOT" || exit 1
+R=$PWD; O=$R/gpurun_out/r6g; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q -x > $O/t_all.log 2>&1; echo "pytest rc=$?" >> $O/summary.log; tail -4 $O/t_all.log >> $O/summary.log
+for rep in 1 2; do
+  echo "== base (round 5)" >> $O/summary.log
+  DSDGP_LIB_PATH=$R/tools/bin/libdsdgp_base.so timeout 400 python tools/ab_kernels.py 2 2>&1 | grep "^{" >> $O/summary.log
+  echo "== tree" >> $O/summary.log
+  timeout 400 python tools/ab_kernels.py 2 3 1 2>&1 | grep "^{" >> $O/summary.log
+done
+echo "== shards" >> $O/summary.log
+timeout 600 python tools/bench_shards.py 2>&1 | grep "^{" | cut -c1-200 >> $O/summary.log
+cd /tmp
+for rows in 1000 125; do
+  rm -rf /tmp/tl$rows
+  timeout 300 rocprofv3 --kernel-trace -d /tmp/tl$rows -o t -- python $R/tools/shard_timeline.py $rows > $O/run$rows.log 2>&1
+  DB=$(find /tmp/tl$rows -name "*.db" | head -1)
+  python $R/tools/timeline_dump.py $DB k_tail 3 > $O/step_$rows.txt
+done
+cat $O/summary.log $O/step_1000.txt $O/step_125.txt
