@@ -39,7 +39,7 @@ extern "C" int xstream_probe_run(void) {
   CK(hipMemset(cnt, 0, 64));
   unsigned long long* flag = nullptr;
   if (can) {
-    CK(hipExtMallocWithFlags((void**)&flag, 64, hipMallocSignalMemory));
+    CK(hipExtMallocWithFlags((void**)&flag, 8, hipMallocSignalMemory));
     CK(hipMemset(flag, 0, 8));
   }
   hipStream_t s1, s2;
