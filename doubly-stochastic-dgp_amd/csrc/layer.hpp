@@ -115,6 +115,13 @@ struct WgradJob {
   int32_t qrows16;      // rows of Q / 16 (= columns of the result / 16)
   int32_t ns_diag;      // sym: K splits of the (cheaper, 10/16) diagonal tiles; their tasks follow the off-diagonal ones
   int32_t pad;
+  // In-launch split-K reduction (round 6): with `fin` set the LAST of a tile's splits to arrive (ticket counter `tick[tile]`, zero between
+  // launches) adds the tile's partials in split order and writes rows < fin_rows, columns < fin_cols of the result (leading dimension
+  // fin_ld) — and, for sym, the mirror tile / the uncomputed upper blocks of a diagonal tile — so that no reduction launch follows the
+  // products.  One split: the tile goes from registers to `fin`, `out` is not touched.  NULL: partials only (k_reduce_grouped adds them).
+  double* fin;
+  int32_t* tick;
+  int32_t fin_ld, fin_rows, fin_cols, pad2;
 };
 
 // jobs_dev: device copy of `njobs` jobs with task_start filled (64 x 64 tiles, one workgroup per (job, split, tile) task)

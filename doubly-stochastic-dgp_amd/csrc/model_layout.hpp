@@ -123,6 +123,11 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
     S.bcnt = b.take<int>(512);
     S.lq = b.take<GemmProblem>(12);
     S.wj = b.take<WgradJob>(d.D_out + 4);
+    {
+      const int tq = (int)ceil_div(v.DP16 / 16, 4), tz = (int)ceil_div(v.DinP16 / 16, 4);
+      S.wtick_cap = (d.D_out + 1) * ti * ti + ti * (tq + tz) + tz * tq + 16;
+      S.wtick = b.take<int32_t>(S.wtick_cap);
+    }
     S.ng_gp = b.take<GemmProblem>(4);
     S.ng_items = b.take<PotrfItem>(d.D_out);
   }

@@ -338,6 +338,20 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     std::vector<WgradJob> jobsA, jobsB;
     std::vector<RedJob> redA, redB;
     int startA = 0, startB = 0;
+    // in-launch split-K reduction (WgradJob::fin): a job's tiles draw their tickets from St.wtick, the result goes where the reduction
+    // launch used to put it and the job leaves k_reduce_grouped's list.  By default only where the plan has ONE split (large M: more
+    // tiles than workgroup slots — the "reduction" was a copy-and-mirror pass over every P_d): the tile goes from registers to its
+    // place(s) with no partial, no ticket.  With several splits every workgroup of the launch would wait for its partial's write
+    // acknowledgement and draw a ticket before it can leave — measured at config 2 (23 splits of ~17 us tasks, wg_red = 2): the three
+    // product launches 0.114 -> 0.294 ms per step, the step 0.510 -> 0.618 ms; config 3 +2 %.  (wg_red = 0: never; 2: always — parity tests.)
+    const bool wfuse = m->force.wg_red >= 2 || (m->force.wg_red == 1 && ns == 1);
+    int tick_off = 0;
+    auto fuse = [&](WgradJob& J, double* fin, int fin_ld, int fin_rows, int fin_cols) {
+      if (!wfuse) return;
+      J.fin = fin; J.fin_ld = fin_ld; J.fin_rows = fin_rows; J.fin_cols = fin_cols;
+      J.tick = St.wtick + tick_off;
+      tick_off += J.sym ? J.ti * (J.ti + 1) / 2 : J.ti * J.tj;
+    };
     // ---- A jobs: operands from the forward chain (A, [X^T;1]) and from the producer of this layer's upstream adjoints (VB, MB)
     for (int j = 1; j <= v.D_out; ++j) {
       WgradJob J{};
@@ -348,18 +362,25 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.sym = 1; J.qrows16 = Mw / 16;                     // P_d = sum_r vbar_d a a^T is symmetric
       J.ns_diag = ns_diag; J.pad = 0;
       startA += ns * n_off + ns_diag * ti;
+      fuse(J, v.bigred + (int64_t)j * MM, v.Mp, v.Mp, v.Mp);
       jobsA.push_back(J);
-      redA.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, v.Mp, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
+      if (!wfuse) redA.push_back(RedJob{J.out, v.bigred + (int64_t)j * MM, MM, ns, 0, 0, v.Mp, 16, MMw, Mw, v.Mp});   // mirror at 16-block granularity
     }
-    jobsA.push_back(WgradJob{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, startA, 0, v.DP16 / 16, 0, 0});      // A mbar^T -> q_mu
+    {
+      WgradJob J{St.A, St.MB, nullptr, out_q, ti, tjq, v.DP16, startA, 0, v.DP16 / 16, 0, 0};      // A mbar^T -> q_mu
+      fuse(J, v.thinq, v.DP16, v.Mp, v.DP16);
+      jobsA.push_back(J);
+    }
     startA += ns * ti * tjq;
-    redA.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DP16, 0, 0});
+    if (!wfuse) redA.push_back(RedJob{out_q, v.thinq, (int64_t)v.Mp * v.DP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DP16, 0, 0});
     if (St.mean_grad) {
       // trainable Linear mean function: d loss / d [A ; b] = [X ; 1]^T MB^T  (XT1 is zero-padded to whole 16*NI-row tiles)
       const int tim = ceil_div(v.DinP16 / 16, NI), tjm = ceil_div(v.DP16 / 16, NI);
-      jobsA.push_back(WgradJob{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, startA, 0, v.DP16 / 16, 0, 0});
+      WgradJob J{St.XT1, St.MB, nullptr, St.part_mean, tim, tjm, v.DP16, startA, 0, v.DP16 / 16, 0, 0};
+      fuse(J, v.meanAB, v.DP16, 16 * NI * tim, v.DP16);
+      jobsA.push_back(J);
       startA += ns * tim * tjm;
-      redA.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, ns, 0, 0, 0, 0, (int64_t)16 * NI * tim * v.DP16, 0, 0});
+      if (!wfuse) redA.push_back(RedJob{St.part_mean, v.meanAB, (int64_t)16 * NI * tim * v.DP16, ns, 0, 0, 0, 0, (int64_t)16 * NI * tim * v.DP16, 0, 0});
     }
     // ---- B jobs: operands from this layer's backward chain (E, GW)
     if (!v.alg_g) {
@@ -369,12 +390,17 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
       J.ti = ti; J.tj = ti; J.ldo = Mw; J.task_start = startB;
       J.sym = 0; J.qrows16 = Mw / 16; J.ns_diag = ns_diag; J.pad = 0;
       startB += ns * ti * ti;
+      fuse(J, v.bigred, v.Mp, v.Mp, v.Mp);
       jobsB.push_back(J);
-      redB.push_back(RedJob{J.out, v.bigred, MM, ns, 0, 0, 0, 16, MMw, Mw, v.Mp});
+      if (!wfuse) redB.push_back(RedJob{J.out, v.bigred, MM, ns, 0, 0, 0, 16, MMw, Mw, v.Mp});
     }
-    jobsB.push_back(WgradJob{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, startB, 0, v.DinP16 / 16, 0, 0});   // GW [X|1]^T -> Z
+    {
+      WgradJob J{St.GW, St.XT1, nullptr, out_z, ti, tjz, v.DinP16, startB, 0, v.DinP16 / 16, 0, 0};   // GW [X|1]^T -> Z
+      fuse(J, v.thinz, v.DinP16, v.Mp, v.DinP16);
+      jobsB.push_back(J);
+    }
     startB += ns * ti * tjz;
-    redB.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
+    if (!wfuse) redB.push_back(RedJob{out_z, v.thinz, (int64_t)v.Mp * v.DinP16, ns, 0, 0, 0, 0, (int64_t)Mw * v.DinP16, 0, 0});
     redB.push_back(RedJob{St.hyp_part, v.hyp_red, (int64_t)v.D_in + 2, St.gemm ? layer_gemm_hyp_parts(ld, v.Mp) : (int)sm_hyp_parts(ld, v.Mp, v.D_in), 0, 1, 0, 0, (int64_t)v.D_in + 2, 0, 0});
     // one list [A | B] with cumulative task numbers: one launch per layer
     std::vector<WgradJob> jobs(jobsA);
@@ -391,6 +417,11 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
     red.insert(red.end(), redA.begin(), redA.end());
     red.insert(red.end(), redB.begin(), redB.end());
     St.red_n = (int)red.size() - St.red_off;
+    if (tick_off > St.wtick_cap) {
+      dsdgp_set_error("internal: weight-gradient ticket list overflow (%d > %d)", tick_off, St.wtick_cap);
+      return DSDGP_ERR_WORKSPACE;
+    }
+    DS_HIP(hipMemsetAsync(St.wtick, 0, (size_t)St.wtick_cap * sizeof(int32_t), ctx->stream));
     // diagonal tiles fill only their first ns_diag partial slots: the rest must read as zero under the new plan
     DS_HIP(hipMemsetAsync(St.part_big, 0, (size_t)St.nsplit_big_max * (1 + v.D_out) * MMw * sizeof(double), ctx->stream));
     DS_HIP(hipMemcpyAsync(St.wj, jobs.data(), jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, ctx->stream));
@@ -572,6 +603,8 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     } else if (skip_chain) { /* nothing downstream of this layer's chain is wanted */ }
     else if (St.gemm) DS_TRY(layer_bwd_gemm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white ? 1 : 0, m->gws));
     else DS_TRY(layer_bwd_sm_launch(ctx, b, v.Mp, v.kern_kind, m->desc.white));
+    // in-launch split-K reduction: what is left for k_reduce_grouped of this layer are the chain's hyper-parameter partials — added
+    // right behind the chain (a handful of workgroups beside the side stream's products) instead of in a launch behind the final join
     if (!overlap || on_main) {
       DS_TRY(launch_wgrad(St, ctx->stream));
       if (defer_upper)

@@ -63,6 +63,8 @@ struct LayerState {
   double* Xcat;     // [X_prop | F] handed to the next layer when input propagation is on (layers.py:105-110)
   int prop;
   double *part_big, *part_thin, *hyp_part;
+  int32_t* wtick = nullptr;      // arrival counters of the in-launch split-K reduction, one per (job, tile) of this layer's products
+  int wtick_cap = 0;
   int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
@@ -166,7 +168,7 @@ struct dsdgp_model {
   // white_fwd = 0: forward-only evaluations in plain coordinates.  last_fuse = 0: the last layer of a training step as its two chains
   // instead of the fused launch (layer_last.hip); last_min_blocks: fewest row blocks for which the fused launch is taken.  gemm_mp: smallest padded inducing count whose layers take the
   // GEMM-formulated passes (layer_gemm.hip) instead of the fused chains, 0 = never (parity tests force it onto small shapes).
-  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1, asm_pre = 1, overlap_min = 1 << 18; } force;
+  struct Force { int save_c = 1, cs_min_blocks = 160, cs_min_dout = 3, cs_max_dout = 1 << 20, wg_defer = -1, alg_g = -1, bwd_split = 1, pipe_tail = 0, head = 1, tail = 1, adj_fuse = 1, ext_ev = 1, lik_fuse = 1, red_ahead = 1, white_fwd = 1, gemm_mp = 512, last_fuse = 1, last_min_blocks = 1, asm_pre = 1, overlap_min = 1 << 18, wg_red = 1; } force;
 };
 static void parse_force(dsdgp_model* m) {
   const char* e = getenv("DSDGP_FORCE");
@@ -201,6 +203,7 @@ static void parse_force(dsdgp_model* m) {
       else if (k == "last_min_blocks") m->force.last_min_blocks = v;
       else if (k == "asm_pre") m->force.asm_pre = v;
       else if (k == "overlap_min") m->force.overlap_min = v;
+      else if (k == "wg_red") m->force.wg_red = v;
     }
     pos = end + 1;
   }

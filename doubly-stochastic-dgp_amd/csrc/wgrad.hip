@@ -101,9 +101,11 @@ __device__ __forceinline__ void wgrad_loop_rolling(gcptr Pp, gcptr Qp, gcptr sca
 // partials of a one-wave-per-task form at the same wave-level parallelism (fp64 MFMA needs >= 2 waves per SIMD for its pipe rate).
 // Forms measured slower and removed in round 3: one wave per task, 32 x 32 tiles, 128 x 128 tiles staged through LDS.
 template <int NI, int NJ>
-__global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
+__global__ __launch_bounds__(256, 2) void k_wgrad_coop(const WgradJob* __restrict__ jobs, int njobs, int nsplit, int64_t ld,
                                                     int64_t Rp, int total_tasks) {
-  __shared__ double red[2 * NI * NJ * 4 * 64];
+  // [2][NS][64] accumulator hand-over of the four waves; the in-launch reduction parks the finished 64 x 65 tile in the second half
+  __shared__ double red[2 * NI * NJ * 4 * 64 + 128];
+  __shared__ int s_ticket;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int w = blockIdx.x;
@@ -183,20 +185,118 @@ __global__ __launch_bounds__(256) void k_wgrad_coop(const WgradJob* __restrict__
         for (int t = 0; t < 4; ++t) r[((ii * NJ + jj) * 4 + t) * 64] = acc[ii][jj][t];
   }
   __syncthreads();
-  if (wave != 0) return;
   const double* r = red + lane;
   const int rowsP = 16 * NI * J.ti;
-  gptr o = (gptr)(J.out + (int64_t)split * rowsP * J.ldo);
+  if (!J.fin) {
+    if (wave != 0) return;
+    gptr o = (gptr)(J.out + (int64_t)split * rowsP * J.ldo);
 #pragma unroll
-  for (int ii = 0; ii < NI; ++ii)
+    for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-      if (jj < njv && !(diag && jj > ii)) {
+      for (int jj = 0; jj < NJ; ++jj)
+        if (jj < njv && !(diag && jj > ii)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] =
-              acc[ii][jj][t] + r[((ii * NJ + jj) * 4 + t) * 64];
+          for (int t = 0; t < 4; ++t)
+            o[(int64_t)(16 * (NI * tile_i + ii) + g + 4 * t) * J.ldo + 16 * (NJ * tile_j + jj) + c] =
+                acc[ii][jj][t] + r[((ii * NJ + jj) * 4 + t) * 64];
+        }
+    return;
+  }
+  // ---- in-launch split-K reduction (WgradJob::fin).  The workgroup's tile goes to LDS first (T, 64 x 65: the second half of `red`, free since
+  // wave 1 took wave 3's accumulators) — the accumulators are dead from here on — and everything below moves whole 512-byte rows of it:
+  // thread (wave, lane) owns column `lane` of the rows wave + 4 k.
+  static_assert(NI == 4 && NJ == 4, "tile staging assumes 64 x 64 tiles");
+  double* T = red + NS * 64;
+  if (wave == 0) {
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (jj < njv && !(diag && jj > ii)) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) T[(16 * ii + g + 4 * t) * 65 + 16 * jj + c] = acc[ii][jj][t] + r[((ii * NJ + jj) * 4 + t) * 64];
+        }
+  }
+  __syncthreads();
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  const int cc = lane;
+  // blocks of the tile that exist: the first njv column blocks; on or below the block diagonal for the diagonal tile of a symmetric result
+  const bool col_ok = cc < 16 * njv;
+  if (ns_eff > 1) {
+    // hand-over without fences (the d-split of the backward chain, layer_sm_impl.hpp: merge_split): partials out as 8-byte agent-scope
+    // stores, one s_waitcnt before the ticket, agent-scope loads by the last arrival — valid across XCDs on their own
+    double* ob = J.out + (int64_t)split * rowsP * J.ldo + (int64_t)(64 * tile_i) * J.ldo + 64 * tile_j;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int rr = wu + 4 * k;
+      if (col_ok && !(diag && (cc >> 4) > (rr >> 4)))
+        __hip_atomic_store(ob + (int64_t)rr * J.ldo + cc, T[rr * 65 + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tix = J.sym ? (tile_i == tile_j ? J.ti * (J.ti - 1) / 2 + tile_i : tile_i * (tile_i - 1) / 2 + tile_j) : tile_i * J.tj + tile_j;
+      const int tk = __hip_atomic_fetch_add(J.tick + tix, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == ns_eff - 1) __hip_atomic_store(J.tick + tix, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every split has arrived
+      s_ticket = tk;
+    }
+    __syncthreads();
+    if (s_ticket != ns_eff - 1) return;
+    // last arrival: the tile's partials added in split order, RB splits of loads in flight (uniform base + lane offset: a 64-bit
+    // pointer per load would take the batch's registers twice over)
+    constexpr int RB = 2;      // (more in flight would spill: this path is the non-default one, see ensure_plan)
+    const double* ub = J.out + (int64_t)(64 * tile_i) * J.ldo + 64 * tile_j;
+    const int64_t ps = (int64_t)rowsP * J.ldo;
+    double sum[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum[k] = 0.0;
+    for (int s0 = 0; s0 < ns_eff; s0 += RB) {
+      double x[RB][16];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int sp = s0 + u < ns_eff ? s0 + u : ns_eff - 1;
+        const double* us = ub + sp * ps;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int rr = wu + 4 * k;
+          x[u][k] = (col_ok && !(diag && (cc >> 4) > (rr >> 4))) ? __hip_atomic_load(us + (int64_t)rr * J.ldo + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        if (s0 + u < ns_eff) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sum[k] += x[u][k];
+        }
+    }
+    // (every wave is past the barrier behind its reads of T)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[(wu + 4 * k) * 65 + cc] = sum[k];
+    __syncthreads();
+  }
+  {
+    // a wave instruction stores one 512-byte row of the tile; the mirror tile reads T transposed (odd stride: conflict-free)
+    const int gc = 64 * tile_j + cc;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int rr = wu + 4 * k;
+      const int gr = 64 * tile_i + rr;
+      if (gr < J.fin_rows && gc < J.fin_cols) {
+        // diagonal tile of a symmetric result: the blocks above the block diagonal were not formed — they mirror the ones below
+        const double v = (diag && (cc >> 4) > (rr >> 4)) ? T[cc * 65 + rr] : T[rr * 65 + cc];
+        J.fin[(int64_t)gr * J.fin_ld + gc] = v;
+      }
+    }
+    if (J.sym && !diag) {
+      const int mc = 64 * tile_i + cc;      // mirror tile (tile_j, tile_i): element (rr, cc) = T[cc][rr]
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+        const int rr = wu + 4 * k;
+        const int mr = 64 * tile_j + rr;
+        if (mr < J.fin_rows && mc < J.fin_cols) J.fin[(int64_t)mr * J.fin_ld + mc] = T[cc * 65 + rr];
+      }
+    }
+  }
 }
 
 int wgrad_launch(dsdgp_ctx* ctx, const WgradJob* jobs_dev, int njobs, int total_tasks, int nsplit, int64_t ld, int64_t Rp,

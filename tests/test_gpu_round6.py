@@ -224,3 +224,39 @@ def test_last_layer_fused_launch_against_the_oracle_and_the_two_chains(monkeypat
 
 
 test_last_layer_fused_launch_against_the_oracle_and_the_two_chains.launches = {}
+
+
+# ---------------------------------------------------------------- split-K reduction inside the weight-gradient launch (wgrad.hip, WgradJob::fin)
+@pytest.mark.parametrize("force", ["wg_red=2", "wg_red=0", ""])
+@pytest.mark.parametrize("shape", [dict(N=300, D=5, M=100, S=5, L=3, kind="rbf", white=False),      # Mp = 112 on 128-row tiles: fin_rows < tile rows, several splits
+                                   dict(N=64, D=3, M=200, S=2, L=2, kind="matern52", white=False),  # 4 x 4 tiles of 64, few rows: one split by the plan
+                                   dict(N=150, D=4, M=130, S=3, L=2, kind="rbf", white=True),       # white: the adjoint of Lu reads E A^T (non-symmetric job)
+                                   dict(N=40, D=20, M=64, S=2, L=2, kind="rbf", white=False)])      # wide thin job (D_in + 1 > 16 columns), dense dl/dKu
+def test_in_launch_split_k_reduction_against_the_oracle(monkeypatch, force, shape):
+    """The weight-gradient launch adding its own split-K partials (last arrival per tile, tickets; `wg_red=2`: every plan), the direct
+    register -> result form of one-split plans (default) and the reduction launch (`wg_red=0`) give the oracle's gradient — symmetric
+    P_d tiles with their mirrors, the diagonal tiles' uncomputed upper blocks, thin jobs with partial column tiles, E A^T — and the
+    same ELBO bits on a second evaluation (tickets back at zero)."""
+    if force:
+        monkeypatch.setenv("DSDGP_FORCE", force)
+    else:
+        monkeypatch.delenv("DSDGP_FORCE", raising=False)
+    c = shape
+    rng = np.random.RandomState(c["N"] + c["M"])
+    N, D, M, S, L = c["N"], c["D"], c["M"], c["S"], c["L"]
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = (X[rng.permutation(N)[:M]] if M <= N else rng.randn(M, D)) + 0.02 * rng.randn(M, D)
+    spec, state, model = make_case(X, Y, Z, [kern_spec(c["kind"], D, 1.1, 1.2)] * L, S=S, num_data=3 * N, seed=6, white=c["white"])
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 2)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=3 * N)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-9)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-7 * (np.max(np.abs(g[k])) + 1e-12), (force, k)
+    g1 = {k: np.asarray(v).copy() for k, v in grads.items()}
+    got2 = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert got2 == got
+    g2 = model.engine().gradient_dict()
+    for k in g1:
+        assert np.array_equal(g1[k], np.asarray(g2[k])), (force, k)
