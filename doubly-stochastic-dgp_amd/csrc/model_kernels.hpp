@@ -64,9 +64,16 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
     __shared__ double tt[4][16][17];
     const int nt = Mp / 16, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tr = lane >> 2, tc = (lane & 3) * 4;
-    const int64_t ntile = (int64_t)v.D_out * nt * nt;
+    // only the tiles on or below the diagonal: above it Tp is zero and so is the mirror tile of TpT — constant since the workspace was
+    // zeroed at model creation (nothing else writes these arrays), so a third of this pass's 3 x 8 D_out Mp^2 bytes is never moved
+    const int ntl = nt * (nt + 1) / 2;
+    const int64_t ntile = (int64_t)v.D_out * ntl;
     for (int64_t tile = (int64_t)bx * 4 + wave; tile < ntile; tile += (int64_t)nprep * 4) {
-      const int d = (int)(tile / (nt * nt)), rem = (int)(tile % (nt * nt)), i0 = (rem / nt) * 16, j0 = (rem % nt) * 16;
+      const int d = (int)(tile / ntl), rem = (int)(tile % ntl);
+      int ti = (int)((sqrt(8.0 * rem + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= rem) ++ti;
+      while (ti * (ti + 1) / 2 > rem) --ti;
+      const int i0 = ti * 16, j0 = (rem - ti * (ti + 1) / 2) * 16;
       const int i = i0 + tr;
       double t4[4];
 #pragma unroll
@@ -89,8 +96,12 @@ __device__ void prep_body(const LayerDev& v, const double* __restrict__ theta, d
     } else {
     __shared__ double tt[16][17];
     const int nt = Mp / 16, ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-    for (int tile = bx; tile < v.D_out * nt * nt; tile += nprep) {
-      const int d = tile / (nt * nt), rem = tile % (nt * nt), i0 = (rem / nt) * 16, j0 = (rem % nt) * 16;
+    const int ntl = nt * (nt + 1) / 2;      // (tiles on or below the diagonal only: see above)
+    for (int tile = bx; tile < v.D_out * ntl; tile += nprep) {
+      const int d = tile / ntl, rem = tile % ntl;
+      int tb = 0;
+      while ((tb + 1) * (tb + 2) / 2 <= rem) ++tb;
+      const int i0 = tb * 16, j0 = (rem - tb * (tb + 1) / 2) * 16;
       const int i = i0 + ti, j = j0 + tj;
       const bool on = threadIdx.x < 256;          // (the head launch runs this body with 512 threads per block)
       const double t = (on && i < M && j <= i) ? theta[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] : 0.0;
