@@ -1199,11 +1199,42 @@ __global__ __launch_bounds__(256) void k_asm_rows(const LayerDev* __restrict__ l
   // q_mu: A mbar + kl_w Ku^-1 q_mu
   for (int d = tid; d < Dout; d += 256) grad[v.off_q_mu + (int64_t)i * Dout + d] = v.thinq[i * v.DP16 + d] + kl_w * v.n4[i * v.DP4 + d];
   // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii)); clamped (unconditional) loads so that several are in flight
-  for (int e = tid; e < Dout * M; e += 256) {
-    const int d = e / M, j = e - d * M;
-    const int64_t p = d * MM + (int64_t)i * Mp + (j <= i ? j : i);
-    const double gq = 2.0 * v.PT[p] + kl_w * (v.U[p] - (i == j ? 1.0 / v.Tp[p] : 0.0));
-    grad[v.off_q_sqrt + ((int64_t)d * M + i) * M + j] = (j <= i) ? gq : 0.0;
+  // Row i of every output d: thread t takes the columns t + 256 u.  The loads of output d + 1 are requested before the stores of output d
+  // (with store and loads in one loop body the stores — which may alias the loads for all the compiler knows — kept every iteration's
+  // loads behind the previous iteration's stores: D_out M / 256 dependent round trips per workgroup, 1.4 TB/s at config 5); columns
+  // right of the diagonal are stored as the zeros the contract promises without loading anything.
+  {
+    constexpr int NU = 4;                   // M <= 1024 on this path (fused tail: D_in <= WIDE_DIN, any M; larger M loops)
+    for (int j0 = 0; j0 < M; j0 += 256 * NU) {
+      double pt[NU], uu[NU], td = 0.0;
+      auto request = [&](int d) {
+        gcptr PT = (gcptr)(v.PT + d * MM + (int64_t)i * Mp), U = (gcptr)(v.U + d * MM + (int64_t)i * Mp);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int j = j0 + tid + 256 * u, jc = j <= i ? j : i;
+          pt[u] = PT[jc];
+          uu[u] = U[jc];
+        }
+        td = ((gcptr)v.Tp)[d * MM + (int64_t)i * Mp + i];
+      };
+      request(0);
+      for (int d = 0; d < Dout; ++d) {
+        double gq[NU];
+        const double tinv = 1.0 / td;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int j = j0 + tid + 256 * u;
+          gq[u] = (j <= i) ? 2.0 * pt[u] + kl_w * (uu[u] - (i == j ? tinv : 0.0)) : 0.0;
+        }
+        if (d + 1 < Dout) request(d + 1);
+        double* gr = grad + v.off_q_sqrt + ((int64_t)d * M + i) * M;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int j = j0 + tid + 256 * u;
+          if (j < M) gr[j] = gq[u];
+        }
+      }
+    }
   }
   }
   // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
