@@ -274,7 +274,11 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     const dsdgp_layer_desc& y = desc->layers[l];
     mark(y.off_Z, (int64_t)y.M * y.D_in, y.trainable_Z);
     mark(y.off_q_mu, (int64_t)y.M * y.D_out, y.trainable_q_mu);
-    mark(y.off_q_sqrt, (int64_t)y.D_out * y.M * y.M, y.trainable_q_sqrt);
+    // q_sqrt: the entries on or below the diagonal only — above it the parameter is structurally zero with a zero gradient (its Adam
+    // update is the identity), and at large M that half of theta is most of what the optimiser sweep would move
+    if (y.trainable_q_sqrt)
+      for (int64_t d = 0; d < y.D_out; ++d)
+        for (int64_t i = 0; i < y.M; ++i) mark(y.off_q_sqrt + (d * y.M + i) * y.M, i + 1, 1);
     // (2: entries whose gradient k_tail's hyper-parameter / likelihood blocks produce and, in a fused training step, update themselves)
     mark(y.off_kvar, 1, 2 * y.trainable_kvar);
     mark(y.off_kls, y.ard ? y.D_in : 1, 2 * y.trainable_kls);

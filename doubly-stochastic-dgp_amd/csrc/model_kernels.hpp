@@ -985,34 +985,63 @@ __device__ __forceinline__ void adam_sweep(double* __restrict__ theta, const dou
                                            double b2, double eps, double want, int64_t first, int64_t nthreads) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int64_t npair = n >> 1;
-  for (int64_t k = first; k < npair; k += nthreads) {
-    const d2 mk = *reinterpret_cast<const d2*>(mask + 2 * k), g = *reinterpret_cast<const d2*>(grad + 2 * k);
-    d2 mm = *reinterpret_cast<const d2*>(m + 2 * k), vv = *reinterpret_cast<const d2*>(v + 2 * k), th = *reinterpret_cast<const d2*>(theta + 2 * k);
-    bool on[2];
+  // Four pairs per thread and pass: their masks first (one batch of loads), then gradient, moments and parameters of the pairs that have
+  // an entry of this sweep (one batch), then the updates.  A pair without one — the structurally zero half of every q_sqrt above the
+  // diagonal is masked out: about half of a large model's entries — costs its 16 mask bytes instead of 64 read and 48 written.
+  for (int64_t k0 = first; k0 < npair; k0 += 4 * nthreads) {
+    d2 mk[4];
+    bool act[4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      on[e] = want == 0.0 ? mk[e] != 0.0 : mk[e] == want;
-      if (on[e]) {
-        const double mi = b1 * mm[e] + (1.0 - b1) * g[e];
-        const double vi = b2 * vv[e] + (1.0 - b2) * g[e] * g[e];
-        mm[e] = mi;
-        vv[e] = vi;
-        th[e] -= lr_t * mi / (sqrt(vi) + eps);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = k0 + u * nthreads;
+      mk[u] = *reinterpret_cast<const d2*>(mask + 2 * (k < npair ? k : first));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = k0 + u * nthreads;
+      act[u] = k < npair && (want == 0.0 ? (mk[u][0] != 0.0 || mk[u][1] != 0.0) : (mk[u][0] == want || mk[u][1] == want));
+    }
+    d2 g[4], mm[4], vv[4], th[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = k0 + u * nthreads;
+      if (act[u]) {
+        g[u] = *reinterpret_cast<const d2*>(grad + 2 * k);
+        mm[u] = *reinterpret_cast<const d2*>(m + 2 * k);
+        vv[u] = *reinterpret_cast<const d2*>(v + 2 * k);
+        th[u] = *reinterpret_cast<const d2*>(theta + 2 * k);
       }
     }
-    // an entry that is not this sweep's is NOT written back: in k_tail its owner (a hyper-parameter / likelihood block) updates it concurrently
-    if (on[0] && on[1]) {
-      *reinterpret_cast<d2*>(m + 2 * k) = mm;
-      *reinterpret_cast<d2*>(v + 2 * k) = vv;
-      *reinterpret_cast<d2*>(theta + 2 * k) = th;
-    } else {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+    for (int u = 0; u < 4; ++u) {
+      if (!act[u]) continue;
+      const int64_t k = k0 + u * nthreads;
+      bool on[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        on[e] = want == 0.0 ? mk[u][e] != 0.0 : mk[u][e] == want;
         if (on[e]) {
-          m[2 * k + e] = mm[e];
-          v[2 * k + e] = vv[e];
-          theta[2 * k + e] = th[e];
+          const double mi = b1 * mm[u][e] + (1.0 - b1) * g[u][e];
+          const double vi = b2 * vv[u][e] + (1.0 - b2) * g[u][e] * g[u][e];
+          mm[u][e] = mi;
+          vv[u][e] = vi;
+          th[u][e] -= lr_t * mi / (sqrt(vi) + eps);
         }
+      }
+      // an entry that is not this sweep's is NOT written back: in k_tail its owner (a hyper-parameter / likelihood block) updates it concurrently
+      if (on[0] && on[1]) {
+        *reinterpret_cast<d2*>(m + 2 * k) = mm[u];
+        *reinterpret_cast<d2*>(v + 2 * k) = vv[u];
+        *reinterpret_cast<d2*>(theta + 2 * k) = th[u];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if (on[e]) {
+            m[2 * k + e] = mm[u][e];
+            v[2 * k + e] = vv[u][e];
+            theta[2 * k + e] = th[u][e];
+          }
+      }
     }
   }
   if ((n & 1) && first == 0) {
