@@ -748,11 +748,27 @@ __global__ __launch_bounds__(256) void k_asm_kbar(const LayerDev* __restrict__ l
     double kb = 0.0, wm = 0.0, wk = 0.0;
     if (i < M && j < M) {
       double nn = 0.0, uu = 0.0;
-      if (!v.white)
-        for (int d = 0; d < v.D_out; ++d) {
-          nn += v.n4[i * v.DP4 + d] * v.n4[j * v.DP4 + d];
-          uu += v.UU[(int64_t)d * Mp * Mp + idx];
+      if (!v.white) {
+        // eight outputs of loads in flight (clamped, masked; the sums in the old order): the rolled loop walked D_out dependent round
+        // trips per element — 30 at config 4, where this launch moved 147 MB in 183 us
+        const int64_t MMk = (int64_t)Mp * Mp;
+        for (int d0 = 0; d0 < v.D_out; d0 += 8) {
+          double xu[8], xa[8], xb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int d = d0 + u < v.D_out ? d0 + u : v.D_out - 1;
+            xu[u] = v.UU[d * MMk + idx];
+            xa[u] = v.n4[i * v.DP4 + d];
+            xb[u] = v.n4[j * v.DP4 + d];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (d0 + u < v.D_out) {
+              nn += xa[u] * xb[u];
+              uu += xu[u];
+            }
         }
+      }
       if (v.white) {
         kb = 0.5 * (v.wX[i * Mp + j] + v.wX[j * Mp + i]);   // KL(white) does not depend on Ku (layers.py:243-244)
       } else {
@@ -760,10 +776,23 @@ __global__ __launch_bounds__(256) void k_asm_kbar(const LayerDev* __restrict__ l
         if (v.alg_g) {
           // sym(sum_r e a^T) = sum_d (GS_d + GS_d^T - P_d) + 1/2 (n t^T + t n^T),  t = A mbar^T (thinq)
           double gs = 0.0, nt = 0.0;
-          for (int d = 0; d < v.D_out; ++d) {
-            const int64_t o = (int64_t)d * Mp * Mp;
-            gs += (v.GS[o + idx] + v.GS[o + j * Mp + i]) - v.bigred[(int64_t)Mp * Mp + o + idx];
-            nt += v.n4[i * v.DP4 + d] * v.thinq[j * v.DP16 + d] + v.n4[j * v.DP4 + d] * v.thinq[i * v.DP16 + d];
+          const int64_t MMg = (int64_t)Mp * Mp;
+          for (int d0 = 0; d0 < v.D_out; d0 += 4) {      // (four outputs of loads in flight, the sums in the old order)
+            double g1[4], g2[4], pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int64_t o = (int64_t)(d0 + u < v.D_out ? d0 + u : v.D_out - 1) * MMg;
+              g1[u] = v.GS[o + idx];
+              g2[u] = v.GS[o + j * Mp + i];
+              pb[u] = v.bigred[MMg + o + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (d0 + u < v.D_out) {
+                const int d = d0 + u;
+                gs += (g1[u] + g2[u]) - pb[u];
+                nt += v.n4[i * v.DP4 + d] * v.thinq[j * v.DP16 + d] + v.n4[j * v.DP4 + d] * v.thinq[i * v.DP16 + d];
+              }
           }
           gsym = gs + 0.5 * nt;
         } else {
@@ -833,14 +862,51 @@ __global__ __launch_bounds__(256) void k_asm_params(const LayerDev* __restrict__
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)(gridDim.x - 1) * blockDim.x;
   const double* ils = v.hyp + HYP_ILS;
   // q_sqrt: 2 tril(P_d T_d) + kl_w (Ku^-1 T_d - diag(1/T_ii))
-  for (int64_t idx = t0; idx < (int64_t)Dout * M * M; idx += nth) {
-    const int d = (int)(idx / ((int64_t)M * M)), rem = (int)(idx % ((int64_t)M * M)), i = rem / M, j = rem % M;
-    double gq = 0.0;
-    if (j <= i) {
-      const int64_t p = ((int64_t)d * Mp + i) * Mp + j;
-      gq = 2.0 * v.PT[p] + kl_w * ((v.white ? v.Tp[p] : v.U[p]) - (i == j ? 1.0 / v.Tp[p] : 0.0));
+  // A WAVE per row (d, i) and 512 columns: lane l takes the eight columns 8 l .. 8 l + 7 — 16-byte loads of the part on or below the
+  // diagonal only, 16-byte stores of the whole row (zeros right of the diagonal).  The element-wise grid-stride loop paid two 64-bit
+  // divisions per element and walked its 15 elements per thread one dependent round trip after the other: 148 us at config 4 for
+  // 147 MB read + 147 MB written (1.9 TB/s).
+  {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = t0 >> 6, nw = nth >> 6;
+    const int nchunk = (M + 511) / 512;
+    const double* Uw = v.white ? v.Tp : v.U;
+    for (int64_t wi = w0; wi < (int64_t)Dout * M * nchunk; wi += nw) {
+      const int row = (int)(wi / nchunk), ch = (int)(wi - (int64_t)row * nchunk);
+      const int d = row / M, i = row - d * M;
+      const int j0 = 512 * ch + 8 * lane;
+      if (j0 >= M) continue;
+      gcptr PT = (gcptr)(v.PT + ((int64_t)d * Mp + i) * Mp + j0), U = (gcptr)(Uw + ((int64_t)d * Mp + i) * Mp + j0);
+      d2 pt[4], uu[4];
+      const bool any = j0 <= i;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pt[u] = (d2){0, 0};
+        uu[u] = (d2){0, 0};
+        if (any && j0 + 2 * u <= i) {       // (a pair that straddles the diagonal is loaded whole: Mp is even, the row is padded)
+          pt[u] = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(PT + 2 * u);
+          uu[u] = *reinterpret_cast<const d2 __attribute__((address_space(1)))*>(U + 2 * u);
+        }
+      }
+      const bool diag = i >= j0 && i < j0 + 8;
+      const double tinv = diag ? 1.0 / v.Tp[((int64_t)d * Mp + i) * Mp + i] : 0.0;
+      double* gr = grad + v.off_q_sqrt + (int64_t)row * M + j0;
+      const bool al = (((uintptr_t)gr) & 15) == 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double g0 = 0.0, g1 = 0.0;
+        const int ja = j0 + 2 * u, jb = ja + 1;
+        if (ja <= i) g0 = 2.0 * pt[u][0] + kl_w * (uu[u][0] - (ja == i ? tinv : 0.0));
+        if (jb <= i) g1 = 2.0 * pt[u][1] + kl_w * (uu[u][1] - (jb == i ? tinv : 0.0));
+        if (al && jb < M) {
+          *reinterpret_cast<d2*>(gr + 2 * u) = (d2){g0, g1};
+        } else {
+          if (ja < M) gr[2 * u] = g0;
+          if (jb < M) gr[2 * u + 1] = g1;
+        }
+      }
     }
-    grad[v.off_q_sqrt + idx] = gq;
   }
   // trainable Linear mean function: rows j < D_in of [X;1]^T MB^T are d loss / d A, row D_in is d loss / d b
   if (v.meanAB) {
@@ -871,7 +937,18 @@ __global__ __launch_bounds__(256) void k_asm_params(const LayerDev* __restrict__
       const int i = (int)(idx / Din), q = (int)(idx % Din);
       const double zi = v.Zp[i * Din + q];
       double s = 0.0;
-      for (int j = lane; j < M; j += 64) s = fma(v.wm[i * Mp + j], zi - v.Zp[j * Din + q], s);
+      for (int j0 = lane; j0 < M; j0 += 512) {      // (eight steps of loads in flight, the terms in the old order)
+        double w[8], z[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + 64 * u < M ? j0 + 64 * u : M - 1;
+          w[u] = v.wm[i * Mp + j];
+          z[u] = v.Zp[j * Din + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + 64 * u < M) s = fma(w[u], zi - z[u], s);
+      }
       s = sum_wave(s);
       if (lane == 0) {
         const double il2 = ils[q] * ils[q];
@@ -934,9 +1011,20 @@ __device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     double a = 0.0, tr = 0.0;
-    for (int b = threadIdx.x; b < parts; b += 256) {
-      a += v.hyp2part[b * stride];
-      tr += v.hyp2part[b * stride + 1];
+    for (int b0 = threadIdx.x; b0 < parts; b0 += 4 * 256) {      // (loads of four steps in flight, sums in the old order)
+      double xa[4], xt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 256 * u < parts ? b0 + 256 * u : parts - 1;
+        xa[u] = v.hyp2part[b * stride];
+        xt[u] = v.hyp2part[b * stride + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (b0 + 256 * u < parts) {
+          a += xa[u];
+          tr += xt[u];
+        }
     }
     a = block_sum_256(a, sh);
     tr = block_sum_256(tr, sh);
@@ -950,7 +1038,16 @@ __device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
     // few lengthscales: one wavefront per q, lanes over the partial rows (a serial walk over the rows is latency-bound)
     for (int q = wave; q < Din; q += 4) {
       double s = 0.0;
-      for (int b = lane; b < parts; b += 64) s += v.hyp2part[b * stride + 2 + q];
+      // (eight steps of loads in flight, added in the old order: with up to 1024 partial rows the rolled loop was 16 dependent round
+      // trips per lengthscale and this ONE block set the duration of the unfused tail's last launch)
+      for (int b0 = lane; b0 < parts; b0 += 512) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = v.hyp2part[(b0 + 64 * u < parts ? b0 + 64 * u : parts - 1) * stride + 2 + q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (b0 + 64 * u < parts) s += x[u];
+      }
       s = sum_wave(s);
       if (lane == 0) gl_s[q] = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
     }
@@ -965,7 +1062,16 @@ __device__ void asm_hyp_final(const LayerDev& v, double* __restrict__ grad) {
   } else {
     for (int q = threadIdx.x; q < Din; q += 256) {
       double s = 0.0;
-      for (int b = 0; b < parts; ++b) s += v.hyp2part[b * stride + 2 + q];
+      // (eight partial rows of loads in flight, added in row order: the rolled loop was `parts` dependent round trips per lengthscale —
+      // this ONE block set the duration of the whole launch at wide inputs: 148 us at config 4)
+      for (int b0 = 0; b0 < parts; b0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = v.hyp2part[(b0 + u < parts ? b0 + u : parts - 1) * stride + 2 + q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (b0 + u < parts) s += x[u];
+      }
       const double gl = -2.0 * ils[q] * ils[q] * ils[q] * s + v.hyp_red[2 + q];
       if (v.ard)
         grad[v.off_kls + q] = gl * v.hyp[HYP_ILS + Din + q];
