@@ -1101,57 +1101,226 @@ __global__ __launch_bounds__(256) void k_trtri_diag64(const PotrfItem* __restric
 
 // factor + inverse of ONE diagonal block (n = 128, or 64 at a ragged end) of the blocked factorisation, LDS-resident (chol_lds.hpp):
 // ~25 us for 128 columns where k_potrf_trtri took 23 us for 64.  PotrfItem as for k_potrf_trtri (pad bit 16: accumulate into scal).
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_block(const PotrfItem* __restrict__ items) {
+//
+// Look-ahead form of the blocked factorisation (round 6): the launch that factors diagonal block q also carries, in further workgroups, the
+// WIDE part of the trailing update with panel q - 1 (block columns >= q + 1: nothing the factorisation of block q reads), so that only
+// k_chol_panel (solve + update of block column q + 1) sits between two diagonal blocks on the critical path.  Workgroups [0, nchol) factor,
+// workgroup nchol + mb * nwide + t updates 64 x 64 sub-tile t (lower triangle of the 64-row strips from row (q + 1) 128 on) of matrix mb:
+// A_ij -= L_i,q-1 L_j,q-1^T with both operands read from the panel parked TRANSPOSED above the block diagonal (rows (q - 1) 128 ..).
+struct CholWide {
+  double* W;
+  int64_t stride;
+  int32_t n, q, nwide, nchol;
+};
+__device__ __forceinline__ void chol_wide_update(const CholWide wa) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  int idx = (int)blockIdx.x - wa.nchol;
+  const int mb = idx / wa.nwide;
+  idx -= mb * wa.nwide;
+  int si = 0;
+  while ((si + 1) * (si + 2) / 2 <= idx) ++si;
+  const int sj = idx - si * (si + 1) / 2;
+  const int64_t n = wa.n;
+  const int base = (wa.q + 1) * 128, pK = (wa.q - 1) * 128;
+  const int ri = base + 64 * si + 16 * (wave >> 1), rj = base + 64 * sj + 32 * (wave & 1);
+  gptr Wb = (gptr)(wa.W + (int64_t)mb * wa.stride);
+  // (the products are summed on their own and subtracted once: accumulating into the large diagonal entries rounds at their magnitude)
+  d4 c0, c1, acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    c0[t] = Wb[(ri + g + 4 * t) * n + rj + c];
+    c1[t] = Wb[(ri + g + 4 * t) * n + rj + 16 + c];
+  }
+  gcptr ma = (gcptr)(Wb + (pK + g) * n + ri + c), mq = (gcptr)(Wb + (pK + g) * n + rj + c);
+#pragma unroll 1
+  for (int s0 = 0; s0 < 32; s0 += 8) {
+    double av[8], b0[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[u] = ma[4 * (s0 + u) * n];
+      b0[u] = mq[4 * (s0 + u) * n];
+      b1[u] = mq[4 * (s0 + u) * n + 16];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc0 = mfma_f64(av[u], b0[u], acc0);
+      acc1 = mfma_f64(av[u], b1[u], acc1);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    Wb[(ri + g + 4 * t) * n + rj + c] = c0[t] - acc0[t];
+    Wb[(ri + g + 4 * t) * n + rj + 16 + c] = c1[t] - acc1[t];
+  }
+}
+
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_block(const PotrfItem it0, const int64_t sW, const int64_t sInv, const int64_t sScal,
+                                                             const CholWide wa) {
   extern __shared__ __attribute__((aligned(16))) double chol_dyn[];
   __shared__ int s_info;
-  const PotrfItem it = items[blockIdx.x];
-  const int n = it.n, ld = n + 5, nb = n >> 4, nreal = it.nreal;
+  if ((int)blockIdx.x >= wa.nchol) {
+    chol_wide_update(wa);
+    return;
+  }
+  // the item of matrix blockIdx.x from the one of matrix 0 (kernel arguments: no dependent load in front of the block's own loads)
+  PotrfItem it = it0;
+  it.W += (int64_t)blockIdx.x * sW;
+  it.Linv += (int64_t)blockIdx.x * sInv;
+  if (it.scal) it.scal += (int64_t)blockIdx.x * sScal;
+  const int n = it.n, ld = n + 5, nb = n >> 4, nreal = it.nreal;      // n = 128, or 64 at a ragged end
+  const int sh = (n == 128) ? 7 : 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   lptr W = (lptr)chol_dyn;
   lptr Xd = (lptr)(chol_dyn + n * ld);
   lptr red = (lptr)(chol_dyn + n * ld + nb * 16 * 17);
   gptr Wg = (gptr)it.W;
   if (tid == 0) s_info = 0;
-  // lower block triangle, the 16 x 16 diagonal blocks whole (mirrored from their lower halves); identity beyond the real order
-  // (eight unconditional loads in flight per thread: a guarded element-per-iteration loop walked 32 dependent round trips)
-  for (int u0 = 0; u0 < n * n; u0 += 8 * CHOL_THREADS) {
-    double v[8];
+  // accumulated logdet / info of the earlier blocks: requested with the block's loads (the read-modify-write at the end waits for nothing)
+  double sc0 = 0.0, sc1 = 0.0;
+  if (tid == 0 && it.scal && (it.pad & 16)) {
+    sc0 = it.scal[0];
+    sc1 = it.scal[1];
+  }
+  // lower block triangle, the 16 x 16 diagonal blocks whole (mirrored from their lower halves); identity beyond the real order.  ONE round
+  // trip: every load of the thread in flight at once, and only the blocks that are kept are requested (the mirrored reads of the upper
+  // blocks — a cache line per lane — were 44 % of the requests and most of the lines)
+  {
+    double v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int idx = u0 + u * CHOL_THREADS + tid;
-      idx = idx < n * n ? idx : 0;
-      const int i = idx / n, j = idx - i * n;
-      v[u] = Wg[(j <= i) ? (int64_t)i * it.ld + j : (int64_t)j * it.ld + i];
+    for (int u = 0; u < 32; ++u) {
+      const int idx = u * CHOL_THREADS + tid;
+      const int i = idx >> sh, j = idx & (n - 1);
+      const bool need = idx < n * n && (j >> 4) <= (i >> 4) && i < nreal && j < nreal;
+      v[u] = need ? Wg[(j <= i) ? (int64_t)i * it.ld + j : (int64_t)j * it.ld + i] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = u0 + u * CHOL_THREADS + tid;
-      const int i = idx / n, j = idx - i * n;
+    for (int u = 0; u < 32; ++u) {
+      const int idx = u * CHOL_THREADS + tid;
+      const int i = idx >> sh, j = idx & (n - 1);
       if (idx < n * n && (j >> 4) <= (i >> 4)) W[i * ld + j] = (i < nreal && j < nreal) ? v[u] : ((i == j) ? 1.0 : 0.0);
     }
   }
+  asm volatile("" : "+v"(sc0), "+v"(sc1));
   __syncthreads();
   long long tl = 0;
   lds_chol_inverse<false>(W, Xd, n, ld, (gptr)it.Linv, (gptr) nullptr, (int64_t)it.ld, &s_info, nullptr, tl);
-  if (!(it.pad & 8))
-    for (int idx = tid; idx < n * n; idx += CHOL_THREADS) {
-      const int i = idx / n, j = idx - i * n;
-      Wg[(int64_t)i * it.ld + j] = (j <= i) ? W[i * ld + j] : 0.0;
-    }
   double s = 0.0;
   for (int i = tid; i < nreal; i += CHOL_THREADS) s += 2.0 * log(W[i * ld + i]);
   s = sum_wave(s);
   if (lane == 0) red[wave] = s;
+  if (!(it.pad & 8))
+    for (int idx = tid; idx < n * n; idx += CHOL_THREADS) {
+      const int i = idx >> sh, j = idx & (n - 1);
+      Wg[(int64_t)i * it.ld + j] = (j <= i) ? W[i * ld + j] : 0.0;
+    }
   __syncthreads();
   if (tid == 0 && it.scal) {
     double ldv = 0.0;
     for (int w = 0; w < CHOL_NW; ++w) ldv += red[w];
     if (it.pad & 16) {
-      it.scal[0] += ldv;
-      if (s_info && it.scal[1] == 0.0) it.scal[1] = (double)(it.info_offset + s_info);
+      it.scal[0] = sc0 + ldv;
+      if (s_info && sc1 == 0.0) it.scal[1] = (double)(it.info_offset + s_info);
     } else {
       it.scal[0] = ldv;
       it.scal[1] = s_info ? (double)(it.info_offset + s_info) : 0.0;
+    }
+  }
+}
+
+// Between two diagonal blocks of the look-ahead form: panel solve and the update of block column p + 1 in ONE launch.  A workgroup owns a
+// 32 x 32 sub-tile (strip s of the rows below block p, strip b of block p + 1's rows: b <= s inside the diagonal tile) and computes both
+// 32-row strips of the panel it needs ITSELF — La = A_s,p L_pp^-T, Lb = A_b,p L_pp^-T from the inverse the factor launch left, column
+// block jc of the result summing the chunks k <= jc only (L_pp^-1 lower triangular) — so nothing in the launch waits for another
+// workgroup: 144 MFMAs per wave, then 8 for the tile.  Operands go from L2 straight to MFMA registers as in k_wgrad_coop (a lane loads
+// 4 consecutive k of one row).  The strips pass through LDS to become operands of the tile update; the
+// b = 0 workgroups park their La TRANSPOSED above the block diagonal (where the wide update of the next factor launch and
+// k_mirror_panels expect the panel).  grid (tasks, batch).
+struct CholPanel {
+  double* W;
+  const double* dinv;      // L_pp^-1 of matrix 0 (lower triangular, upper 16 x 16 blocks never read), leading dimension n
+  int64_t stride, dinv_stride;
+  int32_t n, p;
+};
+#define CPL_LD 132
+__global__ __launch_bounds__(256) void k_chol_panel(const CholPanel a) {
+  __shared__ __attribute__((aligned(32))) double S[64 * CPL_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int64_t n = a.n;
+  const int r0 = (a.p + 1) * 128, pK = a.p * 128;
+  const int nrem = a.n - r0, nbb = (nrem < 128 ? nrem : 128) >> 5;
+  int idx = blockIdx.x, s, b;
+  const int ndiag = nbb * (nbb + 1) / 2;
+  if (idx < ndiag) {
+    s = 0;
+    while ((s + 1) * (s + 2) / 2 <= idx) ++s;
+    b = idx - s * (s + 1) / 2;
+  } else {
+    idx -= ndiag;
+    s = nbb + idx / nbb;
+    b = idx % nbb;
+  }
+  gptr Wb = (gptr)(a.W + (int64_t)blockIdx.y * a.stride);
+  gcptr Li = (gcptr)(a.dinv + (int64_t)blockIdx.y * a.dinv_stride);
+  const int ra = r0 + 32 * s, rb = r0 + 32 * b;
+  const int bi = w >> 1, bj = w & 1;
+  gptr Cp = Wb + (ra + 16 * bi + g) * n + rb + 16 * bj + c;
+  d4 cin, cacc = (d4){0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) cin[t] = Cp[4 * t * n];
+  typedef const d4 __attribute__((address_space(1)))* g4ptr;
+  // wave w owns 16 rows of the two strips (w < 2: La, else Lb) and all eight column blocks of them: its eight A fragments are requested up
+  // front (one round trip), the 36 fragments of L_pp^-1 (the same for every wave and workgroup: L2 hits) stream through a ring RING steps
+  // ahead of the MFMAs that read them (a step = 4 MFMAs: left to the scheduler the loads sink to their uses and every step pays the trip)
+  gcptr rowp = (gcptr)(Wb + ((w < 2 ? ra + 16 * w : rb + 16 * (w - 2)) + c) * n + pK + 4 * g);
+  d4 pa[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) pa[kc] = *reinterpret_cast<g4ptr>(rowp + 16 * kc);
+  constexpr int RING = 8;
+  d4 q[RING];
+  gcptr lip = Li + c * n + 4 * g;
+  // step order: chunk-major (kc = 0: jc = 0 .. 7, kc = 1: jc = 1 .. 7, ...): consecutive MFMAs go to different accumulators
+  constexpr int SJC[36] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+  constexpr int SKC[36] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+  d4 acc[8];
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) acc[jc] = (d4){0, 0, 0, 0};
+#pragma unroll
+  for (int st = 0; st < RING; ++st) q[st] = *reinterpret_cast<g4ptr>(lip + 16 * SJC[st] * n + 16 * SKC[st]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int st = 0; st < 36; ++st) {
+    const int jc = SJC[st], kc = SKC[st];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[jc] = mfma_f64(pa[kc][t], q[st % RING][t], acc[jc]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (st + RING < 36) q[st % RING] = *reinterpret_cast<g4ptr>(lip + 16 * SJC[st + RING] * n + 16 * SKC[st + RING]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) S[(16 * w + g + 4 * t) * CPL_LD + 16 * jc + c] = acc[jc][t];
+  __syncthreads();
+  {
+    const d4* Sa = reinterpret_cast<const d4*>(S + (16 * bi + c) * CPL_LD + 4 * g);
+    const d4* Sb = reinterpret_cast<const d4*>(S + (32 + 16 * bj + c) * CPL_LD + 4 * g);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      const d4 av = Sa[4 * kc], bv = Sb[4 * kc];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cacc = mfma_f64(av[t], bv[t], cacc);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Cp[4 * t * n] = cin[t] - cacc[t];
+  if (b == 0) {
+    gptr Mp = Wb + (int64_t)pK * n + ra + (tid & 31);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int k = it * 8 + (tid >> 5);
+      Mp[k * n] = S[(tid & 31) * CPL_LD + k];
     }
   }
 }
@@ -1186,8 +1355,9 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
       nr = nr < 0 ? 0 : (nr > bn ? bn : nr);
       // without a requested inverse the inverses of the diagonal blocks (needed by the panel solve) live in Tbuf
       double* dinv = Linv ? Linv + off : Tbuf + (int64_t)b * bs * n + p * bs;
+      // (block 0 SETS logdet / info, the later blocks accumulate: no memset of `scal` in front of the sequence)
       items[(size_t)p * batch + b] = PotrfItem{W + off, dinv, nullptr, scal ? scal + b * scal_stride : nullptr,
-                                               bn, n, nr, 16, p * bs, 0};
+                                               bn, n, nr, p == 0 ? 0 : 16, p * bs, 0};
     }
   std::vector<GemmProblem> gp;
   P.tiles.clear();
@@ -1213,7 +1383,13 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     g.alpha = alpha; g.beta = beta; g.lower_only = lower;
     return g;
   };
-  if (!from_tri) {
+  static const bool lookahead_off = getenv("DSDGP_CHOL_LOOKAHEAD") && atoi(getenv("DSDGP_CHOL_LOOKAHEAD")) == 0;      // (A/B aid)
+  // the wide-update workgroups of the look-ahead form each hold a whole CU (the factor launch's LDS): beyond 16 blocks the plain sequence
+  P.lookahead = !from_tri && !lookahead_off && P.nb >= 2 && P.nb <= 16;
+  P.dinv = Linv ? Linv : Tbuf;
+  P.dinv_stride = Linv ? stride : (int64_t)bs * n;
+  P.dinv_step = Linv ? (int64_t)BCB * n + BCB : BCB;
+  if (!from_tri && !P.lookahead) {
     for (int p = 0; p + 1 < P.nb; ++p) {
       const int rem = n - (p + 1) * BCB;
       double* panel = W + (int64_t)(p + 1) * BCB * n + p * BCB;
@@ -1262,6 +1438,8 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
       add_launch(l2, sblk <= 256 ? 0 : 1);
     }
   }
+  P.items0.clear();
+  for (int p = 0; p < nb; ++p) P.items0.push_back(items[(size_t)p * batch]);      // matrix 0's item per block: k_chol_block's argument
   const size_t ib = round_up(items.size() * sizeof(PotrfItem), 256), gb = round_up(gp.size() * sizeof(GemmProblem) + 256, 256);
   DS_HIP(hipMalloc(&P.dev_block, ib + gb));
   P.diag_items = (PotrfItem*)P.dev_block;
@@ -1286,8 +1464,6 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
   int gi = 0;
   auto launch = [&](int i) { gemm_dispatch(P.gp + P.first[i], P.nprob[i], P.tiles[i], ctx->stream); };
   if (!P.from_tri) {
-    if (P.scal)
-      for (int b = 0; b < batch; ++b) DS_HIP(hipMemsetAsync(P.scal + b * P.scal_stride, 0, 2 * sizeof(double), ctx->stream));
     const size_t lds = chol_lds_bytes(BCB);
     static bool lds_set = false;      // the attribute is sticky: one driver call
     if (!lds_set) {
@@ -1295,10 +1471,22 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
       lds_set = true;
     }
     for (int p = 0; p < nb; ++p) {
-      DS_LAUNCH(k_chol_block, dim3(batch), dim3(CHOL_THREADS), lds, ctx->stream, P.diag_items + (size_t)p * batch);
+      CholWide wa{P.W, P.stride, P.n, p, 0, batch};
+      if (P.lookahead && p >= 1) {
+        const int ns64 = (P.n - (p + 1) * BCB) / 64;      // 64-row strips from block p + 1 on
+        wa.nwide = ns64 > 0 ? ns64 * (ns64 + 1) / 2 : 0;
+      }
+      DS_LAUNCH(k_chol_block, dim3(batch + batch * wa.nwide), dim3(CHOL_THREADS), lds, ctx->stream, P.items0[p], P.stride, P.dinv_stride,
+                P.scal_stride, wa);
       if (p + 1 < nb) {
-        launch(gi++);
-        launch(gi++);
+        if (P.lookahead) {
+          const int nrem = P.n - (p + 1) * BCB, nbb = std::min(nrem, BCB) / 32, ns = nrem / 32;
+          const CholPanel pa{P.W, P.dinv + (int64_t)p * P.dinv_step, P.stride, P.dinv_stride, P.n, p};
+          DS_LAUNCH(k_chol_panel, dim3(nbb * (nbb + 1) / 2 + (ns - nbb) * nbb, batch), dim3(256), 0, ctx->stream, pa);
+        } else {
+          launch(gi++);
+          launch(gi++);
+        }
       }
     }
     DS_LAUNCH(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);

@@ -63,7 +63,11 @@ struct BigChol {
   bool want_inverse = false, from_tri = false;   // from_tri: input is already a lower-triangular factor (inverse only)
   double* W = nullptr; double* Linv = nullptr; double* LinvT = nullptr; double* scal = nullptr; double* Tbuf = nullptr;
   int64_t stride = 0, scal_stride = 0;
+  bool lookahead = false;              // k_chol_panel + wide update inside the factor launches (linalg.hip)
+  const double* dinv = nullptr;        // inverse of diagonal block 0 of matrix 0; block p: + p * dinv_step, matrix b: + b * dinv_stride
+  int64_t dinv_stride = 0, dinv_step = 0;
   PotrfItem* diag_items = nullptr;     // device: nb * batch
+  std::vector<PotrfItem> items0;       // host: matrix 0's item of every diagonal block
   GemmProblem* gp = nullptr;           // device: per panel {solve, trailing}, then per block row {T, X}
   std::vector<int> tiles;              // per launch: planned tile count (bit 30: large-tile kernel)
   std::vector<int> nprob, first;       // per launch: number of problems and index of the first one in gp
