@@ -1075,22 +1075,45 @@ __global__ void k_transpose_lower(const double* __restrict__ X, double* __restri
 }
 // inverse of the 64x64 lower-triangular diagonal blocks of already-triangular matrices (from_tri mode), one WG per block
 __global__ __launch_bounds__(256) void k_trtri_diag64(const PotrfItem* __restrict__ items) {
-  __shared__ double Lb[64 * 65];
+  __shared__ __attribute__((aligned(16))) double Lb[64 * 64];
   __shared__ double Xb[64 * 65];
+  __shared__ double rinv[64];
   const PotrfItem it = items[blockIdx.x];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < 64 * 64; idx += 256) {
-    const int i = idx >> 6, j = idx & 63;
-    Lb[i * 65 + j] = (j <= i) ? it.W[(int64_t)i * it.ld + j] : 0.0;
+  {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = u * 256 + tid, i = idx >> 6, j = idx & 63;
+      v[u] = (j <= i) ? it.W[(int64_t)i * it.ld + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = u * 256 + tid, i = idx >> 6, j = idx & 63;
+      Lb[idx] = v[u];
+      if (i == j) rinv[i] = 1.0 / v[u];
+    }
   }
   __syncthreads();
-  if (tid < 64) {   // column tid of X by forward substitution
+  if (tid < 64) {
+    // column tid of X by forward substitution, the column in REGISTERS: row i of L is read at wave-uniform addresses (LDS broadcast) and the
+    // loop is fully unrolled — 2016 FMAs; the entries above the diagonal come out as exact zeros by themselves (all their terms are zero).
+    // (the rolled form — every term two dependent LDS round trips — took 97 us)
     const int col = tid;
+    double x[64];
+#pragma unroll
     for (int i = 0; i < 64; ++i) {
-      double s = (i == col) ? 1.0 : 0.0;
-      for (int k = col; k < i; ++k) s -= Lb[i * 65 + k] * Xb[k * 65 + col];
-      Xb[i * 65 + col] = (i >= col) ? s / Lb[i * 65 + i] : 0.0;
+      double s0 = (i == col) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 1 < i; k += 2) {
+        s0 -= Lb[i * 64 + k] * x[k];
+        s1 -= Lb[i * 64 + k + 1] * x[k + 1];
+      }
+      if (i & 1) s0 -= Lb[i * 64 + i - 1] * x[i - 1];
+      x[i] = (s0 + s1) * rinv[i];
     }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) Xb[i * 65 + col] = x[i];
   }
   __syncthreads();
   for (int idx = tid; idx < 64 * 64; idx += 256) {
@@ -1105,17 +1128,16 @@ __global__ __launch_bounds__(256) void k_trtri_diag64(const PotrfItem* __restric
 // Look-ahead form of the blocked factorisation (round 6): the launch that factors diagonal block q also carries, in further workgroups, the
 // WIDE part of the trailing update with panel q - 1 (block columns >= q + 1: nothing the factorisation of block q reads), so that only
 // k_chol_panel (solve + update of block column q + 1) sits between two diagonal blocks on the critical path.  Workgroups [0, nchol) factor,
-// workgroup nchol + mb * nwide + t updates 64 x 64 sub-tile t (lower triangle of the 64-row strips from row (q + 1) 128 on) of matrix mb:
+// side task mb * nwide + t updates 64 x 64 sub-tile t (lower triangle of the 64-row strips from row (q + 1) 128 on) of matrix mb:
 // A_ij -= L_i,q-1 L_j,q-1^T with both operands read from the panel parked TRANSPOSED above the block diagonal (rows (q - 1) 128 ..).
 struct CholWide {
   double* W;
   int64_t stride;
   int32_t n, q, nwide, nchol;
 };
-__device__ __forceinline__ void chol_wide_update(const CholWide wa) {
+__device__ __forceinline__ void chol_wide_update(const CholWide wa, int idx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  int idx = (int)blockIdx.x - wa.nchol;
   const int mb = idx / wa.nwide;
   idx -= mb * wa.nwide;
   int si = 0;
@@ -1155,12 +1177,133 @@ __device__ __forceinline__ void chol_wide_update(const CholWide wa) {
   }
 }
 
+// X = L^-1 inside the look-ahead sequence (round 6): block row i of X — X_ij = -X_ii sum_{k = j}^{i-1} L_ik X_kj, everything on its right
+// final once diagonal block i is factored — is formed by further workgroups of the launch that factors block i + 1 (the last row by a
+// launch of its own behind the last block), instead of the 2 log2(n / 128) dependent product launches behind the factorisation.  A
+// workgroup owns a 16-column slab of X_ij: wave w the 16 rows 16 w .. of T = sum_k L_ik X_kj (L read from the panels parked transposed
+// above the block diagonal, 32 (i - j) k-steps), the slab through LDS, then the rows of -X_ii T (k <= its own rows: X_ii lower
+// triangular).  j = i (with a transposed output only): the slab of X_ii itself goes to the transposed copy.  8 (i [+ 1]) workgroups per matrix.
+struct CholXrow {
+  const double* W;
+  double* Linv;
+  double* LinvT;      // may be NULL
+  int64_t stride;
+  int32_t n, i, nx, batch;      // nx slabs per matrix
+  // 0: the whole row.  The LAST row is split over two launches: 1 = the terms k <= i - 2 of T (inside the launch that factors block i; the
+  // sums wait in X_ij's own place), 2 = the term k = i - 1 on top of them and the product with X_ii (behind that launch)
+  int32_t mode, pad;
+};
+__device__ __forceinline__ void chol_xrow(const CholXrow xa, lptr T, int idx) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int mb = idx / xa.nx;
+  idx -= mb * xa.nx;
+  const int j = idx >> 3, cs = idx & 7, i = xa.i;
+  const int64_t n = xa.n;
+  const int rows = xa.n - 128 * i < 128 ? xa.n - 128 * i : 128;      // 64 at a ragged end
+  gcptr Wb = (gcptr)(xa.W + (int64_t)mb * xa.stride);
+  gptr Xb = (gptr)(xa.Linv + (int64_t)mb * xa.stride);
+  gptr XT = xa.LinvT ? (gptr)(xa.LinvT + (int64_t)mb * xa.stride) : (gptr) nullptr;
+  if (j == i) {      // X_ii^T, columns 16 cs .. of X_ii (rows from 16 cs on: below the block diagonal of the slab nothing is stored)
+    for (int e = tid; e < rows * 16; e += CHOL_THREADS) {
+      const int r = e >> 4, cc = e & 15;
+      if (r >= 16 * cs && 16 * cs < rows) XT[(128 * i + 16 * cs + cc) * n + 128 * i + r] = Xb[(128 * i + r) * n + 128 * i + 16 * cs + cc];
+    }
+    return;
+  }
+  const bool live = 16 * w < rows;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  typedef const d4 __attribute__((address_space(1)))* g4ptr;
+  // fragments of X_ii for the second product: requested in front of the first (they depend on nothing here)
+  d4 xf[8];
+  if (live && xa.mode != 1) {
+    gcptr xp = (gcptr)(Xb + (128 * i + 16 * w + c) * n + 128 * i + 4 * g);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc)
+      if (kc <= wu) xf[kc] = *reinterpret_cast<g4ptr>(xp + 16 * kc);
+  }
+  gptr own = Xb + (128 * i + 16 * w + g) * n + 128 * j + 16 * cs + c;      // X_ij's rows g + 4 t of this wave's block
+  d4 acc = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+  if (live) {
+    const int kb0 = (xa.mode == 2) ? i - 1 : j, kb1 = (xa.mode == 1) ? i - 1 : i;
+    if (xa.mode == 2 && j < i - 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = own[4 * t * n];
+    }
+    gcptr ap = Wb + (128 * kb0 + g) * n + 128 * i + 16 * w + c;      // L_ik^T: row = k index, column = row of L
+    gcptr bp = (gcptr)(Xb + (128 * kb0 + g) * n + 128 * j + 16 * cs + c);
+    const int steps = 32 * (kb1 - kb0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+      double av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        av[u] = ap[4 * (s0 + u) * n];
+        bv[u] = bp[4 * (s0 + u) * n];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        acc = mfma_f64(av[u], bv[u], acc);
+        acc1 = mfma_f64(av[u + 1], bv[u + 1], acc1);
+      }
+    }
+    acc += acc1;
+    if (xa.mode == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) own[4 * t * n] = acc[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) T[(16 * w + g + 4 * t) * 17 + c] = acc[t];
+    }
+  }
+  if (xa.mode == 1) return;
+  __syncthreads();
+  if (!live) return;
+  d4 r0 = (d4){0, 0, 0, 0}, r1 = (d4){0, 0, 0, 0};
+#pragma unroll
+  for (int kc = 0; kc < 8; kc += 2) {
+    if (kc <= wu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r0 = mfma_f64(xf[kc][t], T[(16 * kc + 4 * g + t) * 17 + c], r0);
+    }
+    if (kc + 1 <= wu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r1 = mfma_f64(xf[kc + 1][t], T[(16 * (kc + 1) + 4 * g + t) * 17 + c], r1);
+    }
+  }
+  r0 += r1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    own[4 * t * n] = -r0[t];
+    if (XT) XT[(128 * j + 16 * cs + c) * n + 128 * i + 16 * w + g + 4 * t] = -r0[t];
+  }
+}
+// the last block row of X (behind the last factor launch)
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_xrow(const CholXrow xa) {
+  __shared__ double T[128 * 17];
+  for (int t = blockIdx.x; t < xa.batch * xa.nx; t += gridDim.x) {
+    chol_xrow(xa, (lptr)T, t);
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_block(const PotrfItem it0, const int64_t sW, const int64_t sInv, const int64_t sScal,
-                                                             const CholWide wa) {
+                                                             const CholWide wa, const CholXrow xa, const CholXrow xb) {
   extern __shared__ __attribute__((aligned(16))) double chol_dyn[];
   __shared__ int s_info;
   if ((int)blockIdx.x >= wa.nchol) {
-    chol_wide_update(wa);
+    // side tasks (wide-update sub-tiles, then slabs of the inverse's block row), dealt round-robin over the launch's further workgroups:
+    // each of them holds a CU (the launch's LDS size), so the host caps their number
+    const int nw = wa.nchol * wa.nwide, nxa = xa.batch * xa.nx, total = nw + nxa + xb.batch * xb.nx;
+    for (int t = (int)blockIdx.x - wa.nchol; t < total; t += (int)gridDim.x - wa.nchol) {
+      if (t < nw) {
+        chol_wide_update(wa, t);
+      } else {
+        if (t < nw + nxa) chol_xrow(xa, (lptr)chol_dyn, t - nw);
+        else chol_xrow(xb, (lptr)chol_dyn, t - nw - nxa);
+        __syncthreads();
+      }
+    }
     return;
   }
   // the item of matrix blockIdx.x from the one of matrix 0 (kernel arguments: no dependent load in front of the block's own loads)
@@ -1327,8 +1470,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(const CholPanel a) {
 
 #define BCB 128     // diagonal block of the blocked factorisation
 int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* LinvT, double* scal, int batch, int64_t stride,
-                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri) {
+                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri, bool need_factor) {
   DS_CHECK_ARG(n % 64 == 0 && n >= 128 && batch >= 1);
+  P.need_factor = need_factor;
   P.n = n; P.batch = batch; P.nb = from_tri ? n / 64 : ceil_div(n, BCB);
   P.W = W; P.Linv = Linv; P.LinvT = LinvT; P.scal = scal; P.Tbuf = Tbuf;
   P.stride = stride; P.scal_stride = scal_stride;
@@ -1407,7 +1551,8 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
       add(g2, 0);
     }
   }
-  if (P.want_inverse) {
+  P.xrows = P.want_inverse && P.lookahead;      // block rows of X inside the factor launches (chol_xrow) instead
+  if (P.want_inverse && !P.xrows) {
     // X = L^-1 by RECURSIVE DOUBLING over the 64 x 64 diagonal inverses the factor kernel left on Linv's diagonal: at block
     // size s every pair of adjacent diagonal blocks [X11 0; X21 X22] gets X21 = -X22 (L21 X11), all n / 2s pairs (and all
     // matrices of the batch) in ONE grouped launch per product: 2 log2(n / 64) launches (8 at n = 1024) instead of the
@@ -1476,8 +1621,16 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
         const int ns64 = (P.n - (p + 1) * BCB) / 64;      // 64-row strips from block p + 1 on
         wa.nwide = ns64 > 0 ? ns64 * (ns64 + 1) / 2 : 0;
       }
-      DS_LAUNCH(k_chol_block, dim3(batch + batch * wa.nwide), dim3(CHOL_THREADS), lds, ctx->stream, P.items0[p], P.stride, P.dinv_stride,
-                P.scal_stride, wa);
+      CholXrow xa{P.W, P.Linv, P.LinvT, P.stride, P.n, p - 1, 0, batch, 0, 0}, xb = xa;
+      if (P.xrows && p >= 1) xa.nx = 8 * (p - 1 + (P.LinvT ? 1 : 0));
+      if (P.xrows && p == nb - 1) {      // the early terms of the last row
+        xb.i = p;
+        xb.nx = 8 * (p - 1);
+        xb.mode = 1;
+      }
+      const int side = std::min(batch * (wa.nwide + xa.nx + xb.nx), std::max(32, 248 - batch));      // (a CU each: one round of them)
+      DS_LAUNCH(k_chol_block, dim3(batch + side), dim3(CHOL_THREADS), lds, ctx->stream, P.items0[p], P.stride, P.dinv_stride,
+                P.scal_stride, wa, xa, xb);
       if (p + 1 < nb) {
         if (P.lookahead) {
           const int nrem = P.n - (p + 1) * BCB, nbb = std::min(nrem, BCB) / 32, ns = nrem / 32;
@@ -1489,11 +1642,17 @@ int bigchol_run(dsdgp_ctx* ctx, const BigChol& P) {
         }
       }
     }
-    DS_LAUNCH(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);
+    if (P.xrows) {
+      CholXrow xa{P.W, P.Linv, P.LinvT, P.stride, P.n, nb - 1, 8 * (nb - 1 + (P.LinvT ? 1 : 0)), batch, 2, 0};
+      if (xa.nx) DS_LAUNCH(k_chol_xrow, dim3(std::min(batch * xa.nx, 2048)), dim3(CHOL_THREADS), 0, ctx->stream, xa);
+    }
+    // (with the inverse formed from the parked panels nothing but a caller that reads L itself needs them moved below the diagonal)
+    if (P.need_factor || !P.xrows)
+      DS_LAUNCH(k_mirror_panels, dim3(std::min(1024, (P.n / 16) * (P.n / 16)), batch), dim3(256), 0, ctx->stream, P.W, P.n, P.stride, BCB);
   } else if (P.want_inverse) {
     DS_LAUNCH(k_trtri_diag64, dim3(nb * batch), dim3(256), 0, ctx->stream, P.diag_items);
   }
-  if (P.want_inverse) {
+  if (P.want_inverse && !P.xrows) {
     while (gi < (int)P.tiles.size()) launch(gi++);
     if (P.LinvT)
       DS_LAUNCH(k_transpose_lower, dim3(256, batch), dim3(256), 0, ctx->stream, P.Linv, P.LinvT, P.n, P.stride);

@@ -64,6 +64,8 @@ struct BigChol {
   double* W = nullptr; double* Linv = nullptr; double* LinvT = nullptr; double* scal = nullptr; double* Tbuf = nullptr;
   int64_t stride = 0, scal_stride = 0;
   bool lookahead = false;              // k_chol_panel + wide update inside the factor launches (linalg.hip)
+  bool need_factor = true;             // false: only the inverse / log det are read (the panels may stay parked above the diagonal)
+  bool xrows = false;                  // ... and the block rows of the inverse (chol_xrow) instead of the recursive doubling
   const double* dinv = nullptr;        // inverse of diagonal block 0 of matrix 0; block p: + p * dinv_step, matrix b: + b * dinv_stride
   int64_t dinv_stride = 0, dinv_step = 0;
   PotrfItem* diag_items = nullptr;     // device: nb * batch
@@ -78,7 +80,7 @@ struct BigChol {
 // W/Linv/LinvT: `batch` matrices of order n (leading dimension n) `stride` doubles apart; scal: 2 doubles per matrix
 // (`scal_stride` apart); Tbuf: batch * 64 * n doubles of scratch (needed when want_inverse).
 int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* LinvT, double* scal, int batch, int64_t stride,
-                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri);
+                  int64_t scal_stride, int n, int nreal, double* Tbuf, bool from_tri, bool need_factor = true);
 int bigchol_run(dsdgp_ctx* ctx, const BigChol& P);
 void bigchol_free(BigChol& P);
 

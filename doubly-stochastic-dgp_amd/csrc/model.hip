@@ -219,11 +219,13 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
         it[d] = PotrfItem{v.ngA + d * MM, v.ngLAinv + d * MM, v.ngLAinvT + d * MM, v.ngScal + 2 * d, Mp, Mp, v.M, 0, 0, 0};
       DS_HIP(hipMemcpyAsync(St.ng_items, it.data(), it.size() * sizeof(PotrfItem), hipMemcpyHostToDevice, st));
       DS_HIP(hipStreamSynchronize(st));
-      St.big = Mp >= big_mp(m->uniform_big);
+      St.big = Mp >= big_mp(m->uniform_big) && Mp % 64 == 0;
       if (St.big) {
-        if (!m->uniform_big) DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false));
-        else if (l == 0) DS_TRY(bigchol_build(ctx, m->big_all, v.Kp, v.Linv, v.LinvT, v.scal, L, MM, 8, Mp, v.M, nullptr, false));
-        DS_TRY(bigchol_build(ctx, St.big_ngA, v.ngA, v.ngLAinv, v.ngLAinvT, v.ngScal, v.D_out, MM, 2, Mp, v.M, nullptr, false));
+        // (Lu itself is read by the white = True adjoint only, the factor of the natural-gradient step's A by nobody)
+        const bool need_lu = desc->white != 0;
+        if (!m->uniform_big) DS_TRY(bigchol_build(ctx, St.big_k, v.Kp, v.Linv, v.LinvT, v.scal, 1, MM, 2, Mp, v.M, nullptr, false, need_lu));
+        else if (l == 0) DS_TRY(bigchol_build(ctx, m->big_all, v.Kp, v.Linv, v.LinvT, v.scal, L, MM, 8, Mp, v.M, nullptr, false, need_lu));
+        DS_TRY(bigchol_build(ctx, St.big_ngA, v.ngA, v.ngLAinv, v.ngLAinvT, v.ngScal, v.D_out, MM, 2, Mp, v.M, nullptr, false, false));
         DS_TRY(bigchol_build(ctx, St.big_ngT, v.ngTI, v.ngTinv, nullptr, nullptr, v.D_out, MM, 0, Mp, v.M, nullptr, true));
       }
     }

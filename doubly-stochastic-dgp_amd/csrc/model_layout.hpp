@@ -29,6 +29,7 @@ static void layout(dsdgp_model* m, char* base, size_t* total) {
   // layers with the same (large) M keep their Ku / Lu^-1 / Lu^-T contiguous so that one batched factorisation serves them all
   bool uniform = D.L > 1 && pad_M(D.layers[0].M) >= big_mp(true);
   for (int l = 1; l < D.L; ++l) uniform = uniform && D.layers[l].M == D.layers[0].M;
+  uniform = uniform && pad_M(D.layers[0].M) % 64 == 0;
   m->uniform_big = uniform;
   double *Kp_all = nullptr, *Linv_all = nullptr, *LinvT_all = nullptr, *scal_all = nullptr;
   if (uniform) {

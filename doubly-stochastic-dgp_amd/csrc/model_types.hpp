@@ -68,7 +68,7 @@ struct LayerState {
   int red_off = 0, red_n = 0, red_blk0 = 0, red_blkn = 0;   // this layer's range of the reduction job list / of its blocks
   double* bpart = nullptr;      // backward-chain d-split: partial abar tiles [row block][split][Mp * 16 + 16]
   int* bcnt = nullptr;          //   arrival counters per row block (zero between launches)
-  bool big = false;    // Mp >= 512: multi-workgroup blocked factorisations (linalg.hpp BigChol)
+  bool big = false;    // Mp >= big_mp(), a multiple of 64: multi-workgroup blocked factorisations (linalg.hpp BigChol)
   BigChol big_k, big_ngA, big_ngT;
   GemmProblem* ng_gp;  // device: 4 natural-gradient GEMM problems (H, Sinv | Y | X)
   PotrfItem* ng_items; // device: D_out factorisation items (the index-reversed A_d)
@@ -130,7 +130,7 @@ struct dsdgp_model {
   int sample_w_S = 0;
   GemmProblem* gp_wz;   // wm [Z | 1] of the layers with D_in > WIDE_DIN
   int n_wz = 0, t_wz = 0, kuu_blocks = 32, asm_blocks = 64, prep_blocks = PREP_BLOCKS;
-  bool uniform_big = false;     // all layers share M and Mp >= 256: ONE batched multi-workgroup Cholesky for all layers
+  bool uniform_big = false;     // all layers share M and Mp >= 192: ONE batched multi-workgroup Cholesky for all layers
   BigChol big_all;
   bool need_hyp_part = false;
   bool tail_ok = false;         // non-white, every D_in <= WIDE_DIN: gradient assembly in k_asm_rows + k_tail (one wave per inducing row)
@@ -239,10 +239,13 @@ static int chain_d_split(int64_t nblk, int D_out) {
   if (ds > D_out) ds = D_out;
   return ds < 1 ? 1 : ds;
 }
-// padded inducing count from which the multi-workgroup blocked Cholesky / inverse replaces the one-workgroup kernel: 512, or
-// 256 when all layers share M and are factorised as ONE batch (measured: config 3 +2 %; per-layer sequences at 256 would lose
-// to the single launch that factors all layers side by side)
-static int big_mp(bool uniform) { return uniform ? 256 : 512; }
+// padded inducing count from which the multi-workgroup blocked Cholesky / inverse (look-ahead sequence, linalg.hip) replaces the
+// one-workgroup kernel: 192 (Mp a multiple of 64).  Measured, factor + inverse of one matrix: Mp = 192 180 -> 77 us, 256 371 -> 101,
+// 448 1990 -> 181.  Layers that share M are factorised as ONE batch.
+static int big_mp(bool uniform) {
+  static const int nonuniform = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 192;      // (A/B aid)
+  return uniform ? 192 : nonuniform;
+}
 // K splits of a weight-gradient launch: about `target_tasks` workgroup tasks (512 = two workgroups of four waves per CU), every
 // wave at least two 16-row chunks
 static int choose_nsplit(int tiles_per_split, int64_t nchunks, int target_tasks) {
