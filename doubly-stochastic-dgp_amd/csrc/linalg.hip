@@ -915,7 +915,7 @@ __global__ void k_unpad(const double* __restrict__ P, int np, double* __restrict
 
 extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t lda, int64_t stride, int* info) {
   DS_CHECK_ARG(ctx && A && batch > 0 && n > 0 && lda >= n);
-  const int np = n > 496 ? (int)round_up(n, 64) : (int)round_up(n, 16);
+  const int np = n > 176 ? (int)round_up(n, 64) : (int)round_up(n, 16);      // from 192 on: the blocked multi-workgroup sequence
   const size_t mat_bytes = (size_t)batch * np * np * sizeof(double);
   const size_t item_bytes = round_up(batch * sizeof(PotrfItem), 256);
   const size_t scal_bytes = round_up((size_t)batch * 2 * sizeof(double), 256);
@@ -930,7 +930,7 @@ extern "C" int dsdgp_potrf(dsdgp_ctx* ctx, int batch, int n, double* A, int64_t 
   }
   DS_TRY(ctx_upload(ctx, items_d, items.data(), batch * sizeof(PotrfItem)));   // asynchronous (pinned staging ring)
   DS_LAUNCH(k_pad_spd, dim3(ceil_div(np * np, 256), batch), dim3(256), 0, ctx->stream, A, lda, stride, n, P, np);
-  if (np >= 512 && np % 64 == 0) {
+  if (np >= 192 && np % 64 == 0) {
     // large matrices: multi-workgroup blocked path; the plan of the last call is kept in the context (the model path pre-builds its plans)
     const int64_t key[4] = {(int64_t)(uintptr_t)P, np, batch, n};
     if (!ctx->potrf_plan || memcmp(key, ctx->potrf_key, sizeof(key)) != 0) {

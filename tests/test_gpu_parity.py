@@ -48,7 +48,9 @@ def test_gemm(ctx, tA, tB, m, n, k):
     assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * k)
 
 
-@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 256, 300, 512, 570, 600, 1024])      # 570 -> 576 = 4 x 128 + 64: ragged last diagonal block
+# 570 -> 576 = 4 x 128 + 64: ragged last diagonal block; 177 .. : the blocked look-ahead sequence (180 -> 192 = 128 + 64); 1536: 12 blocks;
+# 2176 = 17 blocks: the plain blocked sequence (the look-ahead form stops at 16)
+@pytest.mark.parametrize("n", [5, 16, 19, 50, 100, 128, 176, 180, 192, 200, 256, 300, 320, 448, 512, 570, 600, 1024, 1536, 2176])
 def test_potrf(ctx, n):
     from doubly_stochastic_dgp import _lib
     rng = np.random.RandomState(n)

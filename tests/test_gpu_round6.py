@@ -260,3 +260,58 @@ def test_in_launch_split_k_reduction_against_the_oracle(monkeypatch, force, shap
     g2 = model.engine().gradient_dict()
     for k in g1:
         assert np.array_equal(g1[k], np.asarray(g2[k])), (force, k)
+
+
+# ---------------------------------------------------------------- blocked Cholesky with look-ahead (linalg.hip: k_chol_panel, side workgroups)
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("M,L", [(180, 1), (192, 2), (250, 1), (300, 3), (448, 1), (570, 2)])
+def test_lookahead_blocked_cholesky_in_the_model_against_the_oracle(M, L, white):
+    """Ku's factor, inverse factor (block rows formed by side workgroups of the factor launches, the last row split over two launches)
+    and log det through the look-ahead sequence from Mp = 192 on — 128 + 64 ragged (180 -> 192), two full blocks (250 -> 256), 320, 448
+    (ragged again), 570 -> 640; one matrix and batches of L — against the oracle: ELBO, every gradient (white = True reads Lu itself: the
+    parked panels must be moved back and the upper blocks zeroed), then a natural-gradient step (its own factorisation + inverse, whose
+    factor is never moved back)."""
+    from doubly_stochastic_dgp.training import NatGradOptimizer
+    rng = np.random.RandomState(M + L)
+    N, D, S = 24, 3, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D) * 2.0
+    specs = [kern_spec("rbf", D, 1.0, 1.0)] * (L - 1) + [kern_spec("matern52", D, 1.3, 0.9)]
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=500)
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 2)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=500)
+    got = model._build_likelihood(X, Y, zs=zs, with_grad=True)
+    assert_allclose(got, ref, rtol=1e-8)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        err = np.max(np.abs(-g[k] - np.asarray(grads[k]))) / (np.max(np.abs(g[k])) + 1e-12)
+        assert err <= 1e-6, (k, err)
+    # the natural-gradient step from the initial (q_mu, q_sqrt): make_case's random lower-triangular q_sqrt is exponentially
+    # ill-conditioned at these M (the one-workgroup kernels miss rtol 1e-6 on it just the same)
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=500, randomize=False)
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=500)
+    assert_allclose(model._build_likelihood(X, Y, zs=zs, with_grad=True), ref, rtol=1e-8)
+    last = "l%d" % (L - 1)
+    mu, sq = O.natgrad_step(state[last + ".q_mu"], state[last + ".q_sqrt"], -g[last + ".q_mu"], -g[last + ".q_sqrt"], 0.1)
+    lay = model.layers[-1]
+    NatGradOptimizer(0.1).minimize(model, var_list=[[lay.q_mu, lay.q_sqrt]], maxiter=1, X=X, Y=Y, zs=zs)
+    assert_allclose(lay.q_mu.value, mu, rtol=1e-6, atol=1e-8)
+    assert_allclose(lay.q_sqrt.value, sq, rtol=1e-6, atol=1e-8)
+    # a second evaluation on the new parameters (Ku unchanged: its factor is kept; q moved) still matches the oracle
+    state2 = dict(state)
+    state2[last + ".q_mu"], state2[last + ".q_sqrt"] = mu, sq
+    assert_allclose(model._build_likelihood(X, Y, zs=zs), OM.elbo(spec, state2, X, Y, zs, S, num_data=500), rtol=1e-7)
+
+
+def test_lookahead_cholesky_reports_the_failing_pivot_of_a_later_block():
+    import ctypes as C
+    from doubly_stochastic_dgp.engine import Context
+    ctx = Context.get()
+    n = 200                                     # padded 256: two blocks, the bad pivot in the second
+    A = np.eye(n)
+    A[150, 150] = -1.0
+    dA = ctx.to_device(A)
+    info = C.c_int(0)
+    ctx.sync()
+    rc = ctx.lib.dsdgp_potrf(ctx.handle, 1, n, C.c_void_p(dA.data_ptr()), n, n * n, C.byref(info))
+    assert rc == _lib.ERR_NOT_SPD and info.value == 151
