@@ -1584,7 +1584,11 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     }
   }
   P.items0.clear();
-  for (int p = 0; p < nb; ++p) P.items0.push_back(items[(size_t)p * batch]);      // matrix 0's item per block: k_chol_block's argument
+  for (int p = 0; p < nb; ++p) {      // matrix 0's item per block: k_chol_block's argument
+    P.items0.push_back(items[(size_t)p * batch]);
+    // nobody reads L: the panel solve, the wide update and the rows of the inverse all work from L_pp^-1 — the block's own write-back goes too
+    if (P.xrows && !P.need_factor) P.items0.back().pad |= 8;
+  }
   const size_t ib = round_up(items.size() * sizeof(PotrfItem), 256), gb = round_up(gp.size() * sizeof(GemmProblem) + 256, 256);
   DS_HIP(hipMalloc(&P.dev_block, ib + gb));
   P.diag_items = (PotrfItem*)P.dev_block;
