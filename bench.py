@@ -249,7 +249,8 @@ def sub_rooflines(ctx):
         out["potrf_trtri"].append(dict(n=M, us=round(1e3 * ms / reps, 1), algorithmic_gflop=round(fl / 1e9, 3), bound="mfma",
                                        achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                        frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                                       note="one matrix; latency-bound launch sequence" if M >= 512 else
+                                       note="one matrix; look-ahead launch sequence (8 factor launches carrying the wide updates and the "
+                                            "inverse's block rows, 7 panel launches), latency-bound" if M >= 512 else
                                             "one LDS-resident workgroup; latency-bound"))
     ctx.prof_enable(False)
     # K4: the blocked triangular solve at the two right-hand-side shapes north_star names (Kuu^-1/2 Kuf: M x S N), n^2 nrhs flops

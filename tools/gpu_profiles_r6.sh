@@ -61,6 +61,12 @@ rm -rf /tmp/pp; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp
 DB=$(find /tmp/pp -name "*results.db" | head -1)
 [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $P/r06_potrf_n1024_stats.md "round 6: dsdgp_potrf n = 1024, 6 calls, then torch.linalg.cholesky (rocSOLVER) of the same matrix once" > /dev/null
 grep "potrf n=\|relerr" $O/potrf.log > $P/r06_potrf_n1024_wall.txt
+# factor + inverse of Ku through the model path (what sub_rooflines.potrf_trtri times): look-ahead sequence against the plain blocked one, then
+# the launch timeline of one M = 1024 sequence and dsdgp_potrf's orders / residuals
+(cd $R && (echo "== look-ahead sequence (default)"; timeout 300 python tools/potrf_model_time.py 192 256 512 1024 2048; echo "== DSDGP_CHOL_LOOKAHEAD=0 (plain blocked sequence, recursive-doubling inverse)"; DSDGP_CHOL_LOOKAHEAD=0 timeout 300 python tools/potrf_model_time.py 192 256 512 1024 2048; echo "== dsdgp_potrf (wall, pad + factor + unpad)"; timeout 300 python tools/potrf_check.py) 2>&1 | grep -v amdgpu.ids > $P/r06_potrf_model_path.txt)
+rm -rf /tmp/pm; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pm -o p -- python $R/tools/potrf_model_time.py 1024 > /dev/null 2>&1)
+DB=$(find /tmp/pm -name "*results.db" | head -1)
+[ -n "$DB" ] && python $R/tools/timeline_dump.py $DB k_chol_xrow 3 > $P/r06_potrf_model_path_timeline.txt
 # shard steps of a strong-scaling run (1000 / 500 / 250 / 125 rows: fused, elbo + adam, data-parallel flat / bucketed over a one-rank RCCL group)
 (cd $R && timeout 600 python tools/bench_shards.py 2>/dev/null | grep "^{" > $P/r06_strong_scaling_shards.jsonl)
 # one step's timeline at the 125-row shard
