@@ -198,6 +198,98 @@ __device__ __forceinline__ double bern_var_exp(double mu, double v, double y, do
   return ve;
 }
 
+// ---- [UPSTREAM] further GPflow 1.1.1 likelihoods behind BroadcastingLikelihood (utils.py:54-121 wraps ANY likelihood): Poisson and
+// Exponential with the exp link, StudentT.  kind = DSDGP_LIK_*; p0 = StudentT.scale, p1 = Poisson.binsize / StudentT.deg_free.
+// log p(y | f)
+__device__ __forceinline__ double lik_logp(int kind, double f, double y, double p0, double p1) {
+  if (kind == 3) return y * (f + log(p1)) - exp(f) * p1 - lgamma(y + 1.0);      // Poisson: y log(lam) - lam - lgamma(y + 1), lam = exp(f) binsize
+  if (kind == 4) return -y * exp(-f) - f;                                       // Exponential: -y / scale - log(scale), scale = exp(f)
+  const double nu = p1, z = (y - f) / p0;                                       // StudentT
+  return lgamma(0.5 * (nu + 1.0)) - lgamma(0.5 * nu) - 0.5 * (log(nu) + 1.1447298858494001741) - log(p0) -
+         0.5 * (nu + 1.0) * log(1.0 + z * z / nu);
+}
+// conditional mean / variance of y given f
+__device__ __forceinline__ void lik_cond(int kind, double f, double p0, double p1, double* cm, double* cv) {
+  if (kind == 3) { *cm = *cv = exp(f) * p1; return; }
+  if (kind == 4) { const double e = exp(f); *cm = e; *cv = e * e; return; }
+  *cm = f;
+  *cv = p0 * p0 * (p1 / (p1 - 2.0));
+}
+#define DSDGP_GH20_X {0.24534070830090124, 0.7374737285453944, 1.234076215395323, 1.7385377121165861, 2.2549740020892757, \
+                      2.7888060584281305, 3.3478545673832163, 3.944764040115625, 4.603682449550744, 5.387480890011233}
+#define DSDGP_GH20_W {0.2607930634495549, 0.16173933398399998, 0.0615063720639769, 0.013997837447101022, 0.00183010313108049, \
+                      0.00012882627996192928, 4.402121090230851e-06, 6.127490259982928e-08, 2.4820623623151755e-10, 1.2578006724379234e-13}
+// variational expectation int log p(y | f) N(f | mu, v) df and its derivatives w.r.t. mu, v and p0: the closed forms GPflow uses with
+// the exp link (Poisson, Exponential), the base Likelihood's 20-point Gauss-Hermite rule (weights / sqrt(pi)) for StudentT
+__device__ __forceinline__ double lik_var_exp(int kind, double mu, double v, double y, double p0, double p1, double* dmu, double* dv,
+                                              double* dp0) {
+  *dp0 = 0.0;
+  if (kind == 3) {
+    const double e = exp(mu + 0.5 * v) * p1;
+    *dmu = y - e;
+    *dv = -0.5 * e;
+    return y * mu - e - lgamma(y + 1.0) + y * log(p1);
+  }
+  if (kind == 4) {
+    const double e = exp(-mu + 0.5 * v) * y;
+    *dmu = e - 1.0;
+    *dv = -0.5 * e;
+    return -e - mu;
+  }
+  constexpr double GX[10] = DSDGP_GH20_X;
+  constexpr double GW[10] = DSDGP_GH20_W;
+  const double sd = sqrt(2.0 * v), nu = p1;
+  const double c0 = lgamma(0.5 * (nu + 1.0)) - lgamma(0.5 * nu) - 0.5 * (log(nu) + 1.1447298858494001741) - log(p0);
+  double ve = 0.0, gm = 0.0, gv = 0.0, gp = 0.0;
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    const double x = (k < 10) ? -GX[9 - k] : GX[k - 10];
+    const double w = (k < 10) ? GW[9 - k] : GW[k - 10];
+    const double r = y - (mu + sd * x), den = nu * p0 * p0 + r * r;
+    ve += w * (c0 - 0.5 * (nu + 1.0) * log(den / (nu * p0 * p0)));
+    const double dl = (nu + 1.0) * r / den;                       // d log p / d f
+    gm += w * dl;
+    gv += w * dl * x;
+    gp += w * (-1.0 / p0 + (nu + 1.0) * r * r / (p0 * den));      // d log p / d scale
+  }
+  *dmu = gm;
+  *dv = gv / sd;
+  *dp0 = gp;
+  return ve;
+}
+// log int p(y | f) N(f | mu, v) df (predict_density) by the same rule
+__device__ __forceinline__ double lik_log_density(int kind, double mu, double v, double y, double p0, double p1) {
+  constexpr double GX[10] = DSDGP_GH20_X;
+  constexpr double GW[10] = DSDGP_GH20_W;
+  const double sd = sqrt(2.0 * v);
+  double s = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 20; ++k) {
+    const double x = (k < 10) ? -GX[9 - k] : GX[k - 10];
+    const double w = (k < 10) ? GW[9 - k] : GW[k - 10];
+    s += w * exp(lik_logp(kind, mu + sd * x, y, p0, p1));
+  }
+  return log(s);
+}
+// predict_mean_and_var: E_y = sum w cm(f_k), V_y = sum w (cv(f_k) + cm(f_k)^2) - E_y^2
+__device__ __forceinline__ void lik_predict(int kind, double mu, double v, double p0, double p1, double* ey, double* vy) {
+  constexpr double GX[10] = DSDGP_GH20_X;
+  constexpr double GW[10] = DSDGP_GH20_W;
+  const double sd = sqrt(2.0 * v);
+  double e = 0.0, q = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 20; ++k) {
+    const double x = (k < 10) ? -GX[9 - k] : GX[k - 10];
+    const double w = (k < 10) ? GW[9 - k] : GW[k - 10];
+    double cm, cv;
+    lik_cond(kind, mu + sd * x, p0, p1, &cm, &cv);
+    e += w * cm;
+    q += w * (cv + cm * cm);
+  }
+  *ey = e;
+  *vy = q - e * e;
+}
+
 // Cross-lane sums WITHOUT the LDS: __shfl_xor compiles to ds_bpermute_b32 pairs (an LDS round trip of 100-200 cycles per step when
 // 32 waves share the CU); the per-input-dimension reductions at the end of the backward chain were six such dependent steps per
 // dimension and took 23 K of the 61 K clocks of a D_out = 1 workgroup (DSDGP_BWD_TIMING, profiles/r02_chain_phases.txt, before/after in DESIGN.md 5.1).

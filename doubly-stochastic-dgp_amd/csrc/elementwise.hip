@@ -146,6 +146,70 @@ extern "C" int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const
   return DSDGP_OK;
 }
 
+// ---- Poisson / Exponential (exp link) and StudentT through BroadcastingLikelihood: the same two reductions over the samples
+__global__ void k_lik_over_samples(int kind, double p0, double p1, const double* __restrict__ mean, const double* __restrict__ var,
+                                   const double* __restrict__ Y, int64_t n, int S, int DY, int mode, const double* __restrict__ sw,
+                                   double* __restrict__ out) {
+  const int64_t total = n * DY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const double y = Y[i];
+    if (mode == 0) {
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        double dm, dv, dp;
+        const double ve = lik_var_exp(kind, mean[(int64_t)s * total + i], var[(int64_t)s * total + i], y, p0, p1, &dm, &dv, &dp);
+        acc += sw ? sw[s] * ve : ve;
+      }
+      out[i] = sw ? acc : acc / S;
+    } else {
+      double mx = -1.0 / 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double l = lik_log_density(kind, mean[(int64_t)s * total + i], var[(int64_t)s * total + i], y, p0, p1);
+        mx = l > mx ? l : mx;
+      }
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double l = lik_log_density(kind, mean[(int64_t)s * total + i], var[(int64_t)s * total + i], y, p0, p1);
+        acc += exp(l - mx);
+      }
+      out[i] = mx + log(acc) - log((double)S);
+    }
+  }
+}
+static bool lik_quad_kind_ok(int kind, double p0, double p1) {
+  if (kind == DSDGP_LIK_POISSON) return p1 > 0.0;
+  if (kind == DSDGP_LIK_EXPONENTIAL) return true;
+  return kind == DSDGP_LIK_STUDENT_T && p0 > 0.0 && p1 > 0.0;
+}
+extern "C" int dsdgp_lik_var_exp(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var,
+                                 const double* Y, int64_t n, int32_t S, int32_t DY, int mode, const double* sample_w, double* out) {
+  DS_CHECK_ARG(ctx && mean && var && Y && out && n > 0 && S > 0 && DY > 0 && (mode == 0 || mode == 1));
+  DS_CHECK_ARG(mode == 0 || !sample_w);
+  DS_CHECK_ARG(lik_quad_kind_ok(kind, p0, p1));
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(n * DY, 256));
+  DS_LAUNCH(k_lik_over_samples, dim3(nb), dim3(256), 0, ctx->stream, (int)kind, p0, p1, mean, var, Y, n, S, DY, mode, sample_w, out);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+__global__ void k_lik_predict(int kind, double p0, double p1, const double* __restrict__ mean, const double* __restrict__ var,
+                              int64_t count, double* __restrict__ om, double* __restrict__ ov) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    double e, q;
+    lik_predict(kind, mean[i], var[i], p0, p1, &e, &q);
+    om[i] = e;
+    ov[i] = q;
+  }
+}
+extern "C" int dsdgp_lik_predict(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var,
+                                 int64_t count, double* out_mean, double* out_var) {
+  DS_CHECK_ARG(ctx && mean && var && out_mean && out_var && count > 0);
+  DS_CHECK_ARG(lik_quad_kind_ok(kind, p0, p1));
+  const int nb = (int)std::min<int64_t>(4096, ceil_div(count, 256));
+  DS_LAUNCH(k_lik_predict, dim3(nb), dim3(256), 0, ctx->stream, (int)kind, p0, p1, mean, var, count, out_mean, out_var);
+  DS_HIP(hipGetLastError());
+  return DSDGP_OK;
+}
+
 __global__ void k_add_scalar(const double* __restrict__ in, double v, int64_t count, double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = in[i] + v;

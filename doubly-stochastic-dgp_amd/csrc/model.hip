@@ -22,7 +22,10 @@ int gram_launch(dsdgp_ctx* ctx, int kind, const double* X, int64_t n, const doub
 // ------------------------------------------------------------------------------------------------------
 static int validate_desc(const dsdgp_model_desc* d) {
   DS_CHECK_ARG(d && d->L >= 1 && d->L <= DSDGP_MAX_LAYERS && d->n_theta > 0);
-  DS_CHECK_ARG(d->lik_kind == DSDGP_LIK_GAUSSIAN || d->lik_kind == DSDGP_LIK_MULTICLASS || d->lik_kind == DSDGP_LIK_BERNOULLI);
+  DS_CHECK_ARG(d->lik_kind == DSDGP_LIK_GAUSSIAN || d->lik_kind == DSDGP_LIK_MULTICLASS || d->lik_kind == DSDGP_LIK_BERNOULLI ||
+               lik_is_generic(d->lik_kind));
+  DS_CHECK_ARG((d->lik_kind != DSDGP_LIK_POISSON && d->lik_kind != DSDGP_LIK_STUDENT_T) || d->lik_aux > 0.0);      // binsize / deg_free
+  DS_CHECK_ARG(!lik_has_param(d->lik_kind) || (d->off_lik_var >= 0 && d->off_lik_var < d->n_theta));
   for (int l = 0; l < d->L; ++l) {
     const dsdgp_layer_desc& y = d->layers[l];
     DS_CHECK_ARG(y.M >= 1 && y.D_in >= 1 && y.D_out >= 1);
@@ -288,7 +291,7 @@ extern "C" int dsdgp_model_create(dsdgp_ctx* ctx, const dsdgp_model_desc* desc, 
     if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_A >= 0) mark(y.off_mean_A, (int64_t)y.D_in * y.D_out, y.trainable_mean_A);
     if (y.mean_kind == DSDGP_MEAN_LINEAR && y.off_mean_b >= 0) mark(y.off_mean_b, y.D_out, y.trainable_mean_b);
   }
-  if (desc->lik_kind == DSDGP_LIK_GAUSSIAN) mark(desc->off_lik_var, 1, 2 * desc->trainable_lik_var);
+  if (lik_has_param(desc->lik_kind)) mark(desc->off_lik_var, 1, 2 * desc->trainable_lik_var);
   DS_HIP(hipMemcpyAsync(m->mask, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DS_HIP(hipStreamSynchronize(st));
   m->overlap = !(getenv("DSDGP_NO_OVERLAP") && atoi(getenv("DSDGP_NO_OVERLAP")));
@@ -358,7 +361,7 @@ extern "C" int dsdgp_model_set_bucket_callback(dsdgp_model* m, dsdgp_bucket_fn f
     // the buckets are contiguous SEGMENTS of theta: layer l owns [off_Z_l, off_Z_{l+1}), the likelihood variance follows the last
     // layer's segment.  A descriptor with another ordering would hand out segments that are incomplete or not yet produced.
     const int L = m->desc.L;
-    const int64_t lik_lo = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta;
+    const int64_t lik_lo = lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : m->desc.n_theta;
     for (int l = 0; l < L; ++l) {
       const dsdgp_layer_desc& d = m->L[l].d;
       const int64_t lo = d.off_Z, hi = (l + 1 < L) ? m->L[l + 1].d.off_Z : lik_lo;

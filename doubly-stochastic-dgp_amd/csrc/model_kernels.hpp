@@ -384,6 +384,47 @@ __global__ __launch_bounds__(256) void k_lik_bern(const double* __restrict__ mea
   }
 }
 
+// [UPSTREAM] Poisson / Exponential (exp link) and StudentT variational expectations (common.hpp: lik_var_exp) and their adjoints; same
+// outputs as k_lik_gauss — the second partial is d/d(scale) for StudentT (lik_const[0] = scale), zero for the other two
+__global__ __launch_bounds__(256) void k_lik_gen(int kind, const double* __restrict__ lik_const, double aux,
+                                                 const double* __restrict__ mean, const double* __restrict__ var,
+                                                 const double* __restrict__ Y, int64_t n, int S, int DY, double w,
+                                                 const double* __restrict__ sw, double* __restrict__ part,
+                                                 double* __restrict__ dmean, double* __restrict__ dvar,
+                                                 double* __restrict__ MBt, double* __restrict__ VBt, int64_t ldt) {
+  __shared__ double sh[4];
+  const double p0 = (kind == DSDGP_LIK_STUDENT_T) ? lik_const[0] : 1.0;
+  const int64_t total = (int64_t)S * n * DY;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double ve = 0.0, dl = 0.0;
+  if (idx < total) {
+    const int64_t row = idx / DY;
+    const int dd = (int)(idx % DY);
+    const double y = Y[(row % n) * DY + dd];
+    const double f = sw ? sw[row / n] * S : 1.0;
+    double dm, dv, dp;
+    ve = f * lik_var_exp(kind, mean[idx], var[idx], y, p0, aux, &dm, &dv, &dp);
+    dl = f * dp;
+    if (dmean) {
+      dmean[idx] = -w * f * dm;
+      dvar[idx] = -w * f * dv;
+    }
+    if (MBt) {
+      MBt[(int64_t)dd * ldt + row] = -w * f * dm;
+      VBt[(int64_t)dd * ldt + row] = -w * f * dv;
+    }
+  } else if (MBt && idx < ldt * DY) {      // rows of the 16-row padding
+    MBt[(idx % DY) * ldt + idx / DY] = 0.0;
+    VBt[(idx % DY) * ldt + idx / DY] = 0.0;
+  }
+  const double a = block_sum_256(ve, sh);
+  const double b = block_sum_256(dl, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = b;
+  }
+}
+
 // per-sample quadrature weights applied to per-row values (R = S*n rows) and the (R x K) adjoints (MultiClass + DGP_Quad)
 __global__ void k_scale_by_sample(const double* __restrict__ sw, int64_t n, int S, int K, int64_t R, double* __restrict__ ve,
                                   double* __restrict__ dmean, double* __restrict__ dvar) {

@@ -59,12 +59,12 @@ static int prepare_async(dsdgp_model* m, bool with_grad = false, bool side = fal
     g_dsdgp_launches.fetch_add(1, std::memory_order_relaxed);
     hipExtLaunchKernelGGL(k_head, dim3(1 + nprep + r.nblk + gq.nblk, L), dim3(HEAD_THREADS), (uint32_t)lds, ctx->stream, nullptr,
                           head_event ? m->ev_fork : nullptr, 0, (const double*)m->theta, (const LayerDev*)m->layers_dev, m->lik_const,
-                          (int64_t)m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter, nprep,
+                          (int64_t)m->desc.off_lik_var, lik_has_param(m->desc.lik_kind) ? 1 : 0, m->desc.jitter, nprep,
                           keep_kuu ? 1 : 0, m->desc.white ? 1 : 0, getenv("DSDGP_POTRF_TIMING") ? 1 : 0, r, gq);
     DS_HIP(hipGetLastError());
   } else if (!unchanged) {
     DS_LAUNCH(k_prep_kuu, dim3(m->prep_blocks + (keep_kuu ? 0 : m->kuu_blocks), L), dim3(256), 0, ctx->stream, m->theta, m->layers_dev,
-                       m->lik_const, m->desc.off_lik_var, m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? 1 : 0, m->desc.jitter,
+                       m->lik_const, m->desc.off_lik_var, lik_has_param(m->desc.lik_kind) ? 1 : 0, m->desc.jitter,
                        m->prep_blocks, keep_kuu ? 1 : 0);
     DS_HIP(hipGetLastError());
   }
@@ -471,7 +471,7 @@ static int ensure_plan(dsdgp_model* m, int64_t n, int S) {
 static int launch_finalize(dsdgp_model* m, hipStream_t st) {
   DS_LAUNCH(k_finalize, dim3(1), dim3(256), 0, st, m->layers_dev, m->desc.L, m->lik_part, m->fin.nblocks, m->fin.w,
                      m->fin.kl_weight, m->lik_const, m->grad,
-                     m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.with_grad, m->fin.out);
+                     lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : (int64_t)-1, m->fin.with_grad, m->fin.out);
   DS_HIP(hipGetLastError());
   m->fin.done = true;
   return DSDGP_OK;
@@ -523,7 +523,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
       // likelihood variance or the vector ends)
       const int64_t lo = St.d.off_Z;
       const int64_t hi = (l + 1 < L) ? m->L[l + 1].d.off_Z
-                                     : (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta);
+                                     : (lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : m->desc.n_theta);
       m->bucket_fn(m->bucket_user, l, m->grad + lo, hi - lo, (void*)st);
     }
     return DSDGP_OK;
@@ -675,12 +675,12 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     // last bucket: likelihood-variance gradient and the four result scalars (contiguous behind the layers' segments when `out`
     // is grad + n_theta, as the contract of dsdgp_allreduce asks)
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
-              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
+              lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{};
     DS_LAUNCH(k_tail, dim3(1), dim3(256), 0, ctx->stream, m->layers_dev, 0, 0, m->grad, F, A);
     DS_HIP(hipGetLastError());
     m->fin.done = true;
-    const int64_t lo = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : m->desc.n_theta;
+    const int64_t lo = lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : m->desc.n_theta;
     const bool tail_scalars = m->fin.out == m->grad + m->desc.n_theta;
     m->bucket_fn(m->bucket_user, L, m->grad + lo, (m->desc.n_theta - lo) + (tail_scalars ? 4 : 0), (void*)ctx->stream);
     if (!tail_scalars) m->bucket_fn(m->bucket_user, L + 1, m->fin.out, 4, (void*)ctx->stream);
@@ -690,7 +690,7 @@ static int backward_layers(dsdgp_model* m, int64_t n, int S, double kl_weight) {
     DS_LAUNCH(k_asm_rows, dim3(m->m_max_all, La), dim3(256), (size_t)m->mp_max_all * sizeof(double), ctx->stream, lay, m->grad,
                        kl_weight, m->mp_max_all, m->force.asm_pre);
     FinArgs F{m->lik_part, m->fin.nblocks, m->fin.w, m->fin.kl_weight, m->lik_const,
-              m->desc.lik_kind == DSDGP_LIK_GAUSSIAN ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
+              lik_has_param(m->desc.lik_kind) ? m->desc.off_lik_var : (int64_t)-1, m->fin.out, L, 1};
     AdamArgs A{m->theta, m->adam_m, m->adam_v, m->mask, m->desc.n_theta, m->fuse_adam.lr_t, m->fuse_adam.b1, m->fuse_adam.b2,
                m->fuse_adam.eps, (m->fuse_adam.on && gfirst == 0) ? 1 : 0};
     const int nadam = A.on ? (int)std::min<int64_t>(2048, ceil_div(m->desc.n_theta, 512)) : 0;      // a thread per pair of entries, eight workgroups per CU
@@ -769,7 +769,7 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
   // the last layer of a deep model has one output row per input row: its transposed adjoints come straight from the
   // likelihood kernel (no k_adj_prep launch on the critical path) — or, Gaussian likelihood without quadrature weights, from the
   // last forward chain's own epilogue (no likelihood launch either)
-  const bool elementwise = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN || m->desc.lik_kind == DSDGP_LIK_BERNOULLI;
+  const bool elementwise = m->desc.lik_kind == DSDGP_LIK_GAUSSIAN || m->desc.lik_kind == DSDGP_LIK_BERNOULLI || lik_is_generic(m->desc.lik_kind);
   m->fused_last = with_grad && L > 1 && elementwise;
   const bool lik_in_chain = m->fused_last && m->desc.lik_kind == DSDGP_LIK_GAUSSIAN && !m->sample_w && m->force.lik_fuse != 0;
   int lik_nb = 0;
@@ -787,9 +787,12 @@ static int elbo_impl(dsdgp_model* m, const double* X, const double* Y, int64_t n
     if (m->desc.lik_kind == DSDGP_LIK_GAUSSIAN)
       DS_LAUNCH(k_lik_gauss, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, m->lik_const,
                          w, m->sample_w, m->lik_part, dm, dv, mbt, vbt, ldt);
-    else
+    else if (m->desc.lik_kind == DSDGP_LIK_BERNOULLI)
       DS_LAUNCH(k_lik_bern, dim3(nblocks), dim3(256), 0, ctx->stream, last.mean, last.var, Y, n, S, DY, w, m->sample_w,
                          m->lik_part, dm, dv, mbt, vbt, ldt);
+    else
+      DS_LAUNCH(k_lik_gen, dim3(nblocks), dim3(256), 0, ctx->stream, (int)m->desc.lik_kind, (const double*)m->lik_const, m->desc.lik_aux,
+                         last.mean, last.var, Y, n, S, DY, w, m->sample_w, m->lik_part, dm, dv, mbt, vbt, ldt);
   } else {
     // MultiClass: Y is (n x 1) labels, the last layer has K = num_classes outputs; ve per (s, i) row -> last.F scratch
     DS_CHECK_ARG(DY == m->desc.num_classes);

@@ -10,7 +10,7 @@ _LIB_PATH = os.environ.get("DSDGP_LIB_PATH") or os.path.join(os.path.dirname(_HE
 DSDGP_MAX_LAYERS = 16
 KERN_RBF, KERN_MATERN52 = 0, 1
 MEAN_ZERO, MEAN_IDENTITY, MEAN_LINEAR = 0, 1, 2
-LIK_GAUSSIAN, LIK_MULTICLASS, LIK_BERNOULLI = 0, 1, 2
+LIK_GAUSSIAN, LIK_MULTICLASS, LIK_BERNOULLI, LIK_POISSON, LIK_EXPONENTIAL, LIK_STUDENT_T = 0, 1, 2, 3, 4, 5
 ERR_NOT_SPD = -2
 ERR_RCCL = -6
 
@@ -48,7 +48,7 @@ class LayerDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("L", C.c_int32), ("white", C.c_int32), ("lik_kind", C.c_int32), ("num_classes", C.c_int32),
                 ("trainable_lik_var", C.c_int32), ("reserved", C.c_int32),
-                ("jitter", C.c_double), ("off_lik_var", C.c_int64), ("n_theta", C.c_int64),
+                ("jitter", C.c_double), ("lik_aux", C.c_double), ("off_lik_var", C.c_int64), ("n_theta", C.c_int64),
                 ("layers", LayerDesc * DSDGP_MAX_LAYERS)]
 
 
@@ -114,6 +114,10 @@ _PROTOS = {
     "dsdgp_bernoulli_var_exp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                           C.c_int, C.c_void_p, C.c_void_p]),
     "dsdgp_bernoulli_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dsdgp_lik_var_exp": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
+    "dsdgp_lik_predict": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p]),
     "dsdgp_model_set_grad_first_layer": (C.c_int, [C.c_void_p, C.c_int32]),
     "dsdgp_model_set_grad_q_only": (C.c_int, [C.c_void_p, C.c_int32]),
     "dsdgp_model_track_theta": (C.c_int, [C.c_void_p, C.c_int]),

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, settings
-from .gpflow_compat import (Bernoulli, Gaussian, MultiClass, Parameter, positive_backward, positive_forward, split_kernel)
+from .gpflow_compat import (Bernoulli, Exponential, Gaussian, MultiClass, Parameter, Poisson, StudentT, positive_backward, positive_forward, split_kernel)
 
 _KIND = {"rbf": _lib.KERN_RBF, "matern52": _lib.KERN_MATERN52}
 _MEAN = {"zero": _lib.MEAN_ZERO, "identity": _lib.MEAN_IDENTITY, "linear": _lib.MEAN_LINEAR}
@@ -173,6 +173,23 @@ class Engine:
         elif isinstance(self.likelihood, Bernoulli):
             d.lik_kind = _lib.LIK_BERNOULLI
             d.off_lik_var = -1
+        elif isinstance(self.likelihood, Poisson):
+            d.lik_kind = _lib.LIK_POISSON
+            d.lik_aux = self.likelihood.binsize
+            d.off_lik_var = -1
+        elif isinstance(self.likelihood, Exponential):
+            d.lik_kind = _lib.LIK_EXPONENTIAL
+            d.off_lik_var = -1
+        elif isinstance(self.likelihood, StudentT):
+            d.lik_kind = _lib.LIK_STUDENT_T
+            d.lik_aux = self.likelihood.deg_free
+            p = self.likelihood.scale           # the likelihood's one positive parameter: the slot Gaussian.variance takes
+            self.entries.append((p, off, 1, "pos"))
+            if self not in p._owners:
+                p._owners.append(self)
+            d.off_lik_var = off
+            d.trainable_lik_var = int(p.trainable)
+            off += 1
         else:
             raise NotImplementedError(type(self.likelihood).__name__)
         d.n_theta = off
@@ -518,6 +535,8 @@ class Engine:
                 names[id(layer.mean_function.b)] = f"l{l}.mean_b"
         if isinstance(self.likelihood, Gaussian):
             names[id(self.likelihood.variance)] = "lik_variance_raw"
+        if isinstance(self.likelihood, StudentT):
+            names[id(self.likelihood.scale)] = "lik_variance_raw"
         for p, off, cnt, kind in self.entries:
             out[names[id(p)]] = g[off:off + cnt].reshape(p.shape).copy()
         return out

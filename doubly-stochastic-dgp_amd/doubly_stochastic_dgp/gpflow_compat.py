@@ -242,6 +242,42 @@ class Bernoulli(Likelihood):
             raise NotImplementedError("only the default probit link is on the built path")
 
 
+def _exp_link_only(invlink):
+    if invlink is not None and invlink is not np.exp and getattr(invlink, "__name__", "") != "exp":
+        raise NotImplementedError("only the default exp link is on the built path")
+
+
+class Poisson(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.Poisson(invlink=tf.exp, binsize=1.): counts with rate exp(f) * binsize (no free parameter)."""
+    kind = "poisson"
+
+    def __init__(self, invlink=None, binsize=1.0):
+        _exp_link_only(invlink)
+        self.binsize = float(binsize)
+        if not self.binsize > 0.0:
+            raise ValueError("binsize must be positive")
+
+
+class Exponential(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.Exponential(invlink=tf.exp): positive targets with scale exp(f) (no free parameter)."""
+    kind = "exponential"
+
+    def __init__(self, invlink=None):
+        _exp_link_only(invlink)
+
+
+class StudentT(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.StudentT(scale=1.0, deg_free=3.0): `scale` is a positive (trainable) Parameter, `deg_free` a
+    constant."""
+    kind = "student_t"
+
+    def __init__(self, scale=1.0, deg_free=3.0):
+        self.deg_free = float(deg_free)
+        if not self.deg_free > 0.0:
+            raise ValueError("deg_free must be positive")
+        self.scale = Parameter(scale, transform="positive")
+
+
 class InducingPoints(Parameterized):
     """[UPSTREAM] gpflow.features.InducingPoints — holder of Z (layers.py:153)."""
 

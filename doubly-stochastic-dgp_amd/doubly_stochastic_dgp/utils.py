@@ -49,12 +49,25 @@ class BroadcastingLikelihood:
 
     def __init__(self, likelihood):
         self.likelihood = likelihood
-        from .gpflow_compat import Bernoulli, Gaussian, MultiClass
+        from .gpflow_compat import Bernoulli, Exponential, Gaussian, MultiClass, Poisson, StudentT
         self.needs_broadcasting = not isinstance(likelihood, Gaussian)
         self.bernoulli = isinstance(likelihood, Bernoulli)
-        if not isinstance(likelihood, (Gaussian, MultiClass, Bernoulli)):
+        # Poisson / Exponential (exp link) / StudentT: elementwise like Bernoulli, evaluated by dsdgp_lik_var_exp / dsdgp_lik_predict
+        self.generic = isinstance(likelihood, (Poisson, Exponential, StudentT))
+        if not isinstance(likelihood, (Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT)):
             raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
-                                      "(Gaussian, MultiClass, Bernoulli are)")
+                                      "(Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT are)")
+
+    def generic_args(self):
+        """(kind, p0, p1) of dsdgp_lik_var_exp / dsdgp_lik_predict: p0 = StudentT.scale, p1 = Poisson.binsize / StudentT.deg_free."""
+        from . import _lib
+        from .gpflow_compat import Exponential, Poisson
+        lik = self.likelihood
+        if isinstance(lik, Poisson):
+            return _lib.LIK_POISSON, 1.0, lik.binsize
+        if isinstance(lik, Exponential):
+            return _lib.LIK_EXPONENTIAL, 1.0, 1.0
+        return _lib.LIK_STUDENT_T, float(lik.scale.value), lik.deg_free
 
     def check_targets(self, Y):
         """MultiClass: Y must hold integer class labels in [0, num_classes) — the device kernel indexes its per-class
@@ -62,10 +75,11 @@ class BroadcastingLikelihood:
         if not self.needs_broadcasting:
             return
         Y = np.asarray(Y, dtype=np.float64)
-        if self.bernoulli:
-            # [UPSTREAM] tf.where(tf.equal(Y, 1), p, 1 - p): any finite target is accepted (the reference test draws -1 / 1)
+        if self.bernoulli or self.generic:
+            # [UPSTREAM] tf.where(tf.equal(Y, 1), p, 1 - p): any finite target is accepted (the reference test draws -1 / 1); the
+            # count / positive-target likelihoods evaluate their log densities on whatever finite targets they are given, as upstream
             if Y.ndim != 2 or not np.all(np.isfinite(Y)):
-                raise ValueError(f"Bernoulli targets must be a finite (N, D) array, got shape {Y.shape}")
+                raise ValueError(f"{type(self.likelihood).__name__} targets must be a finite (N, D) array, got shape {Y.shape}")
             return
         K = self.likelihood.num_classes
         if Y.ndim != 2 or Y.shape[1] != 1:
@@ -97,6 +111,10 @@ class BroadcastingLikelihood:
         elif self.bernoulli:
             out = ctx.empty(N, D)
             _lib.check(ctx.lib.dsdgp_bernoulli_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
+        elif self.generic:
+            out = ctx.empty(N, D)
+            kind, p0, p1 = self.generic_args()
+            _lib.check(ctx.lib.dsdgp_lik_var_exp(ctx.handle, kind, p0, p1, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
         else:
             out = ctx.empty(N, 1)
             _lib.check(ctx.lib.dsdgp_multiclass_var_exp(ctx.handle, ptr(m), ptr(v), ptr(y), N, S, D, mode, wp, ptr(out)))
@@ -129,6 +147,11 @@ class BroadcastingLikelihood:
         om, ov = ctx.empty(S, N, K), ctx.empty(S, N, K)
         if self.bernoulli:
             _lib.check(ctx.lib.dsdgp_bernoulli_predict(ctx.handle, ptr(m), ptr(v), S * N * K, ptr(om), ptr(ov)))
+            ctx.sync()
+            return om.cpu().numpy(), ov.cpu().numpy()
+        if self.generic:
+            kind, p0, p1 = self.generic_args()
+            _lib.check(ctx.lib.dsdgp_lik_predict(ctx.handle, kind, p0, p1, ptr(m), ptr(v), S * N * K, ptr(om), ptr(ov)))
             ctx.sync()
             return om.cpu().numpy(), ov.cpu().numpy()
         _lib.check(ctx.lib.dsdgp_multiclass_predict(ctx.handle, ptr(m), ptr(v), S * N, K, ptr(om), ptr(ov)))

@@ -41,8 +41,10 @@ typedef enum {
 
 enum { DSDGP_KERN_RBF = 0, DSDGP_KERN_MATERN52 = 1 };            /* [UPSTREAM] gpflow.kernels */
 enum { DSDGP_MEAN_ZERO = 0, DSDGP_MEAN_IDENTITY = 1, DSDGP_MEAN_LINEAR = 2 }; /* layer_initializations.py:30-42,51 */
-enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1, DSDGP_LIK_BERNOULLI = 2 };   /* dgp.py:57, utils.py:54-93,
+enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1, DSDGP_LIK_BERNOULLI = 2,     /* dgp.py:57, utils.py:54-93,
                                                                                        * tests/test_dgp.py:48-54 */
+       /* further likelihoods utils.py:54-121 can wrap ([UPSTREAM] gpflow 1.1.1 likelihoods.py), exp links / StudentT: */
+       DSDGP_LIK_POISSON = 3, DSDGP_LIK_EXPONENTIAL = 4, DSDGP_LIK_STUDENT_T = 5 };
 
 #define DSDGP_MAX_LAYERS 16
 
@@ -136,7 +138,8 @@ typedef struct {
   int32_t trainable_lik_var;
   int32_t reserved;
   double jitter;                   /* settings.jitter, layers.py:171, utils.py:41 */
-  int64_t off_lik_var;             /* scalar, softplus^-1(Gaussian.variance) */
+  double lik_aux;                  /* the likelihood's constant: Poisson.binsize, StudentT.deg_free (else ignored) */
+  int64_t off_lik_var;             /* scalar, softplus^-1 of the likelihood's positive parameter: Gaussian.variance, StudentT.scale */
   int64_t n_theta;
   dsdgp_layer_desc layers[DSDGP_MAX_LAYERS];
 } dsdgp_model_desc;
@@ -313,6 +316,16 @@ int dsdgp_bernoulli_var_exp(dsdgp_ctx* ctx, const double* mean, const double* va
 /* Bernoulli.predict_mean_and_var (probit closed form): out_mean = probit(mean / sqrt(1 + var)), out_var = p - p^2. */
 int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t count, double* out_mean,
                             double* out_var);
+
+/* BroadcastingLikelihood over Poisson(invlink=exp, binsize) / Exponential(invlink=exp) / StudentT(scale, deg_free)
+ * (utils.py:76-93,95-121; [UPSTREAM] gpflow 1.1.1 likelihoods: closed-form variational expectations with the exp link, the base
+ * class's 20-point Gauss-Hermite rule otherwise).  kind = DSDGP_LIK_POISSON / _EXPONENTIAL / _STUDENT_T; p0 = StudentT.scale,
+ * p1 = Poisson.binsize / StudentT.deg_free (ignored where the likelihood has no such parameter).  Modes, shapes: as above. */
+int dsdgp_lik_var_exp(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var, const double* Y,
+                      int64_t n, int32_t S, int32_t DY, int mode, const double* sample_w, double* out);
+/* Likelihood.predict_mean_and_var by the same rule: E_y = sum w cm(f_k), V_y = sum w (cv(f_k) + cm(f_k)^2) - E_y^2. */
+int dsdgp_lik_predict(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var, int64_t count,
+                      double* out_mean, double* out_var);
 
 /* out = in + value (Gaussian.predict_mean_and_var adds the noise variance, dgp.py:116-119). */
 int dsdgp_add_scalar(dsdgp_ctx* ctx, const double* in, double value, int64_t count, double* out);

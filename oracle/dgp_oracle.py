@@ -411,6 +411,114 @@ class Bernoulli:
         return self._logp(xp, p, self._one(xp, Y, p))
 
 
+class _QuadratureLikelihood:
+    """[UPSTREAM] gpflow 1.1.1 likelihoods.Likelihood: the base class's 20-point Gauss-Hermite rule for everything a subclass does
+    not override — X = mu + sqrt(2 var) x_k, weights w_k / sqrt(pi):
+        variational_expectations = sum_k w_k logp(X_k, Y)
+        predict_density          = log sum_k w_k exp(logp(X_k, Y))
+        predict_mean_and_var     : E_y = sum_k w_k cm(X_k),  V_y = sum_k w_k (cv(X_k) + cm(X_k)^2) - E_y^2
+    (cm / cv = conditional_mean / conditional_variance).  BroadcastingLikelihood (utils.py:76-86) flattens to (S*N, D) with Y tiled:
+    elementwise, so shapes are kept here and Y broadcasts over the leading sample axis."""
+    H = 20
+
+    def _gh(self):
+        gh_x, gh_w = np.polynomial.hermite.hermgauss(self.H)
+        return gh_x, gh_w / math.sqrt(math.pi)
+
+    def variational_expectations(self, xp, Fmu, Fvar, Y):
+        gh_x, gh_w = self._gh()
+        out = 0.0
+        for x, w in zip(gh_x, gh_w):
+            out = out + float(w) * self.logp(xp, Fmu + xp.sqrt(2.0 * Fvar) * float(x), Y)
+        return out
+
+    def predict_density(self, xp, Fmu, Fvar, Y):
+        gh_x, gh_w = self._gh()
+        out = 0.0
+        for x, w in zip(gh_x, gh_w):
+            out = out + float(w) * xp.exp(self.logp(xp, Fmu + xp.sqrt(2.0 * Fvar) * float(x), Y))
+        return xp.log(out)
+
+    def predict_mean_and_var(self, xp, Fmu, Fvar):
+        gh_x, gh_w = self._gh()
+        e, q = 0.0, 0.0
+        for x, w in zip(gh_x, gh_w):
+            X = Fmu + xp.sqrt(2.0 * Fvar) * float(x)
+            cm = self.conditional_mean(xp, X)
+            e = e + float(w) * cm
+            q = q + float(w) * (self.conditional_variance(xp, X) + cm ** 2)
+        return e, q - e ** 2
+
+
+def _lgamma(xp, x):
+    if xp is NP:
+        return __import__("scipy.special", fromlist=["gammaln"]).gammaln(x)
+    return TH._t.lgamma(x)
+
+
+class Poisson(_QuadratureLikelihood):
+    """[UPSTREAM] gpflow 1.1.1 Poisson(invlink=tf.exp, binsize=1.): logp = Y log(lam) - lam - lgamma(Y + 1), lam = exp(F) binsize;
+    conditional mean = variance = lam; with the exp link the variational expectations are closed-form:
+    Y Fmu - exp(Fmu + Fvar / 2) binsize - lgamma(Y + 1) + Y log(binsize)."""
+    kind = "poisson"
+
+    def __init__(self, binsize=1.0):
+        self.binsize = float(binsize)
+
+    def logp(self, xp, F, Y):
+        Y = xp.asarray(Y)
+        return Y * (F + math.log(self.binsize)) - xp.exp(F) * self.binsize - _lgamma(xp, Y + 1.0)
+
+    def conditional_mean(self, xp, F):
+        return xp.exp(F) * self.binsize
+
+    conditional_variance = conditional_mean
+
+    def variational_expectations(self, xp, Fmu, Fvar, Y):
+        Y = xp.asarray(Y)
+        return Y * Fmu - xp.exp(Fmu + Fvar / 2.0) * self.binsize - _lgamma(xp, Y + 1.0) + Y * math.log(self.binsize)
+
+
+class Exponential(_QuadratureLikelihood):
+    """[UPSTREAM] gpflow 1.1.1 Exponential(invlink=tf.exp): logp = -Y / scale - log(scale), scale = exp(F); conditional mean = scale,
+    variance = scale^2; closed-form variational expectations with the exp link: -exp(-Fmu + Fvar / 2) Y - Fmu."""
+    kind = "exponential"
+
+    def logp(self, xp, F, Y):
+        return -xp.asarray(Y) * xp.exp(-F) - F
+
+    def conditional_mean(self, xp, F):
+        return xp.exp(F)
+
+    def conditional_variance(self, xp, F):
+        return xp.exp(F) ** 2
+
+    def variational_expectations(self, xp, Fmu, Fvar, Y):
+        return -xp.exp(-Fmu + Fvar / 2.0) * xp.asarray(Y) - Fmu
+
+
+class StudentT(_QuadratureLikelihood):
+    """[UPSTREAM] gpflow 1.1.1 StudentT(scale=1.0, deg_free=3.0): `scale` a positive Parameter (trainable), `deg_free` a constant;
+    logp = lgamma((nu + 1) / 2) - lgamma(nu / 2) - (log nu + log pi) / 2 - log(scale) - (nu + 1) / 2 log(1 + ((Y - F) / scale)^2 / nu);
+    conditional mean F, conditional variance scale^2 nu / (nu - 2); everything else by the base class's quadrature."""
+    kind = "student_t"
+
+    def __init__(self, scale=1.0, deg_free=3.0):
+        self.scale, self.deg_free = scale, float(deg_free)
+
+    def logp(self, xp, F, Y):
+        nu = self.deg_free
+        const = math.lgamma((nu + 1.0) / 2.0) - math.lgamma(nu / 2.0) - 0.5 * (math.log(nu) + math.log(math.pi))
+        sc = self.scale * xp.ones(1)
+        return const - xp.log(sc) - 0.5 * (nu + 1.0) * xp.log(1.0 + (1.0 / nu) * ((xp.asarray(Y) - F) / sc) ** 2)
+
+    def conditional_mean(self, xp, F):
+        return F
+
+    def conditional_variance(self, xp, F):
+        return (self.scale * xp.ones(1)) ** 2 * (self.deg_free / (self.deg_free - 2.0)) + 0.0 * F
+
+
 # --------------------------------------------------------------------------------------------------
 # dgp.py:42-126  DGP_Base
 # --------------------------------------------------------------------------------------------------

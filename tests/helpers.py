@@ -20,11 +20,12 @@ def product_kernel(spec):
 
 
 def make_case(X, Y, Z, kern_specs, white=False, jitter=1e-6, lik_var=0.1, S=2, num_data=None, seed=0,
-              randomize=True, q_sqrt_scale=None, minibatch_size=None, num_classes=None, bernoulli=False):
+              randomize=True, q_sqrt_scale=None, minibatch_size=None, num_classes=None, bernoulli=False, likelihood=None,
+              lik_aux=None):
     """Returns (spec, state, model): oracle description and the product DGP with identical parameters."""
     from doubly_stochastic_dgp import settings
     from doubly_stochastic_dgp.dgp import DGP
-    from doubly_stochastic_dgp.gpflow_compat import Bernoulli, Gaussian, MultiClass
+    from doubly_stochastic_dgp.gpflow_compat import Bernoulli, Exponential, Gaussian, MultiClass, Poisson, StudentT
     rng = np.random.RandomState(seed)
     lds = O.init_layers_linear(X, Y, Z, kern_specs, white=white, jitter=jitter, num_outputs=num_classes)
     for i, l in enumerate(lds):
@@ -34,11 +35,19 @@ def make_case(X, Y, Z, kern_specs, white=False, jitter=1e-6, lik_var=0.1, S=2, n
             l["q_sqrt"] = l["q_sqrt"] * 0.7 + 0.05 * np.tril(rng.randn(D, M, M))
         if q_sqrt_scale is not None and i < len(lds) - 1:
             l["q_sqrt"] = l["q_sqrt"] * q_sqrt_scale
-    likname = "multiclass" if num_classes else ("bernoulli" if bernoulli else "gaussian")
+    # likelihood: "poisson" (lik_aux = binsize) / "exponential" / "student_t" (lik_var = scale, lik_aux = deg_free)
+    likname = likelihood or ("multiclass" if num_classes else ("bernoulli" if bernoulli else "gaussian"))
     sl, state = OM.state_from_layers(lds, lik_variance=lik_var, likelihood=likname)
-    spec = dict(jitter=jitter, white=white, likelihood=likname, layers=sl, num_classes=num_classes)
+    spec = dict(jitter=jitter, white=white, likelihood=likname, layers=sl, num_classes=num_classes, lik_aux=lik_aux)
     with settings.temp_jitter(jitter):
-        lik = MultiClass(num_classes) if num_classes else (Bernoulli() if bernoulli else Gaussian(variance=lik_var))
+        if likname == "poisson":
+            lik = Poisson(binsize=lik_aux or 1.0)
+        elif likname == "exponential":
+            lik = Exponential()
+        elif likname == "student_t":
+            lik = StudentT(scale=lik_var, deg_free=lik_aux or 3.0)
+        else:
+            lik = MultiClass(num_classes) if num_classes else (Bernoulli() if bernoulli else Gaussian(variance=lik_var))
         model = DGP(X, Y, Z, [product_kernel(k) for k in kern_specs], lik, white=white, num_outputs=num_classes,
                     num_samples=S, num_data=num_data, minibatch_size=minibatch_size)
     for l, layer in zip(lds, model.layers):

@@ -40,7 +40,7 @@ def test_struct_layout_matches_header():
     # the ctypes mirrors against the sizes the C side was compiled with (LP64): dsdgp_layer_desc = 18*4 + 8 + 8*8 (round 6: + kvar_identity, reserved0)
     lib = ctypes.CDLL(_lib.lib_path())
     assert ctypes.sizeof(_lib.LayerDesc) == lib.dsdgp_sizeof_layer_desc() == 144
-    assert ctypes.sizeof(_lib.ModelDesc) == lib.dsdgp_sizeof_model_desc() == 48 + 16 * 144
+    assert ctypes.sizeof(_lib.ModelDesc) == lib.dsdgp_sizeof_model_desc() == 56 + 16 * 144
     assert ctypes.sizeof(_lib.KernelSpec) == 40
 
 
@@ -184,3 +184,31 @@ def test_bernoulli_is_a_built_likelihood():
         lik.check_targets(np.array([[np.nan]]))
     with pytest.raises(NotImplementedError):
         Bernoulli(invlink="logit")
+
+
+def test_poisson_exponential_student_t_are_built_likelihoods():
+    """The further GPflow 1.1.1 likelihoods BroadcastingLikelihood (utils.py:54-121) can wrap here: accepted with their upstream
+    constructor signatures; other links and other likelihood classes still fail loudly."""
+    from doubly_stochastic_dgp import _lib
+    from doubly_stochastic_dgp.gpflow_compat import Exponential, Likelihood, Poisson, StudentT
+    from doubly_stochastic_dgp.utils import BroadcastingLikelihood
+    for lik, want in ((Poisson(binsize=2.0), (_lib.LIK_POISSON, 1.0, 2.0)), (Exponential(), (_lib.LIK_EXPONENTIAL, 1.0, 1.0)),
+                      (StudentT(scale=0.7, deg_free=4.0), (_lib.LIK_STUDENT_T, 0.7, 4.0))):
+        b = BroadcastingLikelihood(lik)
+        assert b.needs_broadcasting and b.generic and not b.bernoulli
+        k, p0, p1 = b.generic_args()
+        assert (k, p1) == (want[0], want[2]) and abs(p0 - want[1]) < 1e-12
+        b.check_targets(np.array([[0.0], [3.0]]))
+        with pytest.raises(ValueError):
+            b.check_targets(np.array([[np.inf]]))
+    assert StudentT().scale.trainable and abs(float(StudentT().scale.value) - 1.0) < 1e-12 and StudentT().deg_free == 3.0
+    with pytest.raises(NotImplementedError):
+        Poisson(invlink="square")
+    with pytest.raises(NotImplementedError):
+        Exponential(invlink=np.square)
+    Poisson(invlink=np.exp)
+
+    class Gamma(Likelihood):
+        pass
+    with pytest.raises(NotImplementedError):
+        BroadcastingLikelihood(Gamma())

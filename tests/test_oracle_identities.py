@@ -522,3 +522,76 @@ def test_T13_reference_held_gpr_objective():
     layer = O.SVGPLayer(kern, X, m_opt, np.linalg.cholesky(Sig)[None], O.MeanFn("zero"), white=False, jitter=jitter)
     elbo = O.DGPOracle([layer], O.Gaussian(s2)).build_likelihood(NP, X, Y, [np.zeros((1, N, 1))])
     assert_allclose(-elbo, REFERENCE_GPR_OBJECTIVE, rtol=1e-5)               # reference bar tests/test_collapsed.py:52-54
+
+
+# ---------------------------------------------------------------- Poisson / Exponential / StudentT ([UPSTREAM] gpflow 1.1.1 likelihoods.py)
+@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t"])
+def test_T14_further_likelihood_restatements(name):
+    """(a) log densities against scipy.stats; (b) the exp-link closed forms of the variational expectations against the base class's
+    20-point Gauss-Hermite rule on the same log density and against adaptive quadrature; (c) predict_density / predict_mean_and_var
+    against adaptive quadrature of exp(logp) and of the conditional moments; (d) numpy and torch backends agree."""
+    import math
+    import torch
+    from scipy import integrate, stats
+    lik = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(0.6, 4.0)}[name]
+    rng = np.random.RandomState(7)
+    for _ in range(4):
+        mu, v = float(rng.randn() * 0.7), float(0.05 + rng.rand() * 0.6)
+        y = {"poisson": float(rng.randint(0, 6)), "exponential": float(rng.rand() * 3 + 0.1), "student_t": float(rng.randn())}[name]
+        Fmu, Fvar, Y = np.array([[[mu]]]), np.array([[[v]]]), np.array([[y]])
+        f0 = float(rng.randn())
+        lp = float(np.ravel(lik.logp(O.NP, np.array(f0), np.array(y)))[0])
+        ref = {"poisson": lambda: stats.poisson.logpmf(y, 1.7 * math.exp(f0)), "exponential": lambda: stats.expon.logpdf(y, scale=math.exp(f0)),
+               "student_t": lambda: stats.t.logpdf(y, 4.0, loc=f0, scale=0.6)}[name]()
+        assert abs(lp - ref) < 1e-12 * max(1.0, abs(ref))
+        dens = lambda x: stats.norm.pdf(x, mu, math.sqrt(v))
+        lpf = lambda x: float(np.ravel(lik.logp(O.NP, np.array(x), np.array(y)))[0])
+        ve = float(lik.variational_expectations(O.NP, Fmu, Fvar, Y)[0, 0, 0])
+        ve_gh = float(O._QuadratureLikelihood.variational_expectations(lik, O.NP, Fmu, Fvar, Y)[0, 0, 0])
+        ve_q = integrate.quad(lambda x: lpf(x) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-13, epsrel=1e-13)[0]
+        assert abs(ve - ve_q) < 2e-6 * max(1.0, abs(ve_q)) and abs(ve - ve_gh) < 2e-6 * max(1.0, abs(ve))
+        pd = float(lik.predict_density(O.NP, Fmu, Fvar, Y)[0, 0, 0])
+        pd_q = math.log(integrate.quad(lambda x: math.exp(lpf(x)) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-14,
+                                       epsrel=1e-13)[0])
+        assert abs(pd - pd_q) < 1e-4 * max(1.0, abs(pd_q))
+        m, s2 = lik.predict_mean_and_var(O.NP, Fmu, Fvar)
+        cm = lambda x: float(np.ravel(lik.conditional_mean(O.NP, np.array([x])))[0])
+        cv = lambda x: float(np.ravel(lik.conditional_variance(O.NP, np.array([x])))[0])
+        em = integrate.quad(lambda x: cm(x) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-13, epsrel=1e-13)[0]
+        eq = integrate.quad(lambda x: (cv(x) + cm(x) ** 2) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-13, epsrel=1e-13)[0]
+        assert abs(float(m.ravel()[0]) - em) < 1e-6 * max(1.0, abs(em)) and abs(float(s2.ravel()[0]) - (eq - em ** 2)) < 1e-5 * max(1.0, eq)
+        lt = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(torch.tensor(0.6, dtype=torch.float64), 4.0)}[name]
+        a = (torch.tensor(Fmu), torch.tensor(Fvar), torch.tensor(Y))
+        assert abs(float(lt.variational_expectations(O.TH, *a)) - ve) < 1e-13 * max(1.0, abs(ve))
+        assert abs(float(lt.predict_density(O.TH, *a)) - pd) < 1e-13 * max(1.0, abs(pd))
+
+
+@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t"])
+def test_further_likelihoods_single_layer_elbo_and_torch_gradient(name):
+    """One-layer DGP with each further likelihood: numpy and torch backends agree on the ELBO and the torch gradient matches central
+    differences for q_mu, Z and (StudentT) the raw scale."""
+    rng = np.random.RandomState(11)
+    N, D, M, S = 12, 2, 6, 3
+    X = rng.randn(N, D)
+    Y = {"poisson": rng.poisson(2.0, (N, 1)).astype(float), "exponential": rng.exponential(1.5, (N, 1)), "student_t": rng.randn(N, 1)}[name]
+    lds = O.init_layers_linear(X, Y, X[:M].copy(), [dict(kind="rbf", input_dim=D, variance=1.2, lengthscales=0.9, ARD=False, white_variance=None)],
+                               white=False, jitter=1e-6)
+    lds[0]["q_mu"] = 0.3 * rng.randn(M, 1)
+    sl, state = OM.state_from_layers(lds, lik_variance=0.8, likelihood=name)
+    spec = dict(jitter=1e-6, white=False, likelihood=name, layers=sl, num_classes=None, lik_aux={"poisson": 1.5, "student_t": 5.0}.get(name))
+    zs = [rng.randn(S, N, 1)]
+    e = OM.elbo(spec, state, X, Y, zs, S, num_data=40)
+    et, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=40)
+    assert abs(et - e) < 1e-10 * max(1.0, abs(e))
+    keys = ["l0.q_mu", "l0.Z"] + (["lik_variance_raw"] if name == "student_t" else [])
+    assert (name == "student_t") == ("lik_variance_raw" in state)
+    for k in keys:
+        st = {kk: np.array(vv, dtype=np.float64) for kk, vv in state.items()}
+        idx = tuple(0 for _ in range(st[k].ndim))
+        h = 1e-6
+        st[k][idx] += h
+        ep = OM.elbo(spec, st, X, Y, zs, S, num_data=40)
+        st[k][idx] -= 2 * h
+        em = OM.elbo(spec, st, X, Y, zs, S, num_data=40)
+        fd = (ep - em) / (2 * h)
+        assert abs(fd - np.asarray(g[k])[idx]) < 1e-5 * max(1.0, abs(fd)), (k, fd, np.asarray(g[k])[idx])
