@@ -199,9 +199,26 @@ __device__ __forceinline__ double bern_var_exp(double mu, double v, double y, do
 }
 
 // ---- [UPSTREAM] further GPflow 1.1.1 likelihoods behind BroadcastingLikelihood (utils.py:54-121 wraps ANY likelihood): Poisson and
-// Exponential with the exp link, StudentT.  kind = DSDGP_LIK_*; p0 = StudentT.scale, p1 = Poisson.binsize / StudentT.deg_free.
-// log p(y | f)
+// Exponential / Gamma with the exp link, StudentT, Beta.  kind = DSDGP_LIK_*; p0 = StudentT.scale / Gamma.shape / Beta.scale,
+// p1 = Poisson.binsize / StudentT.deg_free.
+// digamma(x), x > 0: recurrence up to x >= 8, then the asymptotic series (error < 1e-15 there)
+__device__ __forceinline__ double digamma_d(double x) {
+  double r = 0.0;
+  while (x < 8.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double i = 1.0 / x, i2 = i * i;
+  return r + log(x) - 0.5 * i -
+         i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0 - i2 * (691.0 / 32760.0 - i2 / 12.0))))));
+}
+// log p(y | f).  Gamma (kind 6, exp link): p0 = shape.  Beta (kind 7, the Bernoulli's probit link): p0 = scale, y clipped to [1e-6, 1 - 1e-6].
 __device__ __forceinline__ double lik_logp(int kind, double f, double y, double p0, double p1) {
+  if (kind == 6) return -p0 * f - lgamma(p0) + (p0 - 1.0) * log(y) - y * exp(-f);
+  if (kind == 7) {
+    const double mean = bern_probit(f), al = mean * p0, be = p0 - al, yc = fmin(fmax(y, 1e-6), 1.0 - 1e-6);
+    return (al - 1.0) * log(yc) + (be - 1.0) * log(1.0 - yc) + lgamma(al + be) - lgamma(al) - lgamma(be);
+  }
   if (kind == 3) return y * (f + log(p1)) - exp(f) * p1 - lgamma(y + 1.0);      // Poisson: y log(lam) - lam - lgamma(y + 1), lam = exp(f) binsize
   if (kind == 4) return -y * exp(-f) - f;                                       // Exponential: -y / scale - log(scale), scale = exp(f)
   const double nu = p1, z = (y - f) / p0;                                       // StudentT
@@ -212,6 +229,8 @@ __device__ __forceinline__ double lik_logp(int kind, double f, double y, double 
 __device__ __forceinline__ void lik_cond(int kind, double f, double p0, double p1, double* cm, double* cv) {
   if (kind == 3) { *cm = *cv = exp(f) * p1; return; }
   if (kind == 4) { const double e = exp(f); *cm = e; *cv = e * e; return; }
+  if (kind == 6) { const double e = exp(f); *cm = p0 * e; *cv = p0 * e * e; return; }
+  if (kind == 7) { const double m = bern_probit(f); *cm = m; *cv = (m - m * m) / (p0 + 1.0); return; }
   *cm = f;
   *cv = p0 * p0 * (p1 / (p1 - 2.0));
 }
@@ -236,8 +255,37 @@ __device__ __forceinline__ double lik_var_exp(int kind, double mu, double v, dou
     *dv = -0.5 * e;
     return -e - mu;
   }
+  if (kind == 6) {      // Gamma, exp link: -shape mu - lgamma(shape) + (shape - 1) log y - y exp(-mu + v / 2)
+    const double e = exp(-mu + 0.5 * v) * y;
+    *dmu = e - p0;
+    *dv = -0.5 * e;
+    *dp0 = -mu - digamma_d(p0) + log(y);
+    return -p0 * mu - lgamma(p0) + (p0 - 1.0) * log(y) - e;
+  }
   constexpr double GX[10] = DSDGP_GH20_X;
   constexpr double GW[10] = DSDGP_GH20_W;
+  if (kind == 7) {      // Beta: quadrature of the log density, its derivatives through alpha = probit(f) scale, beta = scale - alpha
+    const double sd = sqrt(2.0 * v), yc = fmin(fmax(y, 1e-6), 1.0 - 1e-6), ly = log(yc), l1y = log(1.0 - yc);
+    const double lgs = lgamma(p0), dgs = digamma_d(p0);
+    double ve = 0.0, gm = 0.0, gv = 0.0, gp = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 20; ++k) {
+      const double x = (k < 10) ? -GX[9 - k] : GX[k - 10];
+      const double w = (k < 10) ? GW[9 - k] : GW[k - 10];
+      const double f = mu + sd * x;
+      const double mean = bern_probit(f), al = mean * p0, be = p0 - al;
+      ve += w * ((al - 1.0) * ly + (be - 1.0) * l1y + lgs - lgamma(al) - lgamma(be));
+      const double da = digamma_d(al), db = digamma_d(be);
+      const double dl = (1.0 - 2e-3) * 0.39894228040143267794 * exp(-0.5 * f * f) * p0 * (ly - l1y - da + db);      // d log p / d f
+      gm += w * dl;
+      gv += w * dl * x;
+      gp += w * (mean * ly + (1.0 - mean) * l1y + dgs - mean * da - (1.0 - mean) * db);
+    }
+    *dmu = gm;
+    *dv = gv / sd;
+    *dp0 = gp;
+    return ve;
+  }
   const double sd = sqrt(2.0 * v), nu = p1;
   const double c0 = lgamma(0.5 * (nu + 1.0)) - lgamma(0.5 * nu) - 0.5 * (log(nu) + 1.1447298858494001741) - log(p0);
   double ve = 0.0, gm = 0.0, gv = 0.0, gp = 0.0;

@@ -146,7 +146,7 @@ extern "C" int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const
   return DSDGP_OK;
 }
 
-// ---- Poisson / Exponential (exp link) and StudentT through BroadcastingLikelihood: the same two reductions over the samples
+// ---- Poisson / Exponential / Gamma (exp link), StudentT and Beta through BroadcastingLikelihood: the same two reductions over the samples
 __global__ void k_lik_over_samples(int kind, double p0, double p1, const double* __restrict__ mean, const double* __restrict__ var,
                                    const double* __restrict__ Y, int64_t n, int S, int DY, int mode, const double* __restrict__ sw,
                                    double* __restrict__ out) {
@@ -179,6 +179,7 @@ __global__ void k_lik_over_samples(int kind, double p0, double p1, const double*
 static bool lik_quad_kind_ok(int kind, double p0, double p1) {
   if (kind == DSDGP_LIK_POISSON) return p1 > 0.0;
   if (kind == DSDGP_LIK_EXPONENTIAL) return true;
+  if (kind == DSDGP_LIK_GAMMA || kind == DSDGP_LIK_BETA) return p0 > 0.0;
   return kind == DSDGP_LIK_STUDENT_T && p0 > 0.0 && p1 > 0.0;
 }
 extern "C" int dsdgp_lik_var_exp(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var,

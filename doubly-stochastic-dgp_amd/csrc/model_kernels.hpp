@@ -384,8 +384,9 @@ __global__ __launch_bounds__(256) void k_lik_bern(const double* __restrict__ mea
   }
 }
 
-// [UPSTREAM] Poisson / Exponential (exp link) and StudentT variational expectations (common.hpp: lik_var_exp) and their adjoints; same
-// outputs as k_lik_gauss — the second partial is d/d(scale) for StudentT (lik_const[0] = scale), zero for the other two
+// [UPSTREAM] Poisson / Exponential / Gamma (exp link), StudentT and Beta variational expectations (common.hpp: lik_var_exp) and their
+// adjoints; same outputs as k_lik_gauss — the second partial is the derivative w.r.t. the likelihood's positive parameter
+// (lik_const[0]: StudentT.scale, Gamma.shape, Beta.scale), zero for Poisson / Exponential
 __global__ __launch_bounds__(256) void k_lik_gen(int kind, const double* __restrict__ lik_const, double aux,
                                                  const double* __restrict__ mean, const double* __restrict__ var,
                                                  const double* __restrict__ Y, int64_t n, int S, int DY, double w,
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void k_lik_gen(int kind, const double* __restr
                                                  double* __restrict__ dmean, double* __restrict__ dvar,
                                                  double* __restrict__ MBt, double* __restrict__ VBt, int64_t ldt) {
   __shared__ double sh[4];
-  const double p0 = (kind == DSDGP_LIK_STUDENT_T) ? lik_const[0] : 1.0;
+  const double p0 = (kind == DSDGP_LIK_STUDENT_T || kind == DSDGP_LIK_GAMMA || kind == DSDGP_LIK_BETA) ? lik_const[0] : 1.0;
   const int64_t total = (int64_t)S * n * DY;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double ve = 0.0, dl = 0.0;

@@ -243,9 +243,11 @@ static int chain_d_split(int64_t nblk, int D_out) {
 // one-workgroup kernel: 192 (Mp a multiple of 64).  Measured, factor + inverse of one matrix: Mp = 192 180 -> 77 us, 256 371 -> 101,
 // 448 1990 -> 181.  Layers that share M are factorised as ONE batch.
 // the likelihood owns one positive parameter in theta (Gaussian.variance / StudentT.scale: desc.off_lik_var, lik_const[0])
-static inline bool lik_has_param(int kind) { return kind == DSDGP_LIK_GAUSSIAN || kind == DSDGP_LIK_STUDENT_T; }
-// Poisson / Exponential / StudentT: elementwise, evaluated by lik_var_exp (common.hpp)
-static inline bool lik_is_generic(int kind) { return kind == DSDGP_LIK_POISSON || kind == DSDGP_LIK_EXPONENTIAL || kind == DSDGP_LIK_STUDENT_T; }
+static inline bool lik_has_param(int kind) {
+  return kind == DSDGP_LIK_GAUSSIAN || kind == DSDGP_LIK_STUDENT_T || kind == DSDGP_LIK_GAMMA || kind == DSDGP_LIK_BETA;
+}
+// Poisson / Exponential / StudentT / Gamma / Beta: elementwise, evaluated by lik_var_exp (common.hpp)
+static inline bool lik_is_generic(int kind) { return kind >= DSDGP_LIK_POISSON && kind <= DSDGP_LIK_BETA; }
 static int big_mp(bool uniform) {
   static const int nonuniform = getenv("DSDGP_BIG_MP") ? atoi(getenv("DSDGP_BIG_MP")) : 192;      // (A/B aid)
   return uniform ? 192 : nonuniform;

@@ -10,7 +10,7 @@ _LIB_PATH = os.environ.get("DSDGP_LIB_PATH") or os.path.join(os.path.dirname(_HE
 DSDGP_MAX_LAYERS = 16
 KERN_RBF, KERN_MATERN52 = 0, 1
 MEAN_ZERO, MEAN_IDENTITY, MEAN_LINEAR = 0, 1, 2
-LIK_GAUSSIAN, LIK_MULTICLASS, LIK_BERNOULLI, LIK_POISSON, LIK_EXPONENTIAL, LIK_STUDENT_T = 0, 1, 2, 3, 4, 5
+LIK_GAUSSIAN, LIK_MULTICLASS, LIK_BERNOULLI, LIK_POISSON, LIK_EXPONENTIAL, LIK_STUDENT_T, LIK_GAMMA, LIK_BETA = 0, 1, 2, 3, 4, 5, 6, 7
 ERR_NOT_SPD = -2
 ERR_RCCL = -6
 

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, settings
-from .gpflow_compat import (Bernoulli, Exponential, Gaussian, MultiClass, Parameter, Poisson, StudentT, positive_backward, positive_forward, split_kernel)
+from .gpflow_compat import (Bernoulli, Beta, Exponential, Gamma, Gaussian, MultiClass, Parameter, Poisson, StudentT, positive_backward, positive_forward, split_kernel)
 
 _KIND = {"rbf": _lib.KERN_RBF, "matern52": _lib.KERN_MATERN52}
 _MEAN = {"zero": _lib.MEAN_ZERO, "identity": _lib.MEAN_IDENTITY, "linear": _lib.MEAN_LINEAR}
@@ -180,10 +180,14 @@ class Engine:
         elif isinstance(self.likelihood, Exponential):
             d.lik_kind = _lib.LIK_EXPONENTIAL
             d.off_lik_var = -1
-        elif isinstance(self.likelihood, StudentT):
-            d.lik_kind = _lib.LIK_STUDENT_T
-            d.lik_aux = self.likelihood.deg_free
-            p = self.likelihood.scale           # the likelihood's one positive parameter: the slot Gaussian.variance takes
+        elif isinstance(self.likelihood, (StudentT, Gamma, Beta)):
+            if isinstance(self.likelihood, StudentT):
+                d.lik_kind = _lib.LIK_STUDENT_T
+                d.lik_aux = self.likelihood.deg_free
+            else:
+                d.lik_kind = _lib.LIK_GAMMA if isinstance(self.likelihood, Gamma) else _lib.LIK_BETA
+            # the likelihood's one positive parameter (StudentT.scale, Gamma.shape, Beta.scale): the slot Gaussian.variance takes
+            p = self.likelihood.shape if isinstance(self.likelihood, Gamma) else self.likelihood.scale
             self.entries.append((p, off, 1, "pos"))
             if self not in p._owners:
                 p._owners.append(self)
@@ -535,8 +539,10 @@ class Engine:
                 names[id(layer.mean_function.b)] = f"l{l}.mean_b"
         if isinstance(self.likelihood, Gaussian):
             names[id(self.likelihood.variance)] = "lik_variance_raw"
-        if isinstance(self.likelihood, StudentT):
+        if isinstance(self.likelihood, (StudentT, Beta)):
             names[id(self.likelihood.scale)] = "lik_variance_raw"
+        if isinstance(self.likelihood, Gamma):
+            names[id(self.likelihood.shape)] = "lik_variance_raw"
         for p, off, cnt, kind in self.entries:
             out[names[id(p)]] = g[off:off + cnt].reshape(p.shape).copy()
         return out

@@ -278,6 +278,27 @@ class StudentT(Likelihood):
         self.scale = Parameter(scale, transform="positive")
 
 
+class Gamma(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.Gamma(invlink=tf.exp): positive targets, scale exp(f); `shape` is a positive (trainable)
+    Parameter, 1.0 upstream (settable here for convenience)."""
+    kind = "gamma"
+
+    def __init__(self, invlink=None, shape=1.0):
+        _exp_link_only(invlink)
+        self.shape = Parameter(shape, transform="positive")
+
+
+class Beta(Likelihood):
+    """[UPSTREAM] gpflow.likelihoods.Beta(invlink=probit, scale=1.0): targets in (0, 1) (clipped to [1e-6, 1 - 1e-6]), mean probit(f);
+    `scale` is a positive (trainable) Parameter."""
+    kind = "beta"
+
+    def __init__(self, invlink=None, scale=1.0):
+        if invlink is not None:
+            raise NotImplementedError("only the default probit link is on the built path")
+        self.scale = Parameter(scale, transform="positive")
+
+
 class InducingPoints(Parameterized):
     """[UPSTREAM] gpflow.features.InducingPoints — holder of Z (layers.py:153)."""
 

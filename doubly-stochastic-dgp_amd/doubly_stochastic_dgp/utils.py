@@ -49,24 +49,29 @@ class BroadcastingLikelihood:
 
     def __init__(self, likelihood):
         self.likelihood = likelihood
-        from .gpflow_compat import Bernoulli, Exponential, Gaussian, MultiClass, Poisson, StudentT
+        from .gpflow_compat import Bernoulli, Beta, Exponential, Gamma, Gaussian, MultiClass, Poisson, StudentT
         self.needs_broadcasting = not isinstance(likelihood, Gaussian)
         self.bernoulli = isinstance(likelihood, Bernoulli)
-        # Poisson / Exponential (exp link) / StudentT: elementwise like Bernoulli, evaluated by dsdgp_lik_var_exp / dsdgp_lik_predict
-        self.generic = isinstance(likelihood, (Poisson, Exponential, StudentT))
-        if not isinstance(likelihood, (Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT)):
+        # Poisson / Exponential / Gamma (exp link), StudentT, Beta: elementwise like Bernoulli, evaluated by dsdgp_lik_var_exp / dsdgp_lik_predict
+        self.generic = isinstance(likelihood, (Poisson, Exponential, StudentT, Gamma, Beta))
+        if not isinstance(likelihood, (Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT, Gamma, Beta)):
             raise NotImplementedError(f"likelihood {type(likelihood).__name__} is not on the built path "
-                                      "(Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT are)")
+                                      "(Gaussian, MultiClass, Bernoulli, Poisson, Exponential, StudentT, Gamma, Beta are)")
 
     def generic_args(self):
-        """(kind, p0, p1) of dsdgp_lik_var_exp / dsdgp_lik_predict: p0 = StudentT.scale, p1 = Poisson.binsize / StudentT.deg_free."""
+        """(kind, p0, p1) of dsdgp_lik_var_exp / dsdgp_lik_predict: p0 = StudentT.scale / Gamma.shape / Beta.scale, p1 = Poisson.binsize /
+        StudentT.deg_free."""
         from . import _lib
-        from .gpflow_compat import Exponential, Poisson
+        from .gpflow_compat import Beta, Exponential, Gamma, Poisson
         lik = self.likelihood
         if isinstance(lik, Poisson):
             return _lib.LIK_POISSON, 1.0, lik.binsize
         if isinstance(lik, Exponential):
             return _lib.LIK_EXPONENTIAL, 1.0, 1.0
+        if isinstance(lik, Gamma):
+            return _lib.LIK_GAMMA, float(lik.shape.value), 1.0
+        if isinstance(lik, Beta):
+            return _lib.LIK_BETA, float(lik.scale.value), 1.0
         return _lib.LIK_STUDENT_T, float(lik.scale.value), lik.deg_free
 
     def check_targets(self, Y):

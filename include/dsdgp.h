@@ -44,7 +44,7 @@ enum { DSDGP_MEAN_ZERO = 0, DSDGP_MEAN_IDENTITY = 1, DSDGP_MEAN_LINEAR = 2 }; /*
 enum { DSDGP_LIK_GAUSSIAN = 0, DSDGP_LIK_MULTICLASS = 1, DSDGP_LIK_BERNOULLI = 2,     /* dgp.py:57, utils.py:54-93,
                                                                                        * tests/test_dgp.py:48-54 */
        /* further likelihoods utils.py:54-121 can wrap ([UPSTREAM] gpflow 1.1.1 likelihoods.py), exp links / StudentT: */
-       DSDGP_LIK_POISSON = 3, DSDGP_LIK_EXPONENTIAL = 4, DSDGP_LIK_STUDENT_T = 5 };
+       DSDGP_LIK_POISSON = 3, DSDGP_LIK_EXPONENTIAL = 4, DSDGP_LIK_STUDENT_T = 5, DSDGP_LIK_GAMMA = 6, DSDGP_LIK_BETA = 7 };
 
 #define DSDGP_MAX_LAYERS 16
 
@@ -139,7 +139,8 @@ typedef struct {
   int32_t reserved;
   double jitter;                   /* settings.jitter, layers.py:171, utils.py:41 */
   double lik_aux;                  /* the likelihood's constant: Poisson.binsize, StudentT.deg_free (else ignored) */
-  int64_t off_lik_var;             /* scalar, softplus^-1 of the likelihood's positive parameter: Gaussian.variance, StudentT.scale */
+  int64_t off_lik_var;             /* scalar, softplus^-1 of the likelihood's positive parameter: Gaussian.variance, StudentT.scale,
+                                      Gamma.shape, Beta.scale */
   int64_t n_theta;
   dsdgp_layer_desc layers[DSDGP_MAX_LAYERS];
 } dsdgp_model_desc;
@@ -317,10 +318,11 @@ int dsdgp_bernoulli_var_exp(dsdgp_ctx* ctx, const double* mean, const double* va
 int dsdgp_bernoulli_predict(dsdgp_ctx* ctx, const double* mean, const double* var, int64_t count, double* out_mean,
                             double* out_var);
 
-/* BroadcastingLikelihood over Poisson(invlink=exp, binsize) / Exponential(invlink=exp) / StudentT(scale, deg_free)
+/* BroadcastingLikelihood over Poisson(invlink=exp, binsize) / Exponential(invlink=exp) / Gamma(invlink=exp; shape) /
+ * StudentT(scale, deg_free) / Beta(invlink=probit, scale)
  * (utils.py:76-93,95-121; [UPSTREAM] gpflow 1.1.1 likelihoods: closed-form variational expectations with the exp link, the base
- * class's 20-point Gauss-Hermite rule otherwise).  kind = DSDGP_LIK_POISSON / _EXPONENTIAL / _STUDENT_T; p0 = StudentT.scale,
- * p1 = Poisson.binsize / StudentT.deg_free (ignored where the likelihood has no such parameter).  Modes, shapes: as above. */
+ * class's 20-point Gauss-Hermite rule otherwise).  kind = DSDGP_LIK_POISSON .. DSDGP_LIK_BETA; p0 = StudentT.scale / Gamma.shape /
+ * Beta.scale, p1 = Poisson.binsize / StudentT.deg_free (ignored where the likelihood has no such parameter).  Modes, shapes: as above. */
 int dsdgp_lik_var_exp(dsdgp_ctx* ctx, int32_t kind, double p0, double p1, const double* mean, const double* var, const double* Y,
                       int64_t n, int32_t S, int32_t DY, int mode, const double* sample_w, double* out);
 /* Likelihood.predict_mean_and_var by the same rule: E_y = sum w cm(f_k), V_y = sum w (cv(f_k) + cm(f_k)^2) - E_y^2. */

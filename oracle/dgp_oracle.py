@@ -519,6 +519,59 @@ class StudentT(_QuadratureLikelihood):
         return (self.scale * xp.ones(1)) ** 2 * (self.deg_free / (self.deg_free - 2.0)) + 0.0 * F
 
 
+class Gamma(_QuadratureLikelihood):
+    """[UPSTREAM] gpflow 1.1.1 Gamma(invlink=tf.exp): `shape` a positive Parameter (1.0, trainable);
+    logp = -shape log(scale) - lgamma(shape) + (shape - 1) log Y - Y / scale with scale = exp(F); conditional mean shape scale,
+    variance shape scale^2; closed-form variational expectations with the exp link:
+    -shape Fmu - lgamma(shape) + (shape - 1) log Y - Y exp(-Fmu + Fvar / 2)."""
+    kind = "gamma"
+
+    def __init__(self, shape=1.0):
+        self.shape = shape
+
+    def logp(self, xp, F, Y):
+        sh, Y = self.shape * xp.ones(1), xp.asarray(Y)
+        return -sh * F - _lgamma(xp, sh) + (sh - 1.0) * xp.log(Y) - Y * xp.exp(-F)
+
+    def conditional_mean(self, xp, F):
+        return (self.shape * xp.ones(1)) * xp.exp(F)
+
+    def conditional_variance(self, xp, F):
+        return (self.shape * xp.ones(1)) * xp.exp(F) ** 2
+
+    def variational_expectations(self, xp, Fmu, Fvar, Y):
+        sh, Y = self.shape * xp.ones(1), xp.asarray(Y)
+        return -sh * Fmu - _lgamma(xp, sh) + (sh - 1.0) * xp.log(Y) - Y * xp.exp(-Fmu + Fvar / 2.0)
+
+
+class Beta(_QuadratureLikelihood):
+    """[UPSTREAM] gpflow 1.1.1 Beta(invlink=probit, scale=1.0): `scale` a positive Parameter (trainable); mean = probit(F) (the
+    Bernoulli's probit with its 1e-3 floor), alpha = mean scale, beta = scale - alpha,
+    logp = (alpha - 1) log y + (beta - 1) log(1 - y) + lgamma(alpha + beta) - lgamma(alpha) - lgamma(beta) with y clipped to
+    [1e-6, 1 - 1e-6]; conditional mean = mean, variance (mean - mean^2) / (scale + 1); everything by the base class's quadrature."""
+    kind = "beta"
+
+    def __init__(self, scale=1.0):
+        self.scale = scale
+
+    def logp(self, xp, F, Y):
+        sc = self.scale * xp.ones(1)
+        mean = Bernoulli._probit(xp, F)
+        alpha = mean * sc
+        beta = sc - alpha
+        y = np.clip(np.asarray(Y.detach().numpy() if hasattr(Y, "detach") else Y, dtype=np.float64), 1e-6, 1 - 1e-6)
+        y = xp.asarray(y)
+        return ((alpha - 1.0) * xp.log(y) + (beta - 1.0) * xp.log(1.0 - y) + _lgamma(xp, alpha + beta) - _lgamma(xp, alpha)
+                - _lgamma(xp, beta))
+
+    def conditional_mean(self, xp, F):
+        return Bernoulli._probit(xp, F)
+
+    def conditional_variance(self, xp, F):
+        mean = Bernoulli._probit(xp, F)
+        return (mean - mean ** 2) / (self.scale * xp.ones(1) + 1.0)
+
+
 # --------------------------------------------------------------------------------------------------
 # dgp.py:42-126  DGP_Base
 # --------------------------------------------------------------------------------------------------

@@ -3,13 +3,13 @@
 A model is described by a plain ``spec`` dict and a ``state`` dict of *unconstrained* numpy arrays (the
 free variables GPflow would optimise):
 
-spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass"|"bernoulli"|"poisson"|"exponential"|"student_t",
+spec  = {"jitter": 1e-6, "white": False, "likelihood": "gaussian"|"multiclass"|"bernoulli"|"poisson"|"exponential"|"student_t"|"gamma"|"beta",
          "num_classes": K, "lik_aux": Poisson binsize / StudentT deg_free (optional),
          "layers": [{"kind": "rbf"|"matern52", "input_dim": D_in, "ARD": bool, "has_white": bool,
                      "mean": "zero"|"identity"|"linear", "mean_A": ndarray|None, "kvar_identity": bool (optional)}, ...]}
 state = {"l{i}.Z": (M,D_in), "l{i}.q_mu": (M,D_out), "l{i}.q_sqrt": (D_out,M,M)  [tril part is the free var],
          "l{i}.kern_variance_raw": (), "l{i}.kern_lengthscales_raw": () or (D_in,),
-         "l{i}.white_variance_raw": () [if has_white], "lik_variance_raw": () [gaussian: variance; student_t: scale]}
+         "l{i}.white_variance_raw": () [if has_white], "lik_variance_raw": () [gaussian: variance; student_t / beta: scale; gamma: shape]}
 """
 import math
 import numpy as np
@@ -48,7 +48,7 @@ def state_from_layers(layer_dicts, lik_variance=1.0, likelihood="gaussian"):
         state[f"l{i}.kern_lengthscales_raw"] = np.array(constrained_to_raw(ls))
         if k.white_variance is not None:
             state[f"l{i}.white_variance_raw"] = np.array(constrained_to_raw(k.white_variance))
-    if likelihood in ("gaussian", "student_t"):      # the likelihood's one positive parameter: Gaussian.variance / StudentT.scale
+    if likelihood in ("gaussian", "student_t", "gamma", "beta"):      # the likelihood's one positive parameter (variance / scale / shape)
         state["lik_variance_raw"] = np.array(constrained_to_raw(lik_variance))
     return spec_layers, state
 
@@ -84,6 +84,10 @@ def build(xp, spec, state, num_samples=1, num_data=None, sample_weights=None):
         lik = O.Exponential()
     elif spec["likelihood"] == "student_t":
         lik = O.StudentT(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])), deg_free=spec.get("lik_aux") or 3.0)
+    elif spec["likelihood"] == "gamma":
+        lik = O.Gamma(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
+    elif spec["likelihood"] == "beta":
+        lik = O.Beta(O.positive_forward(xp, xp.asarray(state["lik_variance_raw"])))
     else:
         lik = O.MultiClass(spec["num_classes"])
     return O.DGPOracle(layers, lik, num_samples=num_samples, num_data=num_data, sample_weights=sample_weights)

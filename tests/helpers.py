@@ -25,7 +25,7 @@ def make_case(X, Y, Z, kern_specs, white=False, jitter=1e-6, lik_var=0.1, S=2, n
     """Returns (spec, state, model): oracle description and the product DGP with identical parameters."""
     from doubly_stochastic_dgp import settings
     from doubly_stochastic_dgp.dgp import DGP
-    from doubly_stochastic_dgp.gpflow_compat import Bernoulli, Exponential, Gaussian, MultiClass, Poisson, StudentT
+    from doubly_stochastic_dgp.gpflow_compat import Bernoulli, Beta, Exponential, Gamma, Gaussian, MultiClass, Poisson, StudentT
     rng = np.random.RandomState(seed)
     lds = O.init_layers_linear(X, Y, Z, kern_specs, white=white, jitter=jitter, num_outputs=num_classes)
     for i, l in enumerate(lds):
@@ -35,7 +35,8 @@ def make_case(X, Y, Z, kern_specs, white=False, jitter=1e-6, lik_var=0.1, S=2, n
             l["q_sqrt"] = l["q_sqrt"] * 0.7 + 0.05 * np.tril(rng.randn(D, M, M))
         if q_sqrt_scale is not None and i < len(lds) - 1:
             l["q_sqrt"] = l["q_sqrt"] * q_sqrt_scale
-    # likelihood: "poisson" (lik_aux = binsize) / "exponential" / "student_t" (lik_var = scale, lik_aux = deg_free)
+    # likelihood: "poisson" (lik_aux = binsize) / "exponential" / "student_t" (lik_var = scale, lik_aux = deg_free) / "gamma" (lik_var =
+    # shape) / "beta" (lik_var = scale)
     likname = likelihood or ("multiclass" if num_classes else ("bernoulli" if bernoulli else "gaussian"))
     sl, state = OM.state_from_layers(lds, lik_variance=lik_var, likelihood=likname)
     spec = dict(jitter=jitter, white=white, likelihood=likname, layers=sl, num_classes=num_classes, lik_aux=lik_aux)
@@ -46,6 +47,10 @@ def make_case(X, Y, Z, kern_specs, white=False, jitter=1e-6, lik_var=0.1, S=2, n
             lik = Exponential()
         elif likname == "student_t":
             lik = StudentT(scale=lik_var, deg_free=lik_aux or 3.0)
+        elif likname == "gamma":
+            lik = Gamma(shape=lik_var)
+        elif likname == "beta":
+            lik = Beta(scale=lik_var)
         else:
             lik = MultiClass(num_classes) if num_classes else (Bernoulli() if bernoulli else Gaussian(variance=lik_var))
         model = DGP(X, Y, Z, [product_kernel(k) for k in kern_specs], lik, white=white, num_outputs=num_classes,

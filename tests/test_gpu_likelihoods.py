@@ -1,6 +1,6 @@
-"""Poisson / Exponential (exp link) and StudentT behind BroadcastingLikelihood on the HIP path (/root/reference/doubly_stochastic_dgp/
+"""Poisson / Exponential / Gamma (exp link), StudentT and Beta behind BroadcastingLikelihood on the HIP path (/root/reference/doubly_stochastic_dgp/
 utils.py:54-121 wraps any GPflow likelihood; [UPSTREAM] gpflow 1.1.1 likelihoods.py for the formulas): ELBO, every gradient block
-(incl. StudentT's scale), E_log_p_Y, predict_density, predict_y and the two C-ABI primitives against the oracle; an end-to-end
+(incl. StudentT's scale, Gamma's shape, Beta's scale), E_log_p_Y, predict_density, predict_y and the two C-ABI primitives against the oracle; an end-to-end
 training run per likelihood."""
 import numpy as np
 import pytest
@@ -12,14 +12,18 @@ from tests.helpers import kern_spec, make_case
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["poisson", "exponential", "student_t"]
+KINDS = ["poisson", "exponential", "student_t", "gamma", "beta"]
 
 
 def _targets(name, rng, N, DY):
     if name == "poisson":
         return rng.poisson(2.0, size=(N, DY)).astype(np.float64)
-    if name == "exponential":
+    if name in ("exponential", "gamma"):
         return rng.exponential(1.3, size=(N, DY)) + 1e-3
+    if name == "beta":
+        y = rng.uniform(0.02, 0.98, size=(N, DY))
+        y.ravel()[:2] = [0.0, 1.0]            # clipped to [1e-6, 1 - 1e-6] as upstream's density does
+        return y
     return rng.standard_t(4.0, size=(N, DY))
 
 
@@ -35,11 +39,12 @@ def test_elbo_gradients_and_predictions(name, L, white):
     Z = X[:M].copy()
     specs = [kern_spec("matern52", D, 1.0, 0.5, white_variance=0.01) for _ in range(L)]
     aux = {"poisson": 1.6, "student_t": 4.5}.get(name)
-    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=200, likelihood=name, lik_aux=aux, lik_var=0.7)
+    spec, state, model = make_case(X, Y, Z, specs, white=white, S=S, num_data=200, likelihood=name, lik_aux=aux,
+                                   lik_var={"gamma": 1.8, "beta": 2.5}.get(name, 0.7))
     widths = [D] * (L - 1) + [DY]
     zs = [rng.randn(S, N, w) for w in widths]
     _grad_check(X, Y, spec, state, model, zs, S, num_data=200)
-    assert ("lik_variance_raw" in model.engine().gradient_dict()) == (name == "student_t")
+    assert ("lik_variance_raw" in model.engine().gradient_dict()) == (name in ("student_t", "gamma", "beta"))
     om = OM.build(O.NP, spec, state, S, 200)
     assert_allclose(model.E_log_p_Y(X, Y, zs=zs), om.E_log_p_Y(O.NP, X, Y, zs), rtol=1e-10, atol=1e-12)
     _, Fm, Fv = om.propagate(O.NP, X, zs, S=S)
@@ -55,15 +60,17 @@ def test_elbo_gradients_and_predictions(name, L, white):
 def test_var_exp_and_predict_primitives(name):
     """dsdgp_lik_var_exp (both reductions over the samples, quadrature weights) and dsdgp_lik_predict against the oracle on wide
     ranges of mean / variance; a negative variance gives NaN in the quadrature likelihood as upstream's sqrt does."""
-    from doubly_stochastic_dgp.gpflow_compat import Exponential, Poisson, StudentT
+    from doubly_stochastic_dgp.gpflow_compat import Beta, Exponential, Gamma, Poisson, StudentT
     from doubly_stochastic_dgp.utils import BroadcastingLikelihood
     from scipy.special import logsumexp
     rng = np.random.RandomState(5)
     S, N, D = 4, 37, 3
     mu, var = 1.2 * rng.randn(S, N, D), rng.uniform(1e-6, 2.0, size=(S, N, D))
     Y = _targets(name, rng, N, D)
-    lik = BroadcastingLikelihood({"poisson": Poisson(binsize=0.8), "exponential": Exponential(), "student_t": StudentT(1.3, 3.0)}[name])
-    ol = {"poisson": O.Poisson(0.8), "exponential": O.Exponential(), "student_t": O.StudentT(1.3, 3.0)}[name]
+    lik = BroadcastingLikelihood({"poisson": Poisson(binsize=0.8), "exponential": Exponential(), "student_t": StudentT(1.3, 3.0),
+                                  "gamma": Gamma(shape=2.2), "beta": Beta(scale=3.5)}[name])
+    ol = {"poisson": O.Poisson(0.8), "exponential": O.Exponential(), "student_t": O.StudentT(1.3, 3.0), "gamma": O.Gamma(2.2),
+          "beta": O.Beta(3.5)}[name]
     ve = ol.variational_expectations(O.NP, mu, var, Y)
     assert_allclose(lik.variational_expectations_mean(mu, var, Y), ve.mean(0), rtol=1e-12, atol=1e-13)
     w = rng.uniform(size=S)
@@ -74,7 +81,7 @@ def test_var_exp_and_predict_primitives(name):
     rm, rv = ol.predict_mean_and_var(O.NP, mu, var)
     assert_allclose(pm, rm, rtol=1e-12, atol=1e-13)
     assert_allclose(pv, rv, rtol=1e-9, atol=1e-11)
-    if name == "student_t":
+    if name in ("student_t", "beta"):
         bad = var.copy()
         bad[1, 5, 2] = -0.1
         out = lik.variational_expectations_mean(mu, bad, Y)
@@ -88,8 +95,8 @@ def test_c_abi_rejects_bad_kinds_and_parameters():
     ctx = Context.get()
     a = ctx.to_device(np.ones((1, 4, 1)))
     y, out = ctx.to_device(np.ones((4, 1))), ctx.empty(4, 1)
-    for kind, p0, p1 in ((_lib.LIK_GAUSSIAN, 1.0, 1.0), (7, 1.0, 1.0), (_lib.LIK_STUDENT_T, -1.0, 3.0), (_lib.LIK_STUDENT_T, 1.0, 0.0),
-                         (_lib.LIK_POISSON, 1.0, 0.0)):
+    for kind, p0, p1 in ((_lib.LIK_GAUSSIAN, 1.0, 1.0), (9, 1.0, 1.0), (_lib.LIK_STUDENT_T, -1.0, 3.0), (_lib.LIK_STUDENT_T, 1.0, 0.0),
+                         (_lib.LIK_POISSON, 1.0, 0.0), (_lib.LIK_GAMMA, 0.0, 1.0), (_lib.LIK_BETA, -2.0, 1.0), (8, 1.0, 1.0)):
         assert ctx.lib.dsdgp_lik_var_exp(ctx.handle, kind, p0, p1, ptr(a), ptr(a), ptr(y), 4, 1, 1, 0, None, ptr(out)) != 0
         assert ctx.lib.dsdgp_lik_predict(ctx.handle, kind, p0, p1, ptr(a), ptr(a), 4, ptr(out), ptr(out)) != 0
 
@@ -122,22 +129,25 @@ def test_adam_steps_follow_the_oracle(name):
             st[k] = st[k] - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m1 / (np.sqrt(m2) + eps)
     assert_allclose(model.layers[-1].q_mu.value, st["l1.q_mu"], rtol=1e-6, atol=1e-9)
     assert_allclose(model.layers[0].feature.Z.value, st["l0.Z"], rtol=1e-6, atol=1e-9)
-    if name == "student_t":
-        assert_allclose(float(model.likelihood.likelihood.scale.value), float(O.positive_forward(O.NP, st["lik_variance_raw"])), rtol=1e-7)
-        assert abs(float(model.likelihood.likelihood.scale.value) - 0.9) > 1e-4
+    if name in ("student_t", "gamma", "beta"):
+        par = model.likelihood.likelihood.shape if name == "gamma" else model.likelihood.likelihood.scale
+        assert_allclose(float(par.value), float(O.positive_forward(O.NP, st["lik_variance_raw"])), rtol=1e-7)
+        assert abs(float(par.value) - 0.9) > 1e-4
 
 
 @pytest.mark.parametrize("name", KINDS)
 def test_training_raises_the_elbo(name):
     from doubly_stochastic_dgp.dgp import DGP
-    from doubly_stochastic_dgp.gpflow_compat import RBF, Exponential, Poisson, StudentT
+    from doubly_stochastic_dgp.gpflow_compat import RBF, Beta, Exponential, Gamma, Poisson, StudentT
     rng = np.random.RandomState(1)
     N = 150
     X = rng.uniform(-2, 2, size=(N, 1))
     f = np.sin(2.0 * X)
     Y = {"poisson": rng.poisson(np.exp(f + 0.5)).astype(np.float64), "exponential": rng.exponential(np.exp(f)),
-         "student_t": f + 0.1 * rng.standard_t(3.0, size=(N, 1))}[name]
-    lik = {"poisson": Poisson(), "exponential": Exponential(), "student_t": StudentT(scale=1.0, deg_free=3.0)}[name]
+         "student_t": f + 0.1 * rng.standard_t(3.0, size=(N, 1)), "gamma": rng.gamma(3.0, np.exp(f)),
+         "beta": np.clip(rng.beta(8.0 * (0.5 + 0.3 * f), 8.0 * (0.5 - 0.3 * f)), 1e-3, 1 - 1e-3)}[name]
+    lik = {"poisson": Poisson(), "exponential": Exponential(), "student_t": StudentT(scale=1.0, deg_free=3.0), "gamma": Gamma(),
+           "beta": Beta()}[name]
     # white=True: with the exp links the objective holds exp(mean + var / 2), and in the non-white parameterisation var contains
     # |q_sqrt^T Ku^-1 k|^2, which explodes as soon as the inner layer moves the inputs off the (ill-conditioned, 1-D) inducing set —
     # Adam on the ORACLE's gradients diverges from this start just the same (checked: -489 -> -2e12 in 16 steps)
@@ -151,3 +161,7 @@ def test_training_raises_the_elbo(name):
     assert np.all(np.isfinite(m)) and np.all(v > 0)
     if name == "student_t":
         assert float(lik.scale.value) < 0.9            # the scale moves towards the 0.1-scale noise of the data
+    if name == "gamma":
+        assert float(lik.shape.value) > 1.2            # ... the shape towards the data's 3
+    if name == "beta":
+        assert float(lik.scale.value) > 1.5            # ... the concentration towards the data's 8

@@ -186,14 +186,15 @@ def test_bernoulli_is_a_built_likelihood():
         Bernoulli(invlink="logit")
 
 
-def test_poisson_exponential_student_t_are_built_likelihoods():
+def test_poisson_exponential_student_t_gamma_beta_are_built_likelihoods():
     """The further GPflow 1.1.1 likelihoods BroadcastingLikelihood (utils.py:54-121) can wrap here: accepted with their upstream
     constructor signatures; other links and other likelihood classes still fail loudly."""
     from doubly_stochastic_dgp import _lib
-    from doubly_stochastic_dgp.gpflow_compat import Exponential, Likelihood, Poisson, StudentT
+    from doubly_stochastic_dgp.gpflow_compat import Beta, Exponential, Gamma, Likelihood, Poisson, StudentT
     from doubly_stochastic_dgp.utils import BroadcastingLikelihood
     for lik, want in ((Poisson(binsize=2.0), (_lib.LIK_POISSON, 1.0, 2.0)), (Exponential(), (_lib.LIK_EXPONENTIAL, 1.0, 1.0)),
-                      (StudentT(scale=0.7, deg_free=4.0), (_lib.LIK_STUDENT_T, 0.7, 4.0))):
+                      (StudentT(scale=0.7, deg_free=4.0), (_lib.LIK_STUDENT_T, 0.7, 4.0)), (Gamma(shape=1.5), (_lib.LIK_GAMMA, 1.5, 1.0)),
+                      (Beta(scale=2.5), (_lib.LIK_BETA, 2.5, 1.0))):
         b = BroadcastingLikelihood(lik)
         assert b.needs_broadcasting and b.generic and not b.bernoulli
         k, p0, p1 = b.generic_args()
@@ -208,7 +209,11 @@ def test_poisson_exponential_student_t_are_built_likelihoods():
         Exponential(invlink=np.square)
     Poisson(invlink=np.exp)
 
-    class Gamma(Likelihood):
+    assert abs(float(Gamma().shape.value) - 1.0) < 1e-12 and Gamma().shape.trainable and Beta().scale.trainable
+    with pytest.raises(NotImplementedError):
+        Beta(invlink="logit")
+
+    class Ordinal(Likelihood):
         pass
     with pytest.raises(NotImplementedError):
-        BroadcastingLikelihood(Gamma())
+        BroadcastingLikelihood(Ordinal())

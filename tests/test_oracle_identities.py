@@ -525,7 +525,7 @@ def test_T13_reference_held_gpr_objective():
 
 
 # ---------------------------------------------------------------- Poisson / Exponential / StudentT ([UPSTREAM] gpflow 1.1.1 likelihoods.py)
-@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t"])
+@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t", "gamma", "beta"])
 def test_T14_further_likelihood_restatements(name):
     """(a) log densities against scipy.stats; (b) the exp-link closed forms of the variational expectations against the base class's
     20-point Gauss-Hermite rule on the same log density and against adaptive quadrature; (c) predict_density / predict_mean_and_var
@@ -533,16 +533,20 @@ def test_T14_further_likelihood_restatements(name):
     import math
     import torch
     from scipy import integrate, stats
-    lik = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(0.6, 4.0)}[name]
+    lik = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(0.6, 4.0), "gamma": O.Gamma(2.3),
+           "beta": O.Beta(3.1)}[name]
     rng = np.random.RandomState(7)
     for _ in range(4):
         mu, v = float(rng.randn() * 0.7), float(0.05 + rng.rand() * 0.6)
-        y = {"poisson": float(rng.randint(0, 6)), "exponential": float(rng.rand() * 3 + 0.1), "student_t": float(rng.randn())}[name]
+        y = {"poisson": float(rng.randint(0, 6)), "exponential": float(rng.rand() * 3 + 0.1), "student_t": float(rng.randn()),
+             "gamma": float(rng.rand() * 3 + 0.1), "beta": float(rng.uniform(0.05, 0.95))}[name]
         Fmu, Fvar, Y = np.array([[[mu]]]), np.array([[[v]]]), np.array([[y]])
         f0 = float(rng.randn())
         lp = float(np.ravel(lik.logp(O.NP, np.array(f0), np.array(y)))[0])
         ref = {"poisson": lambda: stats.poisson.logpmf(y, 1.7 * math.exp(f0)), "exponential": lambda: stats.expon.logpdf(y, scale=math.exp(f0)),
-               "student_t": lambda: stats.t.logpdf(y, 4.0, loc=f0, scale=0.6)}[name]()
+               "student_t": lambda: stats.t.logpdf(y, 4.0, loc=f0, scale=0.6), "gamma": lambda: stats.gamma.logpdf(y, 2.3, scale=math.exp(f0)),
+               "beta": lambda: stats.beta.logpdf(y, 3.1 * float(O.Bernoulli._probit(O.NP, np.array(f0))),
+                                                 3.1 * (1.0 - float(O.Bernoulli._probit(O.NP, np.array(f0)))))}[name]()
         assert abs(lp - ref) < 1e-12 * max(1.0, abs(ref))
         dens = lambda x: stats.norm.pdf(x, mu, math.sqrt(v))
         lpf = lambda x: float(np.ravel(lik.logp(O.NP, np.array(x), np.array(y)))[0])
@@ -560,20 +564,22 @@ def test_T14_further_likelihood_restatements(name):
         em = integrate.quad(lambda x: cm(x) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-13, epsrel=1e-13)[0]
         eq = integrate.quad(lambda x: (cv(x) + cm(x) ** 2) * dens(x), mu - 12 * math.sqrt(v), mu + 12 * math.sqrt(v), epsabs=1e-13, epsrel=1e-13)[0]
         assert abs(float(m.ravel()[0]) - em) < 1e-6 * max(1.0, abs(em)) and abs(float(s2.ravel()[0]) - (eq - em ** 2)) < 1e-5 * max(1.0, eq)
-        lt = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(torch.tensor(0.6, dtype=torch.float64), 4.0)}[name]
+        lt = {"poisson": O.Poisson(binsize=1.7), "exponential": O.Exponential(), "student_t": O.StudentT(torch.tensor(0.6, dtype=torch.float64), 4.0),
+              "gamma": O.Gamma(torch.tensor(2.3, dtype=torch.float64)), "beta": O.Beta(torch.tensor(3.1, dtype=torch.float64))}[name]
         a = (torch.tensor(Fmu), torch.tensor(Fvar), torch.tensor(Y))
         assert abs(float(lt.variational_expectations(O.TH, *a)) - ve) < 1e-13 * max(1.0, abs(ve))
         assert abs(float(lt.predict_density(O.TH, *a)) - pd) < 1e-13 * max(1.0, abs(pd))
 
 
-@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t"])
+@pytest.mark.parametrize("name", ["poisson", "exponential", "student_t", "gamma", "beta"])
 def test_further_likelihoods_single_layer_elbo_and_torch_gradient(name):
     """One-layer DGP with each further likelihood: numpy and torch backends agree on the ELBO and the torch gradient matches central
     differences for q_mu, Z and (StudentT) the raw scale."""
     rng = np.random.RandomState(11)
     N, D, M, S = 12, 2, 6, 3
     X = rng.randn(N, D)
-    Y = {"poisson": rng.poisson(2.0, (N, 1)).astype(float), "exponential": rng.exponential(1.5, (N, 1)), "student_t": rng.randn(N, 1)}[name]
+    Y = {"poisson": rng.poisson(2.0, (N, 1)).astype(float), "exponential": rng.exponential(1.5, (N, 1)), "student_t": rng.randn(N, 1),
+         "gamma": rng.exponential(1.5, (N, 1)), "beta": rng.uniform(0.05, 0.95, (N, 1))}[name]
     lds = O.init_layers_linear(X, Y, X[:M].copy(), [dict(kind="rbf", input_dim=D, variance=1.2, lengthscales=0.9, ARD=False, white_variance=None)],
                                white=False, jitter=1e-6)
     lds[0]["q_mu"] = 0.3 * rng.randn(M, 1)
@@ -583,8 +589,8 @@ def test_further_likelihoods_single_layer_elbo_and_torch_gradient(name):
     e = OM.elbo(spec, state, X, Y, zs, S, num_data=40)
     et, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=40)
     assert abs(et - e) < 1e-10 * max(1.0, abs(e))
-    keys = ["l0.q_mu", "l0.Z"] + (["lik_variance_raw"] if name == "student_t" else [])
-    assert (name == "student_t") == ("lik_variance_raw" in state)
+    keys = ["l0.q_mu", "l0.Z"] + (["lik_variance_raw"] if name in ("student_t", "gamma", "beta") else [])
+    assert (name in ("student_t", "gamma", "beta")) == ("lik_variance_raw" in state)
     for k in keys:
         st = {kk: np.array(vv, dtype=np.float64) for kk, vv in state.items()}
         idx = tuple(0 for _ in range(st[k].ndim))
