@@ -1527,7 +1527,7 @@ int bigchol_build(dsdgp_ctx* ctx, BigChol& P, double* W, double* Linv, double* L
     g.alpha = alpha; g.beta = beta; g.lower_only = lower;
     return g;
   };
-  static const bool lookahead_off = getenv("DSDGP_CHOL_LOOKAHEAD") && atoi(getenv("DSDGP_CHOL_LOOKAHEAD")) == 0;      // (A/B aid)
+  const bool lookahead_off = getenv("DSDGP_CHOL_LOOKAHEAD") && atoi(getenv("DSDGP_CHOL_LOOKAHEAD")) == 0;      // (A/B aid; read per plan)
   // the wide-update workgroups of the look-ahead form each hold a whole CU (the factor launch's LDS): beyond 16 blocks the plain sequence
   P.lookahead = !from_tri && !lookahead_off && P.nb >= 2 && P.nb <= 16;
   P.dinv = Linv ? Linv : Tbuf;

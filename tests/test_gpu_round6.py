@@ -303,6 +303,48 @@ def test_lookahead_blocked_cholesky_in_the_model_against_the_oracle(M, L, white)
     assert_allclose(model._build_likelihood(X, Y, zs=zs), OM.elbo(spec, state2, X, Y, zs, S, num_data=500), rtol=1e-7)
 
 
+@pytest.mark.parametrize("M,L", [(300, 2), (570, 1)])
+def test_plain_blocked_sequence_still_matches_the_oracle(monkeypatch, M, L):
+    """`DSDGP_CHOL_LOOKAHEAD=0` (read when a plan is built): panel and trailing update as GEMM launches, the inverse by recursive doubling —
+    the form that remains for more than 16 blocks — against the oracle, white = True (reads Lu)."""
+    monkeypatch.setenv("DSDGP_CHOL_LOOKAHEAD", "0")
+    rng = np.random.RandomState(M)
+    N, D, S = 24, 3, 2
+    X, Y = rng.randn(N, D), rng.randn(N, 2)
+    Z = rng.randn(M, D) * 2.0
+    spec, state, model = make_case(X, Y, Z, [kern_spec("matern52", D, 1.3, 0.9)] * L, white=True, S=S, num_data=500)
+    zs = [rng.randn(S, N, D) for _ in range(L - 1)] + [rng.randn(S, N, 2)]
+    ref, g = OM.elbo_and_grad(spec, state, X, Y, zs, S, num_data=500)
+    assert_allclose(model._build_likelihood(X, Y, zs=zs, with_grad=True), ref, rtol=1e-8)
+    grads = model.engine().gradient_dict()
+    for k in g:
+        assert np.max(np.abs(-g[k] - np.asarray(grads[k]))) <= 1e-6 * (np.max(np.abs(g[k])) + 1e-12), k
+
+
+def test_lookahead_cholesky_batch_with_one_indefinite_matrix():
+    """dsdgp_potrf on a batch whose middle matrix loses positive definiteness in its third block: the call reports that pivot, the
+    other matrices of the batch come out factored."""
+    import ctypes as C
+    from doubly_stochastic_dgp.engine import Context
+    ctx = Context.get()
+    n, batch = 640, 3
+    rng = np.random.RandomState(4)
+    A0 = rng.randn(n, n)
+    A0 = A0 @ A0.T + n * np.eye(n)
+    A = np.stack([A0, A0.copy(), 2.0 * A0])
+    A[1, 300, :] = 0.0
+    A[1, :, 300] = 0.0
+    A[1, 300, 300] = -1.0
+    dA = ctx.to_device(A)
+    info = C.c_int(0)
+    ctx.sync()
+    rc = ctx.lib.dsdgp_potrf(ctx.handle, batch, n, C.c_void_p(dA.data_ptr()), n, n * n, C.byref(info))
+    assert rc == _lib.ERR_NOT_SPD and info.value == 301
+    L = dA.cpu().numpy()
+    for b in (0, 2):
+        assert_allclose(np.tril(L[b]), np.linalg.cholesky(A[b]), rtol=1e-10, atol=1e-10)
+
+
 def test_lookahead_cholesky_reports_the_failing_pivot_of_a_later_block():
     import ctypes as C
     from doubly_stochastic_dgp.engine import Context
